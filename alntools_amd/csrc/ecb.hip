@@ -1,0 +1,1209 @@
+// libecb -- equivalence-class builder for alntools' bam2ec / bam2emase hot path on MI355X (gfx950).
+//
+// What the reference does per alignment in Python (alntools/bam_utils.py:258-344), per merge
+// (:680-724) and per EC (:788-847) is done here by three groups of kernels:
+//
+//   k_stream   one pass over the record tuples (12 B/record, coalesced 16-B loads).  A workgroup
+//              walks a contiguous slice of the stream tile by tile (2048 records).  Per tile it
+//              (a) applies the record filter (bam_utils.py:264-270) and finds read heads from the
+//                  host's run counter (bam_utils.py:289-320);
+//              (b) inserts every valid record into an LDS open-addressing table that is cut into one
+//                  private range per read (2 slots per record of the read): key = locus, value = OR of
+//                  haplotype bits -- this is the duplicate collapse of bam_utils.py:322-325 and the
+//                  per-(EC,target,haplotype) bit test of bam_utils.py:800-819 in one LDS atomic;
+//              (c) one lane per read walks its range, sums a 2x64-bit mix over the distinct
+//                  (locus, mask) pairs -- an order-independent 126-bit set hash, the stand-in for the
+//                  sorted string key of bam_utils.py:307 -- and upserts the global EC table
+//                  (count += 1, first = min(read index): bam_utils.py:309-312, 688-698).  The lane that
+//                  creates an EC copies its pairs into the key arena.
+//   k_slow     the same for single reads that do not fit a tile or hit a full table (one workgroup per
+//              read, global scratch table).
+//   finalize   rank ECs by first appearance (bitmap + scan: bam_utils.py:682-698), exclusive scan of
+//              row lengths, sort each row by locus and emit CSR A / N (bam_utils.py:835-847,
+//              bin_utils.py:208-211).
+//
+// Integer / indexing work only: no MFMA.  The bound is HBM bandwidth.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ecb.h"
+
+namespace {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+constexpr int TPB = 256;             // threads per workgroup (4 waves of 64)
+constexpr int RPL = 8;               // records per lane per tile (2 x 16-byte loads per stream)
+constexpr int TILE = TPB * RPL;      // records per tile
+constexpr u32 MAX_PROBE = 256;       // EC-table probes before a read is deferred to k_slow
+
+constexpr u32 ERR_CONTRACT = 1u;     // device error bits (Counters::err)
+constexpr u32 ERR_RANGE = 2u;
+constexpr u32 ERR_ARENA = 4u;
+constexpr u32 ERR_QUEUE = 8u;
+
+struct Slot {                        // 32 bytes, one EC
+    u64 lo, hi;                      // 126-bit set hash, both non-zero once claimed
+    u32 count;                       // reads in this EC
+    u32 first_inv;                   // ~(smallest read index)  (atomicMax on zero-initialised memory)
+    u32 off, n;                      // key = arena[off .. off+n)
+};
+
+struct Counters {
+    u64 all, valid;                  // records offered / passing the filter
+    u64 arena_top;                   // pairs used in the key arena
+    u64 n_queue;                     // reads deferred to k_slow
+    u64 n_ecs;                       // ECs created
+    u32 err;
+    u32 full;                        // set when a read found no EC-table slot: workgroups park, host grows the table
+};
+
+// ---------------------------------------------------------------------------------------------
+// hashing
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 mix64(u64 z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+// contribution of one (locus, mask) pair to the two 64-bit lanes of the set hash
+__device__ __forceinline__ void pair_hash(u32 locus, u32 mask, u64& a, u64& b) {
+    u64 x = ((u64)locus << 32) | mask;
+    a = mix64(x + 0x9E3779B97F4A7C15ull);
+    b = mix64((~x) * 0xFF51AFD7ED558CCDull + 0xC4CEB9FE1A85EC53ull);
+}
+__device__ __forceinline__ void finish_hash(u64 s1, u64 s2, u32 n, u64& lo, u64& hi) {
+    lo = mix64(s1 ^ ((u64)n * 0xD6E8FEB86659FD93ull)) | 1ull;
+    hi = mix64(s2 + n) | 1ull;
+}
+
+// record filter, bam_utils.py:264-270 (host bits 12/13 carry the two non-flag terms)
+__device__ __forceinline__ bool rec_valid(u32 hf) {
+    if (hf & 0x4u) return false;
+    if (hf & 0x1u) {
+        if ((hf & 0x80u) || !(hf & 0x2u) || (hf & (ECB_FLAG_MATE_OTHER_REF | ECB_FLAG_NEXT_POS_NEG))) return false;
+    }
+    return true;
+}
+
+// EC-table upsert.  Returns slot index, or ~0 if no slot within MAX_PROBE (table too full).
+// *created is set for the one caller that claimed the slot.
+__device__ __forceinline__ u64 table_upsert(Slot* table, u64 cap_mask, u64 lo, u64 hi, u32 add, u32 first,
+                                            bool* created) {
+    u64 j = lo & cap_mask;
+    *created = false;
+    for (u32 probe = 0; probe < MAX_PROBE; ++probe, j = (j + 1) & cap_mask) {
+        Slot* s = table + j;
+        // fast path: a plain load that already shows our key is always right (keys never change)
+        u64 clo = s->lo, chi = s->hi;
+        if (!(clo == lo && chi == hi)) {
+            clo = atomicCAS(&s->lo, 0ull, lo);
+            if (clo != 0ull && clo != lo) continue;
+            chi = atomicCAS(&s->hi, 0ull, hi);
+            if (chi == 0ull) *created = true;
+            else if (chi != hi) continue;
+        }
+        atomicAdd(&s->count, add);
+        atomicMax(&s->first_inv, ~first);
+        return j;
+    }
+    return ~0ull;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_stream
+// ---------------------------------------------------------------------------------------------
+struct StreamArgs {
+    const u32* rid; const u32* loc; const u32* hf; const int* pos;
+    u64 n, chunk;
+    u32 prev_rid;                    // read_id of the record before this batch (0xFFFFFFFF at stream start)
+    u32 n_loci, n_haps;
+    Slot* table; u64 cap_mask;
+    uint2* arena; u64 arena_cap;
+    Counters* ctr;
+    u32* read_slot;                  // slot of every read (indexed by read_id)
+    int* rng_min; int* rng_max;      // per (locus*H + hap), or null
+    u64* queue; u64 queue_cap;       // head record index of deferred reads
+    u64* resume;                     // per workgroup {next record to process, records counted up to}
+};
+
+__global__ __launch_bounds__(TPB) void k_stream(StreamArgs A) {
+    __shared__ unsigned short seg[TILE + 2];   // tile-relative start of every read in the tile
+    __shared__ u32 tkey[2 * TILE];             // per-read locus tables: key = locus + 1, 0 = empty
+    __shared__ u32 tmask[2 * TILE];
+    __shared__ u32 s_err;
+    __shared__ u64 s_red[2 * (TPB / 64)];
+
+    const u32 tid = threadIdx.x, lane = tid & 63u;
+    const u64 c0 = (u64)blockIdx.x * A.chunk;
+    if (c0 >= A.n) return;
+    const u64 c1 = min(c0 + A.chunk, A.n);
+
+    for (u32 q = tid; q < 2 * TILE; q += TPB) { tkey[q] = 0; tmask[q] = 0; }
+    if (tid == 0) s_err = 0;
+    u64 my_all = 0, my_valid = 0;
+    u64 p = A.resume[2 * blockIdx.x], counted = A.resume[2 * blockIdx.x + 1];
+    __syncthreads();
+
+    while (p < c1) {
+        // the EC table filled up somewhere: park here; the host grows it and relaunches
+        if (__hip_atomic_load(&A.ctr->full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        const u64 tb = p & ~(u64)3;
+        const u64 te = min(tb + (u64)TILE, A.n);
+        const u32 base = (p == 0 ? A.prev_rid : A.rid[p - 1]) + 1u;      // read index of the first head >= p
+        const u32 nr = A.rid[te - 1] - base + 1u;                        // heads in [p, te)
+        const u32 nown = (c1 >= te) ? nr : (A.rid[c1 - 1] - base + 1u);  // heads in [p, c1): ours
+        const bool last_complete = (te == A.n);                          // batches end on a read boundary
+        const u32 nrc = last_complete ? nr : (nr ? nr - 1u : 0u);
+        const u32 nproc = min(nrc, nown);
+        const u64 cnt_hi = min(te, c1);
+        if (nr > (u32)(te - p)) {            // more heads than records: run counter is broken
+            if (tid == 0) atomicOr(&A.ctr->err, ERR_CONTRACT);
+            return;
+        }
+
+        // ---- (a) load, filter, heads -------------------------------------------------------
+        u32 r_loc[RPL], r_hf[RPL], r_rl[RPL];
+        u32 r_ok = 0;                        // bit j: record j is valid and belongs to a read we process
+        u32 bad = 0;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const u64 i0 = tb + (u64)g * (TILE / 2) + 4u * tid;
+            u32 rr[4], ll[4], hh[4];
+            if (i0 + 4 <= te) {
+                uint4 v = *reinterpret_cast<const uint4*>(A.rid + i0); rr[0] = v.x; rr[1] = v.y; rr[2] = v.z; rr[3] = v.w;
+                v = *reinterpret_cast<const uint4*>(A.loc + i0);       ll[0] = v.x; ll[1] = v.y; ll[2] = v.z; ll[3] = v.w;
+                v = *reinterpret_cast<const uint4*>(A.hf + i0);        hh[0] = v.x; hh[1] = v.y; hh[2] = v.z; hh[3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool in = i0 + j < te;
+                    rr[j] = in ? A.rid[i0 + j] : 0u; ll[j] = in ? A.loc[i0 + j] : 0u; hh[j] = in ? A.hf[i0 + j] : 0x4u;
+                }
+            }
+            u32 prev = (i0 == 0) ? A.prev_rid : (i0 <= te ? A.rid[i0 - 1] : 0u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u64 i = i0 + j;
+                const int k = g * 4 + j;
+                const bool in = (i >= p) && (i < te);
+                const bool ok = rec_valid(hh[j]);
+                const u32 step = rr[j] - prev;
+                const u32 rl = rr[j] - base;
+                r_loc[k] = ll[j]; r_hf[k] = hh[j]; r_rl[k] = rl;
+                if (in) {
+                    if (step > 1u || (step == 1u && !ok)) bad |= ERR_CONTRACT;
+                    if (step == 1u && rl <= (u32)TILE) seg[rl] = (unsigned short)(i - tb);
+                    if (ok) {
+                        const u32 hap = (hh[j] >> ECB_HAP_SHIFT) & 0xFFu;
+                        if (ll[j] >= A.n_loci || hap >= A.n_haps) bad |= ERR_RANGE;
+                        else if (rl < nproc) r_ok |= 1u << k;
+                    }
+                    if (i >= counted && i < cnt_hi) {
+                        my_all += 1;
+                        if (ok) {
+                            my_valid += 1;
+                            if (A.rng_min && !(bad & ERR_RANGE)) {
+                                const u32 hap = (hh[j] >> ECB_HAP_SHIFT) & 0xFFu;
+                                const u64 sl = (u64)ll[j] * A.n_haps + hap;
+                                const int ps = A.pos[i];
+                                atomicMin(A.rng_min + sl, ps);
+                                atomicMax(A.rng_max + sl, ps);
+                            }
+                        }
+                    }
+                }
+                prev = rr[j];
+            }
+        }
+        if (tid == 0) seg[nr] = (unsigned short)(te - tb);      // end sentinel (nr <= TILE)
+        if (bad) atomicOr(&s_err, bad);
+        __syncthreads();
+        if (s_err) {                                            // never index LDS with a broken run counter
+            if (tid == 0) atomicOr(&A.ctr->err, s_err);
+            return;
+        }
+        const u32 next_head = (nrc < nr) ? seg[nrc] : 0u;       // head of the read left incomplete
+
+        // ---- (b) per-read locus tables in LDS ----------------------------------------------
+#pragma unroll
+        for (int k = 0; k < RPL; ++k) {
+            if (r_ok >> k & 1u) {
+                const u32 s2 = 2u * seg[r_rl[k]], len2 = 2u * seg[r_rl[k] + 1] - s2;
+                const u32 key = r_loc[k] + 1u;
+                const u32 bit = 1u << ((r_hf[k] >> ECB_HAP_SHIFT) & 0xFFu);
+                u32 q = s2 + __umulhi(r_loc[k] * 0x9E3779B1u, len2);
+                for (;;) {
+                    const u32 old = atomicCAS(&tkey[q], 0u, key);
+                    if (old == 0u || old == key) { atomicOr(&tmask[q], bit); break; }
+                    if (++q == s2 + len2) q = s2;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- (c) one lane per read: set hash, EC upsert ------------------------------------
+        for (u32 k0 = 0; k0 < nproc; k0 += TPB) {
+            const u32 k = k0 + tid;
+            const bool act = k < nproc;
+            u32 s2 = 0, e2 = 0, npairs = 0;
+            u64 s_a = 0, s_b = 0;
+            if (act) {
+                s2 = 2u * seg[k]; e2 = 2u * seg[k + 1];
+                for (u32 q = s2; q < e2; ++q) {
+                    const u32 key = tkey[q];
+                    if (key) { u64 a, b; pair_hash(key - 1u, tmask[q], a, b); s_a += a; s_b += b; ++npairs; }
+                }
+            }
+            bool created = false;
+            u64 slot = ~0ull;
+            if (act) {
+                u64 lo, hi;
+                finish_hash(s_a, s_b, npairs, lo, hi);
+                slot = table_upsert(A.table, A.cap_mask, lo, hi, 1u, base + k, &created);
+                if (slot == ~0ull) {                            // table too full here: defer the read
+                    atomicExch(&A.ctr->full, 1u);
+                    const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
+                    if (qi < A.queue_cap) A.queue[qi] = tb + seg[k]; else atomicOr(&A.ctr->err, ERR_QUEUE);
+                } else {
+                    A.read_slot[base + k] = (u32)slot;
+                }
+            }
+            // key arena: one allocation per wave for all the ECs its lanes created
+            const u32 want = created ? npairs : 0u;
+            u32 incl = want;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(incl, d); if (lane >= (u32)d) incl += t; }
+            const u32 total = __shfl(incl, 63);
+            const u64 n_created = __popcll(__ballot(created));
+            u64 wbase = 0;
+            if (total) {
+                if (lane == 63) {
+                    wbase = atomicAdd(&A.ctr->arena_top, (u64)total);
+                    atomicAdd(&A.ctr->n_ecs, n_created);
+                }
+                wbase = __shfl(wbase, 63);
+            }
+            u64 off = wbase + incl - want;
+            const bool fits = off + want <= A.arena_cap;
+            if (created) {
+                if (fits) { A.table[slot].off = (u32)off; A.table[slot].n = npairs; }
+                else atomicOr(&A.ctr->err, ERR_ARENA);
+            }
+            if (act) {                                          // second walk: save the key, clear the range
+                for (u32 q = s2; q < e2; ++q) {
+                    const u32 key = tkey[q];
+                    if (key) {
+                        if (created && fits) A.arena[off++] = make_uint2(key - 1u, tmask[q]);
+                        tkey[q] = 0; tmask[q] = 0;
+                    }
+                }
+            }
+        }
+
+        counted = max(counted, cnt_hi);
+        if (te >= c1 && nown <= nrc) { p = c1; break; }         // every read that starts in our slice is done
+        if (nrc < nr) {
+            const u64 h = tb + next_head;
+            if (h == p) {                                       // a single read fills the whole tile
+                if (tid == 0) {
+                    const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
+                    if (qi < A.queue_cap) A.queue[qi] = p; else atomicOr(&A.ctr->err, ERR_QUEUE);
+                }
+                p = te;
+            } else {
+                p = h;
+            }
+        } else {
+            p = te;
+        }
+        __syncthreads();
+    }
+
+    if (tid == 0) { A.resume[2 * blockIdx.x] = p; A.resume[2 * blockIdx.x + 1] = counted; }
+    // records offered / valid: one atomic pair per workgroup
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { my_all += __shfl_down(my_all, d); my_valid += __shfl_down(my_valid, d); }
+    if (lane == 0) { s_red[2 * (tid >> 6)] = my_all; s_red[2 * (tid >> 6) + 1] = my_valid; }
+    __syncthreads();
+    if (tid == 0) {
+        u64 a = 0, v = 0;
+        for (int w = 0; w < TPB / 64; ++w) { a += s_red[2 * w]; v += s_red[2 * w + 1]; }
+        atomicAdd(&A.ctr->all, a);
+        atomicAdd(&A.ctr->valid, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_slow: one workgroup per deferred read (longer than a tile, or bounced off a full table).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_slow_len(const u32* rid, u64 n, const u64* queue, u64 nq, u64* len) {
+    // length in records of each queued read (its head index .. the next change of read_id)
+    const u64 q = blockIdx.x;
+    if (q >= nq) return;
+    __shared__ u64 s_end;
+    const u64 h = queue[q];
+    const u32 r0 = rid[h];
+    if (threadIdx.x == 0) s_end = n;
+    __syncthreads();
+    for (u64 b = h; b < n; b += TPB) {
+        const u64 i = b + threadIdx.x;
+        if (i < n && rid[i] != r0) atomicMin(&s_end, i);
+        __syncthreads();
+        const bool found = (s_end != n);
+        __syncthreads();
+        if (found) break;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) len[q] = s_end - h;
+}
+
+struct SlowArgs {
+    const u32* rid; const u32* loc; const u32* hf;
+    const u64* queue; const u64* len; const u64* scr_off;   // per queued read
+    u32* scr_key; u32* scr_mask;                            // global scratch tables (zeroed)
+    u32 n_loci, n_haps;
+    Slot* table; u64 cap_mask;
+    uint2* arena; u64 arena_cap;
+    Counters* ctr;
+    u32* read_slot;
+    u64* requeue; u64* n_requeue;                           // reads that still found no slot
+};
+
+__global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
+    const u64 q = blockIdx.x;
+    const u32 tid = threadIdx.x, lane = tid & 63u;
+    const u64 h = A.queue[q], L = A.len[q];
+    const u64 cap2 = 2 * L;
+    u32* key = A.scr_key + A.scr_off[q];
+    u32* msk = A.scr_mask + A.scr_off[q];
+    __shared__ u64 s_a[TPB / 64], s_b[TPB / 64];
+    __shared__ u32 s_n[TPB / 64];
+    __shared__ u64 s_off;
+    __shared__ u32 s_created, s_cnt, s_fits;
+
+    for (u64 i = tid; i < L; i += TPB) {
+        const u32 f = A.hf[h + i];
+        if (!rec_valid(f)) continue;
+        const u32 lc = A.loc[h + i], hap = (f >> ECB_HAP_SHIFT) & 0xFFu;
+        if (lc >= A.n_loci || hap >= A.n_haps) { atomicOr(&A.ctr->err, ERR_RANGE); continue; }
+        u64 p = __umul64hi((u64)(lc * 0x9E3779B1u) << 32, cap2);
+        for (;;) {
+            const u32 old = atomicCAS(&key[p], 0u, lc + 1u);
+            if (old == 0u || old == lc + 1u) { atomicOr(&msk[p], 1u << hap); break; }
+            if (++p == cap2) p = 0;
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    u64 a = 0, b = 0; u32 np = 0;
+    for (u64 p = tid; p < cap2; p += TPB) {
+        const u32 k = __hip_atomic_load(&key[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k) {
+            const u32 m = __hip_atomic_load(&msk[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            u64 x, y; pair_hash(k - 1u, m, x, y); a += x; b += y; ++np;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { a += __shfl_down(a, d); b += __shfl_down(b, d); np += __shfl_down(np, d); }
+    if (lane == 0) { s_a[tid >> 6] = a; s_b[tid >> 6] = b; s_n[tid >> 6] = np; }
+    __syncthreads();
+    if (tid == 0) {
+        a = b = 0; np = 0;
+        for (int w = 0; w < TPB / 64; ++w) { a += s_a[w]; b += s_b[w]; np += s_n[w]; }
+        u64 lo, hi; finish_hash(a, b, np, lo, hi);
+        bool created = false;
+        const u32 r0 = A.rid[h];
+        const u64 slot = table_upsert(A.table, A.cap_mask, lo, hi, 1u, r0, &created);
+        s_created = 0; s_cnt = 0; s_fits = 0; s_off = 0;
+        if (slot == ~0ull) {
+            A.requeue[atomicAdd(A.n_requeue, 1ull)] = h;
+        } else {
+            A.read_slot[r0] = (u32)slot;
+            if (created) {
+                const u64 off = atomicAdd(&A.ctr->arena_top, (u64)np);
+                atomicAdd(&A.ctr->n_ecs, 1ull);
+                s_created = 1; s_off = off; s_fits = (off + np <= A.arena_cap);
+                if (s_fits) { A.table[slot].off = (u32)off; A.table[slot].n = np; }
+                else atomicOr(&A.ctr->err, ERR_ARENA);
+            }
+        }
+    }
+    __syncthreads();
+    for (u64 p = tid; p < cap2; p += TPB) {
+        const u32 k = __hip_atomic_load(&key[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k) {
+            if (s_created && s_fits) {
+                const u32 m = __hip_atomic_load(&msk[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                A.arena[s_off + atomicAdd(&s_cnt, 1u)] = make_uint2(k - 1u, m);
+            }
+            key[p] = 0; msk[p] = 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// table maintenance: grow (rehash), compact, merge
+// ---------------------------------------------------------------------------------------------
+__global__ void k_rehash(const Slot* old_t, u64 old_cap, Slot* new_t, u64 new_mask) {
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < old_cap; i += (u64)gridDim.x * blockDim.x) {
+        const Slot s = old_t[i];
+        if (!s.hi) continue;
+        u64 j = s.lo & new_mask;
+        for (;; j = (j + 1) & new_mask) {                // new table is larger and keys are distinct
+            if (atomicCAS(&new_t[j].lo, 0ull, s.lo) == 0ull) {
+                new_t[j].hi = s.hi; new_t[j].count = s.count; new_t[j].first_inv = s.first_inv;
+                new_t[j].off = s.off; new_t[j].n = s.n;
+                break;
+            }
+        }
+    }
+}
+
+__global__ void k_remap_read_slot(u32* read_slot, u64 n_reads, const Slot* old_t, const Slot* new_t, u64 new_mask) {
+    for (u64 r = blockIdx.x * (u64)blockDim.x + threadIdx.x; r < n_reads; r += (u64)gridDim.x * blockDim.x) {
+        const u32 os = read_slot[r];
+        if (os == 0xFFFFFFFFu) continue;
+        const u64 lo = old_t[os].lo, hi = old_t[os].hi;
+        u64 j = lo & new_mask;
+        while (!(new_t[j].lo == lo && new_t[j].hi == hi)) j = (j + 1) & new_mask;
+        read_slot[r] = (u32)j;
+    }
+}
+
+// occupied slots -> dense list (order irrelevant: ranks come from `first`)
+__global__ __launch_bounds__(TPB) void k_compact(const Slot* table, u64 cap, u32* list, u64 max_list, u64* n_list) {
+    __shared__ u32 s_cnt;
+    __shared__ u64 s_base;
+    for (u64 b = (u64)blockIdx.x * TPB; b < cap; b += (u64)gridDim.x * TPB) {
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        const u64 i = b + threadIdx.x;
+        const bool occ = i < cap && table[i].hi != 0ull;
+        u32 my = 0;
+        if (occ) my = atomicAdd(&s_cnt, 1u);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(n_list, (u64)s_cnt);
+        __syncthreads();
+        if (occ && s_base + my < max_list) list[s_base + my] = (u32)i;
+        __syncthreads();
+    }
+}
+
+// serialise: entry e = slot list[e] with first rebased to the global read numbering
+__global__ void k_export_entries(const Slot* table, const u32* list, u64 n, Slot* out, u32 read_base) {
+    const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    Slot s = table[list[e]];
+    s.first_inv = ~(~s.first_inv + read_base);
+    out[e] = s;
+}
+
+__global__ void k_merge(const Slot* ent, u64 n, const uint2* pairs, u64 n_pairs, Slot* table, u64 cap_mask,
+                        uint2* arena, u64 arena_cap, Counters* ctr) {
+    const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const Slot s = ent[e];
+    if ((u64)s.off + s.n > n_pairs) { atomicOr(&ctr->err, ERR_CONTRACT); return; }
+    bool created = false;
+    const u64 j = table_upsert(table, cap_mask, s.lo, s.hi, s.count, ~s.first_inv, &created);
+    if (j == ~0ull) { atomicAdd(&ctr->n_queue, 1ull); return; }   // host sizes the table so this cannot happen
+    if (created) {
+        const u64 off = atomicAdd(&ctr->arena_top, (u64)s.n);
+        atomicAdd(&ctr->n_ecs, 1ull);
+        if (off + s.n > arena_cap) { atomicOr(&ctr->err, ERR_ARENA); return; }
+        for (u32 t = 0; t < s.n; ++t) arena[off + t] = pairs[s.off + t];
+        table[j].off = (u32)off; table[j].n = s.n;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// finalize: rank by first appearance, CSR emit
+// ---------------------------------------------------------------------------------------------
+__global__ void k_mark_first(const Slot* table, const u32* list, u64 n, u32* bitmap) {
+    const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const u32 f = ~table[list[e]].first_inv;
+    atomicOr(&bitmap[f >> 5], 1u << (f & 31u));
+}
+__global__ void k_popc(const u32* in, u64 n, u32* out) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = __popc(in[i]);
+}
+
+// exclusive scan of u32 (three launches): per-block sums, scan of the sums, per-block scan + offset
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_BLOCK = TPB * SCAN_ITEMS;
+__device__ __forceinline__ u32 block_excl_scan(u32 v, u32* total) {   // over TPB threads
+    __shared__ u32 s_w[TPB / 64];
+    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    u32 incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(incl, d); if (lane >= (u32)d) incl += t; }
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    u32 add = 0, tot = 0;
+    for (u32 k = 0; k < TPB / 64; ++k) { if (k < w) add += s_w[k]; tot += s_w[k]; }
+    __syncthreads();
+    *total = tot;
+    return add + incl - v;
+}
+__global__ __launch_bounds__(TPB) void k_scan_sums(const u32* in, u64 n, u32* sums) {
+    const u64 b0 = (u64)blockIdx.x * SCAN_BLOCK;
+    u32 s = 0;
+    for (int k = 0; k < SCAN_ITEMS; ++k) { const u64 i = b0 + (u64)threadIdx.x * SCAN_ITEMS + k; if (i < n) s += in[i]; }
+    u32 tot; block_excl_scan(s, &tot);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(TPB) void k_scan_top(u32* sums, u64 nb, u32* grand) {   // one block
+    u32 carry = 0;
+    for (u64 b0 = 0; b0 < nb; b0 += TPB) {
+        const u64 i = b0 + threadIdx.x;
+        const u32 v = i < nb ? sums[i] : 0u;
+        u32 tot; const u32 ex = block_excl_scan(v, &tot);
+        if (i < nb) sums[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *grand = carry;
+}
+__global__ __launch_bounds__(TPB) void k_scan_apply(const u32* in, u64 n, const u32* sums, u32* out) {
+    const u64 b0 = (u64)blockIdx.x * SCAN_BLOCK;
+    u32 v[SCAN_ITEMS], s = 0;
+    for (int k = 0; k < SCAN_ITEMS; ++k) { const u64 i = b0 + (u64)threadIdx.x * SCAN_ITEMS + k; v[k] = i < n ? in[i] : 0u; s += v[k]; }
+    u32 tot; u32 ex = block_excl_scan(s, &tot) + sums[blockIdx.x];
+    for (int k = 0; k < SCAN_ITEMS; ++k) { const u64 i = b0 + (u64)threadIdx.x * SCAN_ITEMS + k; if (i < n) out[i] = ex; ex += v[k]; }
+}
+
+__global__ void k_rank(const Slot* table, const u32* list, u64 n, const u32* bitmap, const u32* wprefix,
+                       u32* order, u32* rowlen, u32* rank_of_slot) {
+    const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const u32 si = list[e];
+    const u32 f = ~table[si].first_inv;
+    const u32 r = wprefix[f >> 5] + __popc(bitmap[f >> 5] & ((1u << (f & 31u)) - 1u));
+    order[r] = si;
+    rowlen[r] = table[si].n;
+    rank_of_slot[si] = r;
+}
+
+// one wave per EC row: rank every (locus, mask) pair by locus and write it in place
+__global__ __launch_bounds__(TPB) void k_emit(const Slot* table, const u32* order, u64 n, const uint2* arena,
+                                               const u32* indptr, int* indices, int* data, int* counts) {
+    const u64 e = ((u64)blockIdx.x * TPB + threadIdx.x) >> 6;
+    const u32 lane = threadIdx.x & 63u;
+    if (e >= n) return;
+    const Slot s = table[order[e]];
+    const uint2* src = arena + s.off;
+    const u32 dst = indptr[e];
+    for (u32 i = lane; i < s.n; i += 64) {
+        const uint2 pi = src[i];
+        u32 r = 0;
+        for (u32 j = 0; j < s.n; ++j) r += src[j].x < pi.x;   // loci within a key are distinct
+        indices[dst + r] = (int)pi.x;
+        data[dst + r] = (int)pi.y;
+    }
+    if (lane == 0) counts[e] = (int)s.count;
+}
+
+__global__ void k_iota(int* out, u64 n) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int)i;
+}
+__global__ void k_read_ec(const u32* read_slot, u64 n, const u32* rank_of_slot, int* out) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = read_slot[i] == 0xFFFFFFFFu ? -1 : (int)rank_of_slot[read_slot[i]];
+}
+__global__ void k_range_len(const int* mn, const int* mx, u64 n, long long* out) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = mx[i] == INT_MIN ? 0ll : (long long)mx[i] - (long long)mn[i] + 1ll;
+}
+__global__ void k_fill_i32(int* p, u64 n, int v) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+}  // namespace
+
+// =============================================================================================
+// host side
+// =============================================================================================
+struct ecb_handle {
+    ecb_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool finalized = false;
+
+    Slot* table = nullptr; u64 cap = 0;
+    uint2* arena = nullptr; u64 arena_cap = 0;
+    Counters* ctr = nullptr;
+    Counters hctr{};                  // last read-back
+    u32* read_slot = nullptr; u64 read_slot_cap = 0;
+    int *rng_min = nullptr, *rng_max = nullptr;
+    u64* queue = nullptr; u64 queue_cap = 0;
+    u32 prev_rid = 0xFFFFFFFFu;       // read_id of the last record pushed so far
+    u64 n_reads = 0;
+    u64 reads_hi = 0;                 // read_slot entries [0, reads_hi) may be set (n_reads, or more mid-batch)
+    u64 extra_all = 0, extra_valid = 0, extra_reads = 0;   // counters merged in from other ranks
+
+    // host-pointer staging
+    u32 *st_rid = nullptr, *st_loc = nullptr, *st_hf = nullptr; int* st_pos = nullptr; u64 st_cap = 0;
+    std::vector<u32> c_rid, c_loc, c_hf; std::vector<int> c_pos;   // open read carried between pushes
+
+    // results
+    u32* list = nullptr; u64 n_list = 0;
+    u32 *order = nullptr, *rank_of_slot = nullptr, *indptr = nullptr;
+    int *indices = nullptr, *data = nullptr, *counts = nullptr;
+    ecb_sizes sizes{};
+
+    // profiling
+    bool prof = false; double prof_ms = 0; u64 prof_launches = 0, prof_records = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+std::string g_create_err;
+
+int fail(ecb_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (h) h->err = buf; else g_create_err = buf;
+    return code;
+}
+#define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+    return fail(h, ECB_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
+
+u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
+inline unsigned nblk(u64 n, unsigned per) { return (unsigned)((n + per - 1) / per); }
+
+int sync_counters(ecb_handle* h) {
+    HIPCHK(h, hipMemcpyAsync(&h->hctr, h->ctr, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->hctr.err & ERR_CONTRACT) return fail(h, ECB_ERR_CONTRACT, "read_id run counter violates the tuple contract (see ecb.h)");
+    if (h->hctr.err & ERR_RANGE) return fail(h, ECB_ERR_CONTRACT, "locus or haplotype index out of range in a valid record");
+    if (h->hctr.err & ERR_ARENA) return fail(h, ECB_ERR_TABLE_FULL, "EC key arena exhausted (%llu pairs): raise arena_capacity", (unsigned long long)h->arena_cap);
+    if (h->hctr.err & ERR_QUEUE) return fail(h, ECB_ERR_TABLE_FULL, "deferred-read queue exhausted");
+    return ECB_OK;
+}
+
+int grow_table(ecb_handle* h, u64 new_cap) {
+    Slot* nt = nullptr;
+    HIPCHK(h, hipMalloc(&nt, new_cap * sizeof(Slot)));
+    HIPCHK(h, hipMemsetAsync(nt, 0, new_cap * sizeof(Slot), h->stream));
+    k_rehash<<<2048, TPB, 0, h->stream>>>(h->table, h->cap, nt, new_cap - 1);
+    if (h->reads_hi)
+        k_remap_read_slot<<<2048, TPB, 0, h->stream>>>(h->read_slot, h->reads_hi, h->table, nt, new_cap - 1);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipFree(h->table));
+    h->table = nt; h->cap = new_cap;
+    return ECB_OK;
+}
+
+int ensure_read_slot(ecb_handle* h, u64 need) {
+    if (need <= h->read_slot_cap) return ECB_OK;
+    u64 nc = std::max<u64>(need, h->read_slot_cap * 2);
+    nc = std::max<u64>(nc, 1024);
+    u32* p = nullptr;
+    HIPCHK(h, hipMalloc(&p, nc * sizeof(u32)));
+    HIPCHK(h, hipMemsetAsync(p, 0xFF, nc * sizeof(u32), h->stream));
+    if (h->read_slot) {
+        HIPCHK(h, hipMemcpyAsync(p, h->read_slot, h->n_reads * sizeof(u32), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipFree(h->read_slot));
+    }
+    h->read_slot = p; h->read_slot_cap = nc;
+    return ECB_OK;
+}
+
+// deferred reads: measure, scratch, k_slow; grow the table and repeat while reads bounce
+int run_slow(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf, u64 n) {
+    u64 nq = std::min<u64>(h->hctr.n_queue, h->queue_cap);
+    u64* d_q = h->queue;
+    u64* d_requeue = nullptr;
+    int rc = ECB_OK;
+    while (nq) {
+        u64 *d_len = nullptr, *d_off = nullptr, *d_nre = nullptr;
+        HIPCHK(h, hipMalloc(&d_len, nq * sizeof(u64)));
+        HIPCHK(h, hipMalloc(&d_off, nq * sizeof(u64)));
+        HIPCHK(h, hipMalloc(&d_nre, sizeof(u64)));
+        u64* nre_buf = nullptr;
+        HIPCHK(h, hipMalloc(&nre_buf, nq * sizeof(u64)));
+        HIPCHK(h, hipMemsetAsync(d_nre, 0, sizeof(u64), h->stream));
+        k_slow_len<<<(unsigned)nq, TPB, 0, h->stream>>>(d_rid, n, d_q, nq, d_len);
+        std::vector<u64> len(nq), off(nq);
+        HIPCHK(h, hipMemcpyAsync(len.data(), d_len, nq * sizeof(u64), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        u64 tot = 0;
+        for (u64 i = 0; i < nq; ++i) { off[i] = tot; tot += 2 * len[i]; }
+        u32 *sk = nullptr, *sm = nullptr;
+        HIPCHK(h, hipMalloc(&sk, std::max<u64>(tot, 1) * sizeof(u32)));
+        HIPCHK(h, hipMalloc(&sm, std::max<u64>(tot, 1) * sizeof(u32)));
+        HIPCHK(h, hipMemsetAsync(sk, 0, tot * sizeof(u32), h->stream));
+        HIPCHK(h, hipMemsetAsync(sm, 0, tot * sizeof(u32), h->stream));
+        HIPCHK(h, hipMemcpyAsync(d_off, off.data(), nq * sizeof(u64), hipMemcpyHostToDevice, h->stream));
+        SlowArgs a{d_rid, d_loc, d_hf, d_q, d_len, d_off, sk, sm, h->cfg.n_loci, h->cfg.n_haplotypes,
+                   h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr, h->read_slot, nre_buf, d_nre};
+        k_slow<<<(unsigned)nq, TPB, 0, h->stream>>>(a);
+        u64 nre = 0;
+        HIPCHK(h, hipMemcpyAsync(&nre, d_nre, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
+        rc = sync_counters(h);
+        hipFree(d_len); hipFree(d_off); hipFree(d_nre); hipFree(sk); hipFree(sm);
+        if (d_requeue) hipFree(d_requeue);
+        d_requeue = nre_buf; d_q = nre_buf; nq = nre;
+        if (rc != ECB_OK) break;
+        if (nq) { rc = grow_table(h, h->cap * 4); if (rc != ECB_OK) break; }
+    }
+    if (d_requeue) hipFree(d_requeue);
+    return rc;
+}
+
+// one batch of whole reads, device-resident
+int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf, const int* d_pos, u64 n) {
+    if (n == 0) return ECB_OK;
+    u32 last_rid = 0;
+    HIPCHK(h, hipMemcpyAsync(&last_rid, d_rid + (n - 1), sizeof(u32), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const u64 reads_after = (u64)(u32)(last_rid + 1u);
+    if (reads_after < h->n_reads) return fail(h, ECB_ERR_CONTRACT, "read_id went backwards across pushes");
+    int rc = ensure_read_slot(h, reads_after);
+    if (rc != ECB_OK) return rc;
+    h->reads_hi = reads_after;
+    // keep the table at most half full before a batch (it grows again, via k_slow, if a batch overfills it)
+    while (h->hctr.n_ecs * 2 > h->cap) { rc = grow_table(h, h->cap * 4); if (rc != ECB_OK) return rc; }
+    int cus = 256;
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+    u64 blocks = std::min<u64>((u64)cus * 4, (n + 4 * TILE - 1) / (4 * TILE));
+    blocks = std::max<u64>(blocks, 1);
+    u64 chunk = (n + blocks - 1) / blocks;
+    chunk = (chunk + 3) & ~(u64)3;
+    blocks = (n + chunk - 1) / chunk;
+    // a parked launch defers at most the reads of the tiles in flight
+    const u64 need_q = blocks * (u64)TILE + 16;
+    if (h->queue_cap < need_q) {
+        if (h->queue) hipFree(h->queue);
+        h->queue_cap = need_q;
+        HIPCHK(h, hipMalloc(&h->queue, h->queue_cap * sizeof(u64)));
+    }
+    u64* d_resume = nullptr;
+    HIPCHK(h, hipMalloc(&d_resume, 2 * blocks * sizeof(u64)));
+    {
+        std::vector<u64> r0(2 * blocks);
+        for (u64 b = 0; b < blocks; ++b) r0[2 * b] = r0[2 * b + 1] = b * chunk;
+        HIPCHK(h, hipMemcpyAsync(d_resume, r0.data(), 2 * blocks * sizeof(u64), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    StreamArgs a{d_rid, d_loc, d_hf, d_pos, n, chunk, h->prev_rid, h->cfg.n_loci, h->cfg.n_haplotypes,
+                 h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr, h->read_slot,
+                 h->rng_min, h->rng_max, h->queue, h->queue_cap, d_resume};
+    for (;;) {
+        HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));   // per launch
+        HIPCHK(h, hipMemsetAsync(&h->ctr->full, 0, sizeof(u32), h->stream));
+        a.table = h->table; a.cap_mask = h->cap - 1;
+        if (h->prof) hipEventRecord(h->ev0, h->stream);
+        k_stream<<<(unsigned)blocks, TPB, 0, h->stream>>>(a);
+        if (h->prof) hipEventRecord(h->ev1, h->stream);
+        HIPCHK(h, hipGetLastError());
+        rc = sync_counters(h);
+        if (h->prof) {
+            float ms = 0; hipEventElapsedTime(&ms, h->ev0, h->ev1);
+            h->prof_ms += ms; h->prof_launches += 1;
+        }
+        if (rc != ECB_OK) break;
+        const bool parked = h->hctr.full != 0;
+        if (h->hctr.n_queue) { rc = run_slow(h, d_rid, d_loc, d_hf, n); if (rc != ECB_OK) break; }
+        if (!parked) break;
+        rc = grow_table(h, h->cap * 4);                 // some workgroups stopped early: more room, then resume
+        if (rc != ECB_OK) break;
+    }
+    hipFree(d_resume);
+    if (rc != ECB_OK) return rc;
+    if (h->prof) h->prof_records += n;
+    h->prev_rid = last_rid;
+    h->n_reads = reads_after;
+    return ECB_OK;
+}
+
+int ensure_staging(ecb_handle* h, u64 need) {
+    if (need <= h->st_cap) return ECB_OK;
+    if (h->st_rid) { hipFree(h->st_rid); hipFree(h->st_loc); hipFree(h->st_hf); if (h->st_pos) hipFree(h->st_pos); }
+    h->st_cap = std::max<u64>(need, h->cfg.max_batch_records);
+    HIPCHK(h, hipMalloc(&h->st_rid, h->st_cap * sizeof(u32)));
+    HIPCHK(h, hipMalloc(&h->st_loc, h->st_cap * sizeof(u32)));
+    HIPCHK(h, hipMalloc(&h->st_hf, h->st_cap * sizeof(u32)));
+    if (h->cfg.flags & ECB_F_RANGES) HIPCHK(h, hipMalloc(&h->st_pos, h->st_cap * sizeof(int)));
+    return ECB_OK;
+}
+
+// send carry[0..nc) ++ src[0..m) as one batch
+int stage_and_process(ecb_handle* h, const u32* rid, const u32* loc, const u32* hf, const int* pos, u64 m) {
+    const u64 nc = h->c_rid.size();
+    const u64 n = nc + m;
+    if (!n) return ECB_OK;
+    int rc = ensure_staging(h, n);
+    if (rc != ECB_OK) return rc;
+    const bool rg = (h->cfg.flags & ECB_F_RANGES) != 0;
+    if (nc) {
+        HIPCHK(h, hipMemcpyAsync(h->st_rid, h->c_rid.data(), nc * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->st_loc, h->c_loc.data(), nc * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->st_hf, h->c_hf.data(), nc * 4, hipMemcpyHostToDevice, h->stream));
+        if (rg) HIPCHK(h, hipMemcpyAsync(h->st_pos, h->c_pos.data(), nc * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    if (m) {
+        HIPCHK(h, hipMemcpyAsync(h->st_rid + nc, rid, m * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->st_loc + nc, loc, m * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->st_hf + nc, hf, m * 4, hipMemcpyHostToDevice, h->stream));
+        if (rg) HIPCHK(h, hipMemcpyAsync(h->st_pos + nc, pos, m * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));   // the carry vectors may be rewritten by the caller next
+    h->c_rid.clear(); h->c_loc.clear(); h->c_hf.clear(); h->c_pos.clear();
+    return process_batch(h, h->st_rid, h->st_loc, h->st_hf, rg ? h->st_pos : nullptr, n);
+}
+
+void free_results(ecb_handle* h) {
+    hipFree(h->list); hipFree(h->order); hipFree(h->rank_of_slot); hipFree(h->indptr);
+    hipFree(h->indices); hipFree(h->data); hipFree(h->counts);
+    h->list = h->order = h->rank_of_slot = h->indptr = nullptr;
+    h->indices = h->data = h->counts = nullptr;
+}
+
+int excl_scan(ecb_handle* h, const u32* in, u64 n, u32* out, u32* total) {
+    const u64 nb = std::max<u64>(1, (n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    u32* sums = nullptr;
+    HIPCHK(h, hipMalloc(&sums, (nb + 1) * sizeof(u32)));
+    k_scan_sums<<<(unsigned)nb, TPB, 0, h->stream>>>(in, n, sums);
+    k_scan_top<<<1, TPB, 0, h->stream>>>(sums, nb, sums + nb);
+    k_scan_apply<<<(unsigned)nb, TPB, 0, h->stream>>>(in, n, sums, out);
+    HIPCHK(h, hipMemcpyAsync(total, sums + nb, sizeof(u32), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipFree(sums));
+    return ECB_OK;
+}
+
+int compact_table(ecb_handle* h) {
+    if (h->list) { hipFree(h->list); h->list = nullptr; }
+    u64* d_n = nullptr;
+    HIPCHK(h, hipMalloc(&d_n, sizeof(u64)));
+    HIPCHK(h, hipMemsetAsync(d_n, 0, sizeof(u64), h->stream));
+    HIPCHK(h, hipMalloc(&h->list, std::max<u64>(h->hctr.n_ecs, 1) * sizeof(u32)));
+    k_compact<<<(unsigned)std::min<u64>(4096, (h->cap + TPB - 1) / TPB), TPB, 0, h->stream>>>(h->table, h->cap, h->list, std::max<u64>(h->hctr.n_ecs, 1), d_n);
+    HIPCHK(h, hipMemcpyAsync(&h->n_list, d_n, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipFree(d_n));
+    if (h->n_list != h->hctr.n_ecs) return fail(h, ECB_ERR_HIP, "internal: %llu occupied slots but %llu ECs created",
+                                                (unsigned long long)h->n_list, (unsigned long long)h->hctr.n_ecs);
+    return ECB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ecb_abi_version(void) { return ECB_ABI_VERSION; }
+
+int ecb_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* ecb_last_error(const ecb_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int ecb_create(const ecb_config* cfg, ecb_handle** out) {
+    if (!cfg || !out || cfg->struct_size != sizeof(ecb_config)) return fail(nullptr, ECB_ERR_ARG, "bad ecb_config (struct_size)");
+    if (cfg->n_loci == 0 || cfg->n_loci >= (1u << 31)) return fail(nullptr, ECB_ERR_ARG, "n_loci out of range");
+    if (cfg->n_haplotypes == 0 || cfg->n_haplotypes > 31) return fail(nullptr, ECB_ERR_ARG, "n_haplotypes must be 1..31 (A stores a bitmask in int32)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, ECB_ERR_NO_DEVICE, "no HIP device: libecb has no CPU path");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, ECB_ERR_ARG, "device %d out of range (%d present)", cfg->device, ndev);
+    ecb_handle* h = new ecb_handle();
+    h->cfg = *cfg;
+    h->device = cfg->device;
+    if (!h->cfg.ec_capacity) h->cfg.ec_capacity = 1ull << 22;
+    if (!h->cfg.arena_capacity) h->cfg.arena_capacity = 1ull << 26;
+    if (!h->cfg.max_batch_records) h->cfg.max_batch_records = 1ull << 24;
+    h->cap = std::max<u64>(next_pow2(h->cfg.ec_capacity), 1024);
+    h->arena_cap = std::min<u64>(h->cfg.arena_capacity, 1ull << 32);
+    auto bail = [&](int code, const char* what, hipError_t e) {
+        fail(nullptr, code, "%s: %s", what, hipGetErrorString(e));
+        ecb_destroy(h);
+        return code;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(h->device)) != hipSuccess) return bail(ECB_ERR_HIP, "hipSetDevice", e);
+    if ((e = hipStreamCreate(&h->stream)) != hipSuccess) return bail(ECB_ERR_HIP, "hipStreamCreate", e);
+    if ((e = hipMalloc(&h->table, h->cap * sizeof(Slot))) != hipSuccess) return bail(ECB_ERR_HIP, "hipMalloc(table)", e);
+    if ((e = hipMalloc(&h->arena, h->arena_cap * sizeof(uint2))) != hipSuccess) return bail(ECB_ERR_HIP, "hipMalloc(arena)", e);
+    if ((e = hipMalloc(&h->ctr, sizeof(Counters))) != hipSuccess) return bail(ECB_ERR_HIP, "hipMalloc(counters)", e);
+    hipMemsetAsync(h->table, 0, h->cap * sizeof(Slot), h->stream);
+    hipMemsetAsync(h->ctr, 0, sizeof(Counters), h->stream);
+    if (cfg->flags & ECB_F_RANGES) {
+        const u64 ns = (u64)cfg->n_loci * cfg->n_haplotypes;
+        if ((e = hipMalloc(&h->rng_min, ns * sizeof(int))) != hipSuccess) return bail(ECB_ERR_HIP, "hipMalloc(ranges)", e);
+        if ((e = hipMalloc(&h->rng_max, ns * sizeof(int))) != hipSuccess) return bail(ECB_ERR_HIP, "hipMalloc(ranges)", e);
+        k_fill_i32<<<nblk(ns, TPB), TPB, 0, h->stream>>>(h->rng_min, ns, INT_MAX);
+        k_fill_i32<<<nblk(ns, TPB), TPB, 0, h->stream>>>(h->rng_max, ns, INT_MIN);
+    }
+    hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
+    if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return bail(ECB_ERR_HIP, "init", e);
+    *out = h;
+    return ECB_OK;
+}
+
+void ecb_destroy(ecb_handle* h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    free_results(h);
+    hipFree(h->table); hipFree(h->arena); hipFree(h->ctr); hipFree(h->read_slot);
+    hipFree(h->rng_min); hipFree(h->rng_max); hipFree(h->queue);
+    hipFree(h->st_rid); hipFree(h->st_loc); hipFree(h->st_hf); hipFree(h->st_pos);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int ecb_push_device(ecb_handle* h, const void* d_read_id, const void* d_locus, const void* d_hapflag,
+                    const void* d_pos, size_t n) {
+    if (!h) return ECB_ERR_ARG;
+    if (h->finalized) return fail(h, ECB_ERR_STATE, "push after finalize");
+    if (n && (!d_read_id || !d_locus || !d_hapflag)) return fail(h, ECB_ERR_ARG, "null tuple stream");
+    if ((h->cfg.flags & ECB_F_RANGES) && n && !d_pos) return fail(h, ECB_ERR_ARG, "ECB_F_RANGES needs pos");
+    if (((uintptr_t)d_read_id | (uintptr_t)d_locus | (uintptr_t)d_hapflag) & 15) return fail(h, ECB_ERR_ARG, "device streams must be 16-byte aligned");
+    if (!h->c_rid.empty()) return fail(h, ECB_ERR_STATE, "ecb_push_device while a host push has an open read");
+    HIPCHK(h, hipSetDevice(h->device));
+    return process_batch(h, (const u32*)d_read_id, (const u32*)d_locus, (const u32*)d_hapflag, (const int*)d_pos, n);
+}
+
+int ecb_push(ecb_handle* h, const uint32_t* rid, const uint32_t* loc, const uint32_t* hf, const int32_t* pos, size_t n) {
+    if (!h) return ECB_ERR_ARG;
+    if (h->finalized) return fail(h, ECB_ERR_STATE, "push after finalize");
+    if (n && (!rid || !loc || !hf)) return fail(h, ECB_ERR_ARG, "null tuple stream");
+    const bool rg = (h->cfg.flags & ECB_F_RANGES) != 0;
+    if (rg && n && !pos) return fail(h, ECB_ERR_ARG, "ECB_F_RANGES needs pos");
+    HIPCHK(h, hipSetDevice(h->device));
+    u64 done = 0;
+    while (done < n) {
+        const u64 m = std::min<u64>(h->cfg.max_batch_records, n - done);
+        const u32 *r = rid + done, *l = loc + done, *f = hf + done;
+        const int* ps = rg ? pos + done : nullptr;
+        // records [cut, m) share the window's last read_id: that read may continue in the next push
+        const u32 last = r[m - 1];
+        u64 cut = m;
+        while (cut > 0 && r[cut - 1] == last) --cut;
+        const bool carry_continues = !h->c_rid.empty() && h->c_rid.back() == last;
+        if (cut == 0 && (carry_continues || h->c_rid.empty())) {
+            h->c_rid.insert(h->c_rid.end(), r, r + m);
+            h->c_loc.insert(h->c_loc.end(), l, l + m);
+            h->c_hf.insert(h->c_hf.end(), f, f + m);
+            if (rg) h->c_pos.insert(h->c_pos.end(), ps, ps + m);
+        } else {
+            int rc = stage_and_process(h, r, l, f, ps, cut);      // carry ++ window[0, cut): whole reads
+            if (rc != ECB_OK) return rc;
+            h->c_rid.assign(r + cut, r + m);
+            h->c_loc.assign(l + cut, l + m);
+            h->c_hf.assign(f + cut, f + m);
+            if (rg) h->c_pos.assign(ps + cut, ps + m);
+        }
+        done += m;
+    }
+    return ECB_OK;
+}
+
+int ecb_push_cells(ecb_handle* h, const uint32_t*, uint64_t, size_t) {
+    if (!h) return ECB_ERR_ARG;
+    return fail(h, ECB_ERR_STATE, "multisample is not built into this libecb yet");
+}
+
+int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
+    if (!h || !out) return ECB_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->finalized) {
+        if (!h->c_rid.empty()) {                     // the stream ends here: the carried read is complete
+            int rc = stage_and_process(h, nullptr, nullptr, nullptr, nullptr, 0);
+            if (rc != ECB_OK) return rc;
+        }
+        int rc = sync_counters(h);
+        if (rc != ECB_OK) return rc;
+    }
+    const u64 E = h->hctr.n_ecs;
+    const u64 valid = h->hctr.valid + h->extra_valid;
+    if (E == 0 || valid == 0) return fail(h, ECB_ERR_EMPTY, "no valid alignments: nothing to build (the reference fails here too)");
+    if (E >= (1ull << 31) - 1) return fail(h, ECB_ERR_LIMIT, "more than 2^31-2 equivalence classes");
+    free_results(h);
+    int rc = compact_table(h);
+    if (rc != ECB_OK) return rc;
+    // rank by first appearance: bitmap over read indices, popcount prefix
+    const u64 total_reads = h->n_reads + h->extra_reads;
+    const u64 words = (total_reads + 31) / 32 + 1;
+    u32 *bitmap = nullptr, *wpop = nullptr, *wprefix = nullptr, *rowlen = nullptr;
+    HIPCHK(h, hipMalloc(&bitmap, words * 4)); HIPCHK(h, hipMalloc(&wpop, words * 4)); HIPCHK(h, hipMalloc(&wprefix, words * 4));
+    HIPCHK(h, hipMalloc(&rowlen, E * 4));
+    HIPCHK(h, hipMalloc(&h->order, E * 4)); HIPCHK(h, hipMalloc(&h->rank_of_slot, h->cap * 4));
+    HIPCHK(h, hipMalloc(&h->indptr, (E + 1) * 4)); HIPCHK(h, hipMalloc(&h->counts, E * 4));
+    HIPCHK(h, hipMemsetAsync(bitmap, 0, words * 4, h->stream));
+    k_mark_first<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->table, h->list, E, bitmap);
+    k_popc<<<nblk(words, TPB), TPB, 0, h->stream>>>(bitmap, words, wpop);
+    u32 tot = 0;
+    rc = excl_scan(h, wpop, words, wprefix, &tot);
+    if (rc != ECB_OK) return rc;
+    if (tot != E) return fail(h, ECB_ERR_HIP, "internal: %u distinct first-appearance indices for %llu ECs", tot, (unsigned long long)E);
+    k_rank<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->table, h->list, E, bitmap, wprefix, h->order, rowlen, h->rank_of_slot);
+    u32 nnz = 0;
+    {   // 64-bit check of the row-length total before trusting a 32-bit scan
+        rc = excl_scan(h, rowlen, E, h->indptr, &nnz);
+        if (rc != ECB_OK) return rc;
+        if (h->hctr.arena_top >= (1ull << 31)) return fail(h, ECB_ERR_LIMIT, "A has more than 2^31-1 non-zeros");
+        if ((u64)nnz != h->hctr.arena_top) return fail(h, ECB_ERR_HIP, "internal: nnz %u != arena %llu", nnz, (unsigned long long)h->hctr.arena_top);
+        HIPCHK(h, hipMemcpyAsync(h->indptr + E, &nnz, 4, hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(h, hipMalloc(&h->indices, std::max<u64>(nnz, 1) * 4)); HIPCHK(h, hipMalloc(&h->data, std::max<u64>(nnz, 1) * 4));
+    k_emit<<<nblk(E * 64, TPB), TPB, 0, h->stream>>>(h->table, h->order, E, h->arena, h->indptr, h->indices, h->data, h->counts);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    hipFree(bitmap); hipFree(wpop); hipFree(wprefix); hipFree(rowlen);
+    h->sizes.n_ecs = E; h->sizes.nnz_a = nnz; h->sizes.n_samples = 1; h->sizes.nnz_n = E;
+    h->sizes.all_alignments = h->hctr.all + h->extra_all;
+    h->sizes.valid_alignments = valid;
+    h->sizes.n_reads = total_reads;
+    h->finalized = true;
+    *out = h->sizes;
+    return ECB_OK;
+}
+
+int ecb_export_device(ecb_handle* h, void* ia, void* ja, void* da, void* in_, void* jn, void* dn) {
+    if (!h) return ECB_ERR_ARG;
+    if (!h->finalized) return fail(h, ECB_ERR_STATE, "export before finalize");
+    HIPCHK(h, hipSetDevice(h->device));
+    const u64 E = h->sizes.n_ecs, nnz = h->sizes.nnz_a;
+    if (ia) HIPCHK(h, hipMemcpyAsync(ia, h->indptr, (E + 1) * 4, hipMemcpyDeviceToDevice, h->stream));
+    if (ja) HIPCHK(h, hipMemcpyAsync(ja, h->indices, nnz * 4, hipMemcpyDeviceToDevice, h->stream));
+    if (da) HIPCHK(h, hipMemcpyAsync(da, h->data, nnz * 4, hipMemcpyDeviceToDevice, h->stream));
+    if (in_) { const int v[2] = {0, (int)E}; HIPCHK(h, hipMemcpyAsync(in_, v, 8, hipMemcpyHostToDevice, h->stream)); }
+    if (jn) k_iota<<<nblk(E, TPB), TPB, 0, h->stream>>>((int*)jn, E);
+    if (dn) HIPCHK(h, hipMemcpyAsync(dn, h->counts, E * 4, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ECB_OK;
+}
+
+int ecb_export(ecb_handle* h, int32_t* ia, int32_t* ja, int32_t* da, int32_t* in_, int32_t* jn, int32_t* dn) {
+    if (!h) return ECB_ERR_ARG;
+    if (!h->finalized) return fail(h, ECB_ERR_STATE, "export before finalize");
+    HIPCHK(h, hipSetDevice(h->device));
+    const u64 E = h->sizes.n_ecs, nnz = h->sizes.nnz_a;
+    if (ia) HIPCHK(h, hipMemcpyAsync(ia, h->indptr, (E + 1) * 4, hipMemcpyDeviceToHost, h->stream));
+    if (ja) HIPCHK(h, hipMemcpyAsync(ja, h->indices, nnz * 4, hipMemcpyDeviceToHost, h->stream));
+    if (da) HIPCHK(h, hipMemcpyAsync(da, h->data, nnz * 4, hipMemcpyDeviceToHost, h->stream));
+    if (dn) HIPCHK(h, hipMemcpyAsync(dn, h->counts, E * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (in_) { in_[0] = 0; in_[1] = (int32_t)E; }
+    if (jn) for (u64 i = 0; i < E; ++i) jn[i] = (int32_t)i;
+    return ECB_OK;
+}
+
+int ecb_export_ranges(ecb_handle* h, int64_t* out) {
+    if (!h || !out) return ECB_ERR_ARG;
+    if (!(h->cfg.flags & ECB_F_RANGES)) return fail(h, ECB_ERR_STATE, "handle was created without ECB_F_RANGES");
+    HIPCHK(h, hipSetDevice(h->device));
+    const u64 ns = (u64)h->cfg.n_loci * h->cfg.n_haplotypes;
+    long long* d = nullptr;
+    HIPCHK(h, hipMalloc(&d, ns * 8));
+    k_range_len<<<nblk(ns, TPB), TPB, 0, h->stream>>>(h->rng_min, h->rng_max, ns, d);
+    HIPCHK(h, hipMemcpyAsync(out, d, ns * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipFree(d));
+    return ECB_OK;
+}
+
+int ecb_export_read_ec(ecb_handle* h, int32_t* out) {
+    if (!h || !out) return ECB_ERR_ARG;
+    if (!h->finalized) return fail(h, ECB_ERR_STATE, "export before finalize");
+    if (h->extra_reads) return fail(h, ECB_ERR_STATE, "per-read EC ids are not kept across a multi-GPU merge");
+    HIPCHK(h, hipSetDevice(h->device));
+    int* d = nullptr;
+    HIPCHK(h, hipMalloc(&d, std::max<u64>(h->n_reads, 1) * 4));
+    k_read_ec<<<nblk(h->n_reads, TPB), TPB, 0, h->stream>>>(h->read_slot, h->n_reads, h->rank_of_slot, d);
+    HIPCHK(h, hipMemcpyAsync(out, d, h->n_reads * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipFree(d));
+    return ECB_OK;
+}
+
+int ecb_table_sizes(ecb_handle* h, uint64_t* n_entries, uint64_t* n_pairs, uint64_t* n_reads) {
+    if (!h) return ECB_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->c_rid.empty()) {
+        int rc = stage_and_process(h, nullptr, nullptr, nullptr, nullptr, 0);
+        if (rc != ECB_OK) return rc;
+    }
+    int rc = sync_counters(h);
+    if (rc != ECB_OK) return rc;
+    if (n_entries) *n_entries = h->hctr.n_ecs;
+    if (n_pairs) *n_pairs = h->hctr.arena_top;
+    if (n_reads) *n_reads = h->n_reads;
+    return ECB_OK;
+}
+
+int ecb_table_export_device(ecb_handle* h, void* d_entries, void* d_pairs, uint64_t read_base) {
+    if (!h || !d_entries || !d_pairs) return ECB_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = sync_counters(h);
+    if (rc != ECB_OK) return rc;
+    if (read_base + h->n_reads >= (1ull << 32) - 1) return fail(h, ECB_ERR_LIMIT, "more than 2^32-2 reads in total");
+    rc = compact_table(h);
+    if (rc != ECB_OK) return rc;
+    const u64 E = h->hctr.n_ecs;
+    if (E) k_export_entries<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->table, h->list, E, (Slot*)d_entries, (u32)read_base);
+    HIPCHK(h, hipMemcpyAsync(d_pairs, h->arena, h->hctr.arena_top * sizeof(uint2), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ECB_OK;
+}
+
+int ecb_table_merge_device(ecb_handle* h, const void* d_entries, uint64_t n_entries, const void* d_pairs, uint64_t n_pairs) {
+    if (!h) return ECB_ERR_ARG;
+    if (h->finalized) return fail(h, ECB_ERR_STATE, "merge after finalize");
+    if (!n_entries) return ECB_OK;
+    if (!d_entries || (n_pairs && !d_pairs)) return fail(h, ECB_ERR_ARG, "null table buffers");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = sync_counters(h);
+    if (rc != ECB_OK) return rc;
+    while ((h->hctr.n_ecs + n_entries) * 2 > h->cap) { rc = grow_table(h, h->cap * 4); if (rc != ECB_OK) return rc; }
+    HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));
+    k_merge<<<nblk(n_entries, TPB), TPB, 0, h->stream>>>((const Slot*)d_entries, n_entries, (const uint2*)d_pairs, n_pairs,
+                                                          h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr);
+    rc = sync_counters(h);
+    if (rc != ECB_OK) return rc;
+    if (h->hctr.n_queue) return fail(h, ECB_ERR_TABLE_FULL, "internal: merge found no slot in a half-empty table");
+    return ECB_OK;
+}
+
+int ecb_add_counters(ecb_handle* h, uint64_t all_alignments, uint64_t valid_alignments, uint64_t n_reads) {
+    if (!h) return ECB_ERR_ARG;
+    h->extra_all += all_alignments; h->extra_valid += valid_alignments; h->extra_reads += n_reads;
+    return ECB_OK;
+}
+
+int ecb_profile(ecb_handle* h, int enable) {
+    if (!h) return ECB_ERR_ARG;
+    h->prof = enable != 0; h->prof_ms = 0; h->prof_launches = 0; h->prof_records = 0;
+    return ECB_OK;
+}
+
+int ecb_profile_read(ecb_handle* h, double* ms, uint64_t* launches, uint64_t* records) {
+    if (!h) return ECB_ERR_ARG;
+    if (ms) *ms = h->prof_ms;
+    if (launches) *launches = h->prof_launches;
+    if (records) *records = h->prof_records;
+    return ECB_OK;
+}
+
+}  // extern "C"

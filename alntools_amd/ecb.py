@@ -1,0 +1,210 @@
+# -*- coding: utf-8 -*-
+"""ctypes binding of ``libecb.so`` (``include/ecb.h``) -- the device side of the
+reference's ``process_convert_bam`` + merge + A/N construction
+(``alntools/bam_utils.py:198-363, 680-724, 768-847``).
+
+There is no CPU fallback here on purpose: if the library is missing or no GPU is
+present, constructing an :class:`EcBuilder` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libecb.so")
+
+F_RANGES = 1
+F_MULTISAMPLE = 2
+HAP_SHIFT = 16
+FLAG_MATE_OTHER_REF = 0x1000
+FLAG_NEXT_POS_NEG = 0x2000
+
+#: every symbol include/ecb.h declares
+SYMBOLS = ("ecb_abi_version", "ecb_device_count", "ecb_create", "ecb_destroy", "ecb_last_error",
+           "ecb_push", "ecb_push_device", "ecb_push_cells", "ecb_finalize", "ecb_export",
+           "ecb_export_device", "ecb_export_ranges", "ecb_export_read_ec", "ecb_table_sizes",
+           "ecb_table_export_device", "ecb_table_merge_device", "ecb_add_counters", "ecb_profile",
+           "ecb_profile_read")
+
+
+class EcbError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "libecb error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("n_loci", C.c_uint32),
+                ("n_haplotypes", C.c_uint32), ("flags", C.c_uint32), ("reserved", C.c_uint32),
+                ("ec_capacity", C.c_uint64), ("arena_capacity", C.c_uint64),
+                ("max_batch_records", C.c_uint64)]
+
+
+class Sizes(C.Structure):
+    _fields_ = [("n_ecs", C.c_uint64), ("nnz_a", C.c_uint64), ("n_samples", C.c_uint64),
+                ("nnz_n", C.c_uint64), ("all_alignments", C.c_uint64), ("valid_alignments", C.c_uint64),
+                ("n_reads", C.c_uint64)]
+
+
+_lib = None
+
+
+def load():
+    """``ctypes.CDLL`` of the in-tree library (raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as
+    # /opt/rocm's).  Importing torch first makes the loader bind libecb's libamdhip64.so.7 to the copy
+    # torch already mapped, so tensors and libecb share one runtime (two copies cannot both open the GPU).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not found: build it with `python -m alntools_amd.build` "
+                          "(the HIP path has no fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, u64, sz = C.c_void_p, C.c_uint64, C.c_size_t
+    lib.ecb_abi_version.restype = C.c_int
+    lib.ecb_device_count.restype = C.c_int
+    lib.ecb_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    lib.ecb_destroy.argtypes = [vp]
+    lib.ecb_destroy.restype = None
+    lib.ecb_last_error.argtypes = [vp]
+    lib.ecb_last_error.restype = C.c_char_p
+    lib.ecb_push.argtypes = [vp, vp, vp, vp, vp, sz]
+    lib.ecb_push_device.argtypes = [vp, vp, vp, vp, vp, sz]
+    lib.ecb_push_cells.argtypes = [vp, vp, u64, sz]
+    lib.ecb_finalize.argtypes = [vp, C.POINTER(Sizes)]
+    lib.ecb_export.argtypes = [vp] + [vp] * 6
+    lib.ecb_export_device.argtypes = [vp] + [vp] * 6
+    lib.ecb_export_ranges.argtypes = [vp, vp]
+    lib.ecb_export_read_ec.argtypes = [vp, vp]
+    lib.ecb_table_sizes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+    lib.ecb_table_export_device.argtypes = [vp, vp, vp, u64]
+    lib.ecb_table_merge_device.argtypes = [vp, vp, u64, vp, u64]
+    lib.ecb_add_counters.argtypes = [vp, u64, u64, u64]
+    lib.ecb_profile.argtypes = [vp, C.c_int]
+    lib.ecb_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _dev_ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class EcBuilder(object):
+    """One handle = one GPU.  Push record tuples, finalize, read back CSR A and N."""
+
+    def __init__(self, n_loci, n_haplotypes, device=0, track_ranges=False, ec_capacity=0,
+                 arena_capacity=0, max_batch_records=0):
+        self._lib = load()
+        self._h = C.c_void_p()
+        flags = F_RANGES if track_ranges else 0
+        cfg = Config(C.sizeof(Config), device, n_loci, n_haplotypes, flags, 0, ec_capacity,
+                     arena_capacity, max_batch_records)
+        rc = self._lib.ecb_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            raise EcbError(rc, (self._lib.ecb_last_error(None) or b"").decode())
+        self.n_loci, self.n_haplotypes, self.track_ranges = n_loci, n_haplotypes, track_ranges
+        self.sizes = None
+
+    # -- plumbing ------------------------------------------------------------
+    def _chk(self, rc):
+        if rc != 0:
+            raise EcbError(rc, (self._lib.ecb_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.ecb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- input ---------------------------------------------------------------
+    def push(self, read_id, locus, hapflag, pos=None):
+        """Host (numpy) tuple streams; a read may straddle calls."""
+        rid = np.ascontiguousarray(read_id, dtype=np.uint32)
+        loc = np.ascontiguousarray(locus, dtype=np.uint32)
+        hf = np.ascontiguousarray(hapflag, dtype=np.uint32)
+        ps = None if pos is None else np.ascontiguousarray(pos, dtype=np.int32)
+        if not (len(rid) == len(loc) == len(hf)) or (ps is not None and len(ps) != len(rid)):
+            raise ValueError("tuple streams differ in length")
+        self._chk(self._lib.ecb_push(self._h, _ptr(rid), _ptr(loc), _ptr(hf), _ptr(ps), len(rid)))
+
+    def push_device(self, read_id, locus, hapflag, pos=None):
+        """torch tensors already in HBM (int32/uint32 bit patterns); whole reads per call."""
+        n = read_id.numel()
+        for t in (read_id, locus, hapflag) + ((pos,) if pos is not None else ()):
+            if not t.is_cuda or not t.is_contiguous() or t.element_size() != 4 or t.numel() != n:
+                raise ValueError("device tuple streams must be contiguous 4-byte CUDA tensors of equal length")
+        self._chk(self._lib.ecb_push_device(self._h, _dev_ptr(read_id), _dev_ptr(locus), _dev_ptr(hapflag),
+                                            _dev_ptr(pos), n))
+
+    # -- results -------------------------------------------------------------
+    def finalize(self):
+        s = Sizes()
+        self._chk(self._lib.ecb_finalize(self._h, C.byref(s)))
+        self.sizes = {k: int(getattr(s, k)) for k, _ in Sizes._fields_}
+        return self.sizes
+
+    def export(self):
+        """-> dict of int32 numpy arrays: indptrA, indicesA, dataA, indptrN, indicesN, dataN."""
+        s = self.sizes or self.finalize()
+        E, nnz, S, nnzn = s["n_ecs"], s["nnz_a"], s["n_samples"], s["nnz_n"]
+        out = dict(indptrA=np.empty(E + 1, np.int32), indicesA=np.empty(nnz, np.int32),
+                   dataA=np.empty(nnz, np.int32), indptrN=np.empty(S + 1, np.int32),
+                   indicesN=np.empty(nnzn, np.int32), dataN=np.empty(nnzn, np.int32))
+        self._chk(self._lib.ecb_export(self._h, *[_ptr(out[k]) for k in
+                                                  ("indptrA", "indicesA", "dataA", "indptrN", "indicesN", "dataN")]))
+        return out
+
+    def export_ranges(self):
+        out = np.empty((self.n_loci, self.n_haplotypes), np.int64)
+        self._chk(self._lib.ecb_export_ranges(self._h, _ptr(out)))
+        return out
+
+    def export_read_ec(self):
+        s = self.sizes or self.finalize()
+        out = np.empty(s["n_reads"], np.int32)
+        self._chk(self._lib.ecb_export_read_ec(self._h, _ptr(out)))
+        return out
+
+    # -- multi-GPU -----------------------------------------------------------
+    def table_sizes(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._chk(self._lib.ecb_table_sizes(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def table_export_device(self, entries, pairs, read_base):
+        self._chk(self._lib.ecb_table_export_device(self._h, _dev_ptr(entries), _dev_ptr(pairs), read_base))
+
+    def table_merge_device(self, entries, n_entries, pairs, n_pairs):
+        self._chk(self._lib.ecb_table_merge_device(self._h, _dev_ptr(entries), n_entries, _dev_ptr(pairs), n_pairs))
+
+    def add_counters(self, all_alignments, valid_alignments, n_reads):
+        self._chk(self._lib.ecb_add_counters(self._h, all_alignments, valid_alignments, n_reads))
+
+    # -- measurement ---------------------------------------------------------
+    def profile(self, enable=True):
+        self._chk(self._lib.ecb_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self):
+        ms, n, r = C.c_double(), C.c_uint64(), C.c_uint64()
+        self._chk(self._lib.ecb_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(r)))
+        return ms.value, n.value, r.value

@@ -1,0 +1,148 @@
+/*
+ * ecb.h -- C ABI of libecb.so, the MI355X (gfx950) equivalence-class builder behind
+ * alntools' bam2ec / bam2emase hot path.
+ *
+ * The reference (churchill-lab/alntools v0.1.1, pure Python) has no FFI; its seam is the
+ * call boundary between bam_utils.convert() and its per-chunk worker:
+ *
+ *     process_convert_bam(cp: ConvertParams) -> ConvertResults      alntools/bam_utils.py:198-363
+ *         in : chunk descriptors of one BAM file                    alntools/bam_utils.py:37-47
+ *         out: {valid_alignments, all_alignments, ec: OrderedDict[key -> count],
+ *               unique_reads, tid_ranges}                           alntools/bam_utils.py:53-62,356-363
+ *     merge of the workers' results, EC rank = first appearance     alntools/bam_utils.py:680-724
+ *     A (incidence) / N (count) construction                        alntools/bam_utils.py:768-847
+ *     (multisample variant: alntools/bam_utils_multisample.py:175-321, 503-793)
+ *
+ * The functions below replace exactly that: the host keeps decoding BAM (pysam) and streams
+ * the decoded per-record tuples in; the library filters, groups records into reads, builds
+ * each read's target set, reduces reads into equivalence classes in first-appearance order
+ * and hands back the CSR A matrix (value = haplotype bitmask, bin_utils.py:208-211) and the
+ * N matrix that alntools' writers (bin_utils.ecsave2, APM.save) consume.
+ *
+ * Conventions: plain C types only; caller owns every buffer it passes; the library owns
+ * the device memory behind the opaque handle; return 0 = OK, < 0 = error code and
+ * ecb_last_error() explains.  A handle is bound to one GPU and is not thread-safe.
+ * There is no CPU fallback: without a usable HIP device ecb_create fails.
+ *
+ * Record tuple (struct-of-arrays, 12 bytes per BAM record):
+ *   read_id  u32  run counter of reads.  A read is a run of equal (space-trimmed) query
+ *                 names among the records that PASS the filter (bam_utils.py:289-320); the
+ *                 host numbers those runs 0,1,2,... and every record -- passing or not --
+ *                 carries the number of the latest run started at or before it
+ *                 (0xFFFFFFFF before the first).  So read_id never decreases, steps by at
+ *                 most 1, and steps only on a passing record; the library verifies this.
+ *   locus    u32  index of the record's main target (bam_utils.py:596-598 order)
+ *   hapflag  u32  bits 0-11 BAM flag; bit 12 = (refID != next_refID); bit 13 = (next_pos < 0)
+ *                 (the two fields of the filter that are not in the flag, bam_utils.py:269);
+ *                 bits 16-23 haplotype index (bam_utils.py:602 order); other bits 0
+ *   pos      i32  reference_start, only with ECB_F_RANGES (bam_utils.py:282-286)
+ */
+#ifndef ECB_H
+#define ECB_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ECB_ABI_VERSION 1
+
+#define ECB_OK               0
+#define ECB_ERR_ARG         -1   /* bad argument / configuration */
+#define ECB_ERR_HIP         -2   /* HIP runtime error (message has the HIP error string) */
+#define ECB_ERR_NO_DEVICE   -3   /* no usable gfx950 device */
+#define ECB_ERR_TABLE_FULL  -4   /* EC table or key arena exhausted: raise ec_capacity / arena_capacity */
+#define ECB_ERR_CONTRACT    -5   /* input violates the tuple contract (read_id steps, locus/hap range) */
+#define ECB_ERR_STATE       -6   /* call out of order (push after finalize, export before finalize) */
+#define ECB_ERR_EMPTY       -7   /* no valid alignment at all (the reference fails too: bam_utils.py:336-339) */
+#define ECB_ERR_LIMIT       -8   /* result exceeds the .bin format's int32 limits (bin_utils.py:214-232) */
+
+#define ECB_F_RANGES        1u   /* track min/max reference_start per (locus, haplotype) */
+#define ECB_F_MULTISAMPLE   2u   /* per-read cell ids; N becomes EC x cell (bam_utils_multisample.py) */
+
+#define ECB_HAP_SHIFT 16
+#define ECB_FLAG_MATE_OTHER_REF 0x1000u
+#define ECB_FLAG_NEXT_POS_NEG   0x2000u
+
+typedef struct ecb_handle ecb_handle;
+
+typedef struct ecb_config {
+    uint32_t struct_size;        /* = sizeof(ecb_config) */
+    int32_t  device;             /* HIP device ordinal */
+    uint32_t n_loci;             /* T: number of main targets */
+    uint32_t n_haplotypes;       /* H: 1..31 */
+    uint32_t flags;              /* ECB_F_* */
+    uint32_t reserved;
+    uint64_t ec_capacity;        /* EC hash-table slots (rounded up to a power of two); 0 = default */
+    uint64_t arena_capacity;     /* (locus, mask) pairs of EC key storage; 0 = default */
+    uint64_t max_batch_records;  /* device staging size for ecb_push (host pointers); 0 = default */
+} ecb_config;
+
+typedef struct ecb_sizes {
+    uint64_t n_ecs;              /* E */
+    uint64_t nnz_a;              /* non-zeros of A */
+    uint64_t n_samples;          /* S (1 unless multisample) */
+    uint64_t nnz_n;              /* non-zeros of N */
+    uint64_t all_alignments;     /* records offered (bam_utils.py:261) */
+    uint64_t valid_alignments;   /* records that passed the filter (bam_utils.py:272) */
+    uint64_t n_reads;            /* reads = name runs among valid records */
+} ecb_sizes;
+
+/* Lifetime. */
+int  ecb_abi_version(void);
+int  ecb_device_count(void);
+int  ecb_create(const ecb_config* cfg, ecb_handle** out);
+void ecb_destroy(ecb_handle* h);
+const char* ecb_last_error(const ecb_handle* h);   /* h may be NULL: error of the last failed ecb_create */
+
+/* Streaming input -- replaces the per-alignment loop of process_convert_bam (bam_utils.py:258-344).
+ * ecb_push: host pointers; batches may cut a read anywhere (the library carries the open read over).
+ * ecb_push_device: device pointers (HBM-resident tuples); every call must hold whole reads.
+ * pos may be NULL unless ECB_F_RANGES. */
+int ecb_push(ecb_handle* h, const uint32_t* read_id, const uint32_t* locus, const uint32_t* hapflag,
+             const int32_t* pos, size_t n);
+int ecb_push_device(ecb_handle* h, const void* d_read_id, const void* d_locus, const void* d_hapflag,
+                    const void* d_pos, size_t n);
+
+/* Multisample only: cell id of reads [first_read, first_read + n) (dictionary-encoded by the host,
+ * bam_utils_multisample.py:270-280), and the start of a new input file (the reference never counts
+ * the last read of a file, bam_utils_multisample.py:306-321 -- the host drops it before pushing). */
+int ecb_push_cells(ecb_handle* h, const uint32_t* cell, uint64_t first_read, size_t n);
+
+/* Close the stream: rank ECs by first appearance (bam_utils.py:682-698), build CSR A and N. */
+int ecb_finalize(ecb_handle* h, ecb_sizes* out);
+
+/* Results, into caller buffers of the sizes ecb_finalize reported (int32, as the .bin stores them).
+ * A: CSR over (EC, locus), columns ascending, value = OR of 1 << haplotype.
+ * N: CSC over (EC, sample); single-sample: indptr = {0, E}, indices = 0..E-1, data = counts. */
+int ecb_export(ecb_handle* h, int32_t* indptr_a, int32_t* indices_a, int32_t* data_a,
+               int32_t* indptr_n, int32_t* indices_n, int32_t* data_n);
+int ecb_export_device(ecb_handle* h, void* d_indptr_a, void* d_indices_a, void* d_data_a,
+                      void* d_indptr_n, void* d_indices_n, void* d_data_n);
+/* ECB_F_RANGES: per (locus, haplotype) max - min + 1 of reference_start over valid alignments, 0 if
+ * none (the numbers of the reference's range file, bam_utils.py:756-763); n_loci * n_haplotypes values. */
+int ecb_export_ranges(ecb_handle* h, int64_t* range_len);
+/* EC index of every read, in read order (n_reads values). */
+int ecb_export_read_ec(ecb_handle* h, int32_t* ec_of_read);
+
+/* Multi-GPU: one handle per GPU over contiguous read shards (the reference's contiguous chunk
+ * ranges per process, bam_utils.py:646-658).  A rank serialises its EC table (device buffers the
+ * caller allocates: n_entries * 32 bytes and n_pairs * 8 bytes), the caller moves it (RCCL), and the
+ * receiving rank merges it -- the reference's ordered merge, bam_utils.py:680-724.
+ * read_base = number of reads on all lower ranks (makes "first appearance" global). */
+int ecb_table_sizes(ecb_handle* h, uint64_t* n_entries, uint64_t* n_pairs, uint64_t* n_reads);
+int ecb_table_export_device(ecb_handle* h, void* d_entries, void* d_pairs, uint64_t read_base);
+int ecb_table_merge_device(ecb_handle* h, const void* d_entries, uint64_t n_entries,
+                           const void* d_pairs, uint64_t n_pairs);
+int ecb_add_counters(ecb_handle* h, uint64_t all_alignments, uint64_t valid_alignments, uint64_t n_reads);
+
+/* Measurement: HIP-event time of the record-stream kernel on the handle's own stream. */
+int ecb_profile(ecb_handle* h, int enable);
+int ecb_profile_read(ecb_handle* h, double* kernel_ms, uint64_t* launches, uint64_t* records);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ECB_H */
