@@ -30,6 +30,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -112,8 +113,8 @@ __device__ __forceinline__ u64 table_upsert(Slot* table, u64 cap_mask, u64 lo, u
             if (chi == 0ull) *created = true;
             else if (chi != hi) continue;
         }
-        atomicAdd(&s->count, add);
-        atomicMax(&s->first_inv, ~first);
+        if (add) atomicAdd(&s->count, add);
+        if (first != 0xFFFFFFFFu) atomicMax(&s->first_inv, ~first);
         return j;
     }
     return ~0ull;
@@ -134,6 +135,7 @@ struct StreamArgs {
     int* rng_min; int* rng_max;      // per (locus*H + hap), or null
     u64* queue; u64 queue_cap;       // head record index of deferred reads
     u64* resume;                     // per workgroup {next record to process, records counted up to}
+    u32 ablate;                      // profiling only (env ECB_ABLATE): 1 = stop after (a), 2 = after (b), 4 = no EC-table upsert
 };
 
 __global__ __launch_bounds__(TPB) void k_stream(StreamArgs A) {
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(TPB) void k_stream(StreamArgs A) {
         // ---- (b) per-read locus tables in LDS ----------------------------------------------
 #pragma unroll
         for (int k = 0; k < RPL; ++k) {
-            if (r_ok >> k & 1u) {
+            if ((r_ok >> k & 1u) && !(A.ablate & 1u)) {
                 const u32 s2 = 2u * seg[r_rl[k]], len2 = 2u * seg[r_rl[k] + 1] - s2;
                 const u32 key = r_loc[k] + 1u;
                 const u32 bit = 1u << ((r_hf[k] >> ECB_HAP_SHIFT) & 0xFFu);
@@ -252,7 +254,11 @@ __global__ __launch_bounds__(TPB) void k_stream(StreamArgs A) {
         __syncthreads();
 
         // ---- (c) one lane per read: set hash, EC upsert ------------------------------------
-        for (u32 k0 = 0; k0 < nproc; k0 += TPB) {
+        if (A.ablate & 2u) {                                    // profiling only: just clear the tables
+            __syncthreads();
+            for (u32 q = tid; q < 2 * TILE; q += TPB) { tkey[q] = 0; tmask[q] = 0; }
+        }
+        for (u32 k0 = 0; k0 < nproc && !(A.ablate & 3u); k0 += TPB) {
             const u32 k = k0 + tid;
             const bool act = k < nproc;
             u32 s2 = 0, e2 = 0, npairs = 0;
@@ -269,7 +275,13 @@ __global__ __launch_bounds__(TPB) void k_stream(StreamArgs A) {
             if (act) {
                 u64 lo, hi;
                 finish_hash(s_a, s_b, npairs, lo, hi);
-                slot = table_upsert(A.table, A.cap_mask, lo, hi, 1u, base + k, &created);
+                if (A.ablate & 4u) slot = lo & A.cap_mask;
+                else if (A.ablate & 8u) {                       // profiling only: same atomics, uncontended random slots
+                    slot = (lo ^ mix64(base + k)) & A.cap_mask;
+                    atomicAdd(&A.table[slot].count, 1u); atomicMax(&A.table[slot].first_inv, ~(base + k));
+                } else if (A.ablate & 16u) {                    // profiling only: lookup without the two atomics
+                    slot = table_upsert(A.table, A.cap_mask, lo, hi, 0u, 0xFFFFFFFFu, &created);
+                } else slot = table_upsert(A.table, A.cap_mask, lo, hi, 1u, base + k, &created);
                 if (slot == ~0ull) {                            // table too full here: defer the read
                     atomicExch(&A.ctr->full, 1u);
                     const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
@@ -804,7 +816,8 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     }
     StreamArgs a{d_rid, d_loc, d_hf, d_pos, n, chunk, h->prev_rid, h->cfg.n_loci, h->cfg.n_haplotypes,
                  h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr, h->read_slot,
-                 h->rng_min, h->rng_max, h->queue, h->queue_cap, d_resume};
+                 h->rng_min, h->rng_max, h->queue, h->queue_cap, d_resume,
+                 getenv("ECB_ABLATE") ? (u32)atoi(getenv("ECB_ABLATE")) : 0u};
     for (;;) {
         HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));   // per launch
         HIPCHK(h, hipMemsetAsync(&h->ctr->full, 0, sizeof(u32), h->stream));
@@ -971,6 +984,27 @@ void ecb_destroy(ecb_handle* h) {
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
+}
+
+int ecb_reset(ecb_handle* h) {
+    if (!h) return ECB_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    free_results(h);
+    HIPCHK(h, hipMemsetAsync(h->table, 0, h->cap * sizeof(Slot), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->ctr, 0, sizeof(Counters), h->stream));
+    if (h->read_slot && h->reads_hi) HIPCHK(h, hipMemsetAsync(h->read_slot, 0xFF, h->reads_hi * sizeof(u32), h->stream));
+    if (h->rng_min) {
+        const u64 ns = (u64)h->cfg.n_loci * h->cfg.n_haplotypes;
+        k_fill_i32<<<nblk(ns, TPB), TPB, 0, h->stream>>>(h->rng_min, ns, INT_MAX);
+        k_fill_i32<<<nblk(ns, TPB), TPB, 0, h->stream>>>(h->rng_max, ns, INT_MIN);
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->hctr = Counters{};
+    h->prev_rid = 0xFFFFFFFFu; h->n_reads = 0; h->reads_hi = 0;
+    h->extra_all = h->extra_valid = h->extra_reads = 0;
+    h->c_rid.clear(); h->c_loc.clear(); h->c_hf.clear(); h->c_pos.clear();
+    h->finalized = false; h->sizes = ecb_sizes{}; h->n_list = 0;
+    return ECB_OK;
 }
 
 int ecb_push_device(ecb_handle* h, const void* d_read_id, const void* d_locus, const void* d_hapflag,
@@ -1183,6 +1217,21 @@ int ecb_table_merge_device(ecb_handle* h, const void* d_entries, uint64_t n_entr
     rc = sync_counters(h);
     if (rc != ECB_OK) return rc;
     if (h->hctr.n_queue) return fail(h, ECB_ERR_TABLE_FULL, "internal: merge found no slot in a half-empty table");
+    return ECB_OK;
+}
+
+int ecb_counters(ecb_handle* h, uint64_t* all_alignments, uint64_t* valid_alignments, uint64_t* n_reads) {
+    if (!h) return ECB_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->finalized && !h->c_rid.empty()) {
+        int rc = stage_and_process(h, nullptr, nullptr, nullptr, nullptr, 0);
+        if (rc != ECB_OK) return rc;
+    }
+    int rc = sync_counters(h);
+    if (rc != ECB_OK) return rc;
+    if (all_alignments) *all_alignments = h->hctr.all + h->extra_all;
+    if (valid_alignments) *valid_alignments = h->hctr.valid + h->extra_valid;
+    if (n_reads) *n_reads = h->n_reads + h->extra_reads;
     return ECB_OK;
 }
 

@@ -23,10 +23,10 @@ FLAG_MATE_OTHER_REF = 0x1000
 FLAG_NEXT_POS_NEG = 0x2000
 
 #: every symbol include/ecb.h declares
-SYMBOLS = ("ecb_abi_version", "ecb_device_count", "ecb_create", "ecb_destroy", "ecb_last_error",
+SYMBOLS = ("ecb_abi_version", "ecb_device_count", "ecb_create", "ecb_destroy", "ecb_reset", "ecb_last_error",
            "ecb_push", "ecb_push_device", "ecb_push_cells", "ecb_finalize", "ecb_export",
            "ecb_export_device", "ecb_export_ranges", "ecb_export_read_ec", "ecb_table_sizes",
-           "ecb_table_export_device", "ecb_table_merge_device", "ecb_add_counters", "ecb_profile",
+           "ecb_table_export_device", "ecb_table_merge_device", "ecb_counters", "ecb_add_counters", "ecb_profile",
            "ecb_profile_read")
 
 
@@ -74,6 +74,7 @@ def load():
     lib.ecb_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     lib.ecb_destroy.argtypes = [vp]
     lib.ecb_destroy.restype = None
+    lib.ecb_reset.argtypes = [vp]
     lib.ecb_last_error.argtypes = [vp]
     lib.ecb_last_error.restype = C.c_char_p
     lib.ecb_push.argtypes = [vp, vp, vp, vp, vp, sz]
@@ -87,6 +88,7 @@ def load():
     lib.ecb_table_sizes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     lib.ecb_table_export_device.argtypes = [vp, vp, vp, u64]
     lib.ecb_table_merge_device.argtypes = [vp, vp, u64, vp, u64]
+    lib.ecb_counters.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     lib.ecb_add_counters.argtypes = [vp, u64, u64, u64]
     lib.ecb_profile.argtypes = [vp, C.c_int]
     lib.ecb_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]
@@ -135,6 +137,11 @@ class EcBuilder(object):
 
     def __exit__(self, *a):
         self.close()
+
+    def reset(self):
+        """Forget all input and results; allocations (table, arena, staging) are kept."""
+        self._chk(self._lib.ecb_reset(self._h))
+        self.sizes = None
 
     # -- input ---------------------------------------------------------------
     def push(self, read_id, locus, hapflag, pos=None):
@@ -196,6 +203,12 @@ class EcBuilder(object):
 
     def table_merge_device(self, entries, n_entries, pairs, n_pairs):
         self._chk(self._lib.ecb_table_merge_device(self._h, _dev_ptr(entries), n_entries, _dev_ptr(pairs), n_pairs))
+
+    def counters(self):
+        """-> (all_alignments, valid_alignments, n_reads) so far."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._chk(self._lib.ecb_counters(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def add_counters(self, all_alignments, valid_alignments, n_reads):
         self._chk(self._lib.ecb_add_counters(self._h, all_alignments, valid_alignments, n_reads))

@@ -1,0 +1,223 @@
+#!/usr/bin/env python
+# -*- coding: utf-8 -*-
+"""bench.py -- alignments/sec BAM->EC on MI355X (BASELINE.json metric).
+
+One "step" = one whole pass of the hot path over the workload's record tuples, already
+resident in HBM: reset the EC table, stream every record through libecb's k_stream kernel
+(filter, read segmentation, per-read target sets, EC hash-reduce), exchange + merge the
+per-GPU EC tables when N > 1 (RCCL all-gather), rank ECs by first appearance and emit CSR A / N.
+
+Workload (default): BASELINE config 3 -- 100 M paired-end reads, 8 haplotypes x 80 k
+transcripts (~3.3 G BAM records, ~40 GB of tuples), synthetic (alntools_amd/synth.py, seed
+20260101), read-sharded contiguously over the N GPUs (strong scaling: total work fixed).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c1|tiny]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (reads, loci, haplotypes, paired, description)
+    "c3": (100_000_000, 80_000, 8, True, "BASELINE config 3: 100M paired-end reads, 8 hap x 80k transcripts, bam2emase path"),
+    "c2": (50_000_000, 40_000, 8, False, "BASELINE config 2: 50M single-end reads, 8 hap x 40k transcripts, bam2ec path"),
+    "c1": (10_000, 1_000, 2, False, "BASELINE config 1: 10k single-end reads, 2 hap x 1k transcripts"),
+    "tiny": (400_000, 4_000, 8, True, "smoke-sized paired-end workload"),
+}
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+
+def generate_shard(spec, r0, r1, device, chunk_reads=1 << 20):
+    """Tuples of reads [r0, r1) as three int32 CUDA tensors (uint32 bit patterns); read ids local from 0."""
+    import torch
+    from alntools_amd import synth
+    n = synth.count_records(spec, r0, r1, device=device)
+    rid = torch.empty(n, dtype=torch.int32, device=device)
+    loc = torch.empty(n, dtype=torch.int32, device=device)
+    hf = torch.empty(n, dtype=torch.int32, device=device)
+    at, reads, valid = 0, 0, 0
+    for a in range(r0, r1, chunk_reads):
+        g = synth.generate(spec, a, min(a + chunk_reads, r1), device=device, read_id_base=reads)
+        m = g["n_records"]
+        rid[at:at + m] = g["read_id"]
+        loc[at:at + m] = g["locus"]
+        hf[at:at + m] = g["hapflag"]
+        at += m
+        reads += g["n_reads"]
+        valid += g["n_valid"]
+        del g
+    assert at == n
+    return rid, loc, hf, dict(records=n, reads=reads, valid=valid)
+
+
+def cpu_baseline(rid, loc, hf, n_haps, sample_reads):
+    """The oracle's C restatement (oracle/ec_oracle.c) on a bounded sample, on the host cores."""
+    import numpy as np
+    import torch
+    from oracle import c_oracle
+    cut = int(torch.searchsorted(rid, torch.tensor([sample_reads], dtype=torch.int32, device=rid.device))[0])
+    if cut == 0:
+        cut = rid.numel()
+    h = [t[:cut].cpu().numpy().view(np.uint32) for t in (rid, loc, hf)]
+    cores = min(os.cpu_count() or 1, 32)
+    c_oracle.load()
+    t0 = time.perf_counter()
+    r = c_oracle.ec_from_tuples(h[0], h[1], h[2], n_haps, threads=cores)
+    dt = time.perf_counter() - t0
+    return dict(value=cut / dt, unit="alignments/s", cores=cores, kind="port",
+                sample="first %d reads (%d records) of the same stream, %d ECs; oracle/ec_oracle.c, "
+                       "%d threads over contiguous read shards + ordered merge; %.2f s"
+                       % (r["n_reads"], cut, len(r["count"]), cores, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-sample-reads", type=int, default=6_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from alntools_amd import dist as ecdist
+    from alntools_amd import ecb, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" %
+                             (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libecb has no CPU path")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    R, T, H, paired, desc = WORKLOADS[args.workload]
+    spec = synth.SynthSpec(R, T, H, paired=paired)
+    r0, r1 = rank * R // world, (rank + 1) * R // world
+    t_gen = time.perf_counter()
+    rid, loc, hf, st = generate_shard(spec, r0, r1, device)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
+
+    ec_cap = 1 << 22
+    b = ecb.EcBuilder(T, H, device=local, ec_capacity=ec_cap, arena_capacity=1 << 26)
+    eng = ecdist.GpuEngine(b, device)
+    root_eng = None
+    if world > 1 and rank == 0:
+        root_eng = ecdist.GpuEngine(ecb.EcBuilder(T, H, device=local, ec_capacity=ec_cap, arena_capacity=1 << 26), device)
+
+    def make_root():
+        root_eng.b.reset()
+        return root_eng
+
+    sizes = {}
+
+    def step():
+        b.reset()
+        b.push_device(rid, loc, hf)
+        if world > 1:
+            m = ecdist.exchange_and_merge(eng, make_root, root=0)
+            if m is not None:
+                sizes.update(m.b.finalize())
+        elif os.environ.get("ECB_ABLATE"):      # profiling-only builds of the kernel produce no ECs
+            try:
+                sizes.update(b.finalize())
+            except ecb.EcbError:
+                pass
+        else:
+            sizes.update(b.finalize())
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    b.profile(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    k_ms, k_launches, _ = b.profile_read()
+    b.profile(False)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+        tot = torch.tensor([st["records"], st["reads"], st["valid"]], dtype=torch.int64, device=device)
+        dist.all_reduce(tot)
+        total_records, total_reads, total_valid = [int(x) for x in tot.tolist()]
+    else:
+        total_records, total_reads, total_valid = st["records"], st["reads"], st["valid"]
+
+    if rank == 0:
+        ms_per_step = dt * 1e3 / args.steps
+        # dominant kernel: k_stream.  Algorithmic bytes per launch: every record tuple read
+        # once (12 B) + one EC-slot id written per read (4 B).  This rank's launch, this rank's bytes.
+        launches_per_step = max(k_launches / max(args.steps, 1), 1e-9)
+        k_ms_per_launch = k_ms / max(k_launches, 1)
+        alg_bytes = 12.0 * st["records"] + 4.0 * st["reads"]
+        achieved = alg_bytes / (k_ms / max(args.steps, 1) * 1e-3) / 1e9      # GB/s over the kernel's own time
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic_%s_n%d.json" % (args.workload, world))
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "alignments/sec BAM->EC (100M PE reads, 8-hap) at 1/2/4/8 MI355X",
+            "value": total_records / (ms_per_step * 1e-3),
+            "unit": "alignments/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": desc, "reads": R, "loci": T, "haplotypes": H, "paired_end": paired,
+                       "records": total_records, "valid_alignments": total_valid, "reads_with_alignments": total_reads,
+                       "ecs": sizes.get("n_ecs"), "nnz_a": sizes.get("nnz_a"),
+                       "sharding": "contiguous reads over %d GPU(s)%s" % (world, ", RCCL all-gather EC-table merge on rank 0" if world > 1 else ""),
+                       "generate_s": round(t_gen, 2)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_stream", "kernel_ms_per_launch": k_ms_per_launch,
+                         "launches_per_step": launches_per_step,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(rid, loc, hf, H, min(args.cpu_sample_reads, st["reads"]))
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -95,6 +95,7 @@ int  ecb_abi_version(void);
 int  ecb_device_count(void);
 int  ecb_create(const ecb_config* cfg, ecb_handle** out);
 void ecb_destroy(ecb_handle* h);
+int  ecb_reset(ecb_handle* h);                      /* forget all input and results, keep the allocations */
 const char* ecb_last_error(const ecb_handle* h);   /* h may be NULL: error of the last failed ecb_create */
 
 /* Streaming input -- replaces the per-alignment loop of process_convert_bam (bam_utils.py:258-344).
@@ -136,6 +137,7 @@ int ecb_table_sizes(ecb_handle* h, uint64_t* n_entries, uint64_t* n_pairs, uint6
 int ecb_table_export_device(ecb_handle* h, void* d_entries, void* d_pairs, uint64_t read_base);
 int ecb_table_merge_device(ecb_handle* h, const void* d_entries, uint64_t n_entries,
                            const void* d_pairs, uint64_t n_pairs);
+int ecb_counters(ecb_handle* h, uint64_t* all_alignments, uint64_t* valid_alignments, uint64_t* n_reads);
 int ecb_add_counters(ecb_handle* h, uint64_t all_alignments, uint64_t valid_alignments, uint64_t n_reads);
 
 /* Measurement: HIP-event time of the record-stream kernel on the handle's own stream. */
