@@ -44,7 +44,11 @@ typedef unsigned int u32;
 constexpr int TPB = 256;             // threads per workgroup (4 waves of 64)
 constexpr int RPL = 8;               // records per lane per tile (2 x 16-byte loads per stream)
 constexpr int TILE = TPB * RPL;      // records per tile
+constexpr int MAXR = 512;            // reads finished per tile (more heads than this: the next tile starts there)
 constexpr u32 MAX_PROBE = 256;       // EC-table probes before a read is deferred to k_slow
+constexpr u32 PENDING = 0xFFFFFFFFu;
+constexpr u32 KEY_PENDING = 0x80000000u;   // Slot::n bit: key not extracted yet, (off, n) hold the head record index
+constexpr u32 MAX_LOCI = 1u << 27;   // (locus << 5 | hap) + 1 must fit 32 bits
 
 constexpr u32 ERR_CONTRACT = 1u;     // device error bits (Counters::err)
 constexpr u32 ERR_RANGE = 2u;
@@ -55,20 +59,22 @@ struct Slot {                        // 32 bytes, one EC
     u64 lo, hi;                      // 126-bit set hash, both non-zero once claimed
     u32 count;                       // reads in this EC
     u32 first_inv;                   // ~(smallest read index)  (atomicMax on zero-initialised memory)
-    u32 off, n;                      // key = arena[off .. off+n)
+    u32 off, n;                      // key = arena[off .. off+n); or, while n & KEY_PENDING, the creating read's head index
 };
 
 struct Counters {
     u64 all, valid;                  // records offered / passing the filter
     u64 arena_top;                   // pairs used in the key arena
     u64 n_queue;                     // reads deferred to k_slow
-    u64 n_ecs;                       // ECs created
+    u64 n_ecs;                       // ECs created by k_slow / k_merge (k_stream's are counted by k_collect_new)
     u32 err;
     u32 full;                        // set when a read found no EC-table slot: workgroups park, host grows the table
 };
 
 // ---------------------------------------------------------------------------------------------
-// hashing
+// hashing: EC identity = the SET of (locus, haplotype) targets of a read (bam_utils.py:307 builds a
+// sorted string for the same purpose).  Set hash = sum over distinct targets of a 2 x 64-bit mix,
+// finalised; commutative, so records need no sorting and duplicates are dropped before summing.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ u64 mix64(u64 z) {
     z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
@@ -76,15 +82,15 @@ __device__ __forceinline__ u64 mix64(u64 z) {
     z ^= z >> 31;
     return z;
 }
-// contribution of one (locus, mask) pair to the two 64-bit lanes of the set hash
-__device__ __forceinline__ void pair_hash(u32 locus, u32 mask, u64& a, u64& b) {
-    u64 x = ((u64)locus << 32) | mask;
+__device__ __forceinline__ u32 target_key(u32 locus, u32 hap) { return (locus << 5) | hap; }
+__device__ __forceinline__ void target_hash(u32 tkey, u64& a, u64& b) {
+    const u64 x = tkey;
     a = mix64(x + 0x9E3779B97F4A7C15ull);
-    b = mix64((~x) * 0xFF51AFD7ED558CCDull + 0xC4CEB9FE1A85EC53ull);
+    b = mix64((x ^ 0xD6E8FEB86659FD93ull) * 0xFF51AFD7ED558CCDull + 0xC4CEB9FE1A85EC53ull);
 }
-__device__ __forceinline__ void finish_hash(u64 s1, u64 s2, u32 n, u64& lo, u64& hi) {
-    lo = mix64(s1 ^ ((u64)n * 0xD6E8FEB86659FD93ull)) | 1ull;
-    hi = mix64(s2 + n) | 1ull;
+__device__ __forceinline__ void finish_hash(u64 s1, u64 s2, u64& lo, u64& hi) {
+    lo = mix64(s1) | 1ull;
+    hi = mix64(s2 ^ 0xA0761D6478BD642Full) | 1ull;
 }
 
 // record filter, bam_utils.py:264-270 (host bits 12/13 carry the two non-flag terms)
@@ -96,262 +102,440 @@ __device__ __forceinline__ bool rec_valid(u32 hf) {
     return true;
 }
 
-// EC-table upsert.  Returns slot index, or ~0 if no slot within MAX_PROBE (table too full).
-// *created is set for the one caller that claimed the slot.
-__device__ __forceinline__ u64 table_upsert(Slot* table, u64 cap_mask, u64 lo, u64 hi, u32 add, u32 first,
-                                            bool* created) {
+// EC-table lookup / insert.  Returns the slot index, or ~0 if no slot within MAX_PROBE (table too full).
+// *created is set for the one caller that claimed the slot.  Keys only ever go 0 -> value, so a plain
+// load that shows another key (or ours) can be trusted; a plain load that shows "empty" is re-checked by
+// the CAS.  Read counts and first appearances are NOT maintained here: per-read atomics on a skewed EC
+// distribution run at ~5 G/s chip-wide (measured), so k_stream only records the slot of every read and
+// k_count reduces them afterwards without global atomics.
+__device__ __forceinline__ u64 table_find_or_insert(Slot* table, u64 cap_mask, u64 lo, u64 hi, bool* created) {
     u64 j = lo & cap_mask;
     *created = false;
     for (u32 probe = 0; probe < MAX_PROBE; ++probe, j = (j + 1) & cap_mask) {
         Slot* s = table + j;
-        // fast path: a plain load that already shows our key is always right (keys never change)
         u64 clo = s->lo, chi = s->hi;
-        if (!(clo == lo && chi == hi)) {
-            clo = atomicCAS(&s->lo, 0ull, lo);
-            if (clo != 0ull && clo != lo) continue;
-            chi = atomicCAS(&s->hi, 0ull, hi);
-            if (chi == 0ull) *created = true;
-            else if (chi != hi) continue;
-        }
-        if (add) atomicAdd(&s->count, add);
-        if (first != 0xFFFFFFFFu) atomicMax(&s->first_inv, ~first);
+        if (clo == lo && chi == hi) return j;
+        if (clo != 0ull && (clo != lo || (chi != 0ull && chi != hi))) continue;
+        clo = atomicCAS(&s->lo, 0ull, lo);
+        if (clo != 0ull && clo != lo) continue;
+        chi = atomicCAS(&s->hi, 0ull, hi);
+        if (chi == 0ull) *created = true;
+        else if (chi != hi) continue;
         return j;
     }
     return ~0ull;
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_stream
+// k_stream -- wave-autonomous: every wave owns a contiguous slice of the record stream and walks it in
+// tiles of WT records with wave-private LDS and no workgroup barriers, so the 16-20 waves of a CU
+// overlap each other's HBM and EC-table latency.  The workgroup only shares the hot-EC cache.
 // ---------------------------------------------------------------------------------------------
+constexpr int WT = 512;              // records per wave tile (8 per lane: 2 x 16-byte loads per stream)
+constexpr int WMAXR = 64;            // reads finished per wave tile (one lane each in phase (c))
+constexpr int NWAVE = TPB / 64;
+
+struct WaveLds {
+    unsigned short seg[WT + 4];      // tile-relative start of every read in the tile (+ end sentinel)
+    u32 tkey[2 * WT];                // per-read sets of targets: 2 slots per record of the read, 0 = empty
+    u64 acc_a[WMAXR], acc_b[WMAXR];  // per-read set-hash accumulators
+};
+
 struct StreamArgs {
     const u32* rid; const u32* loc; const u32* hf; const int* pos;
     u64 n, chunk;
     u32 prev_rid;                    // read_id of the record before this batch (0xFFFFFFFF at stream start)
     u32 n_loci, n_haps;
     Slot* table; u64 cap_mask;
-    uint2* arena; u64 arena_cap;
     Counters* ctr;
     u32* read_slot;                  // slot of every read (indexed by read_id)
     int* rng_min; int* rng_max;      // per (locus*H + hap), or null
     u64* queue; u64 queue_cap;       // head record index of deferred reads
-    u64* resume;                     // per workgroup {next record to process, records counted up to}
-    u32 ablate;                      // profiling only (env ECB_ABLATE): 1 = stop after (a), 2 = after (b), 4 = no EC-table upsert
+    u64* resume;                     // per wave {next record to process, records counted up to}
+    u32 ablate;                      // profiling only (env ECB_ABLATE): 1 = stop after (a), 2 = after (b), 4 = no EC table
 };
 
-__global__ __launch_bounds__(TPB) void k_stream(StreamArgs A) {
-    __shared__ unsigned short seg[TILE + 2];   // tile-relative start of every read in the tile
-    __shared__ u32 tkey[2 * TILE];             // per-read locus tables: key = locus + 1, 0 = empty
-    __shared__ u32 tmask[2 * TILE];
-    __shared__ u32 s_err;
-    __shared__ u64 s_red[2 * (TPB / 64)];
-
-    const u32 tid = threadIdx.x, lane = tid & 63u;
-    const u64 c0 = (u64)blockIdx.x * A.chunk;
-    if (c0 >= A.n) return;
-    const u64 c1 = min(c0 + A.chunk, A.n);
-
-    for (u32 q = tid; q < 2 * TILE; q += TPB) { tkey[q] = 0; tmask[q] = 0; }
-    if (tid == 0) s_err = 0;
-    u64 my_all = 0, my_valid = 0;
-    u64 p = A.resume[2 * blockIdx.x], counted = A.resume[2 * blockIdx.x + 1];
-    __syncthreads();
-
-    while (p < c1) {
-        // the EC table filled up somewhere: park here; the host grows it and relaunches
-        if (__hip_atomic_load(&A.ctr->full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-        const u64 tb = p & ~(u64)3;
-        const u64 te = min(tb + (u64)TILE, A.n);
-        const u32 base = (p == 0 ? A.prev_rid : A.rid[p - 1]) + 1u;      // read index of the first head >= p
-        const u32 nr = A.rid[te - 1] - base + 1u;                        // heads in [p, te)
-        const u32 nown = (c1 >= te) ? nr : (A.rid[c1 - 1] - base + 1u);  // heads in [p, c1): ours
-        const bool last_complete = (te == A.n);                          // batches end on a read boundary
-        const u32 nrc = last_complete ? nr : (nr ? nr - 1u : 0u);
-        const u32 nproc = min(nrc, nown);
-        const u64 cnt_hi = min(te, c1);
-        if (nr > (u32)(te - p)) {            // more heads than records: run counter is broken
-            if (tid == 0) atomicOr(&A.ctr->err, ERR_CONTRACT);
-            return;
-        }
-
-        // ---- (a) load, filter, heads -------------------------------------------------------
-        u32 r_loc[RPL], r_hf[RPL], r_rl[RPL];
-        u32 r_ok = 0;                        // bit j: record j is valid and belongs to a read we process
-        u32 bad = 0;
+__device__ __forceinline__ void wave_sync() {   // orders this wave's LDS traffic (lanes run in lockstep)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ u32 wave_sum(u32 v) {
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const u64 i0 = tb + (u64)g * (TILE / 2) + 4u * tid;
-            u32 rr[4], ll[4], hh[4];
-            if (i0 + 4 <= te) {
-                uint4 v = *reinterpret_cast<const uint4*>(A.rid + i0); rr[0] = v.x; rr[1] = v.y; rr[2] = v.z; rr[3] = v.w;
-                v = *reinterpret_cast<const uint4*>(A.loc + i0);       ll[0] = v.x; ll[1] = v.y; ll[2] = v.z; ll[3] = v.w;
-                v = *reinterpret_cast<const uint4*>(A.hf + i0);        hh[0] = v.x; hh[1] = v.y; hh[2] = v.z; hh[3] = v.w;
-            } else {
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+struct TileRegs { u32 rr[8], ll[8], hh[8]; };
+
+__device__ __forceinline__ void load_tile(const StreamArgs& A, u64 tb, u64 te, u32 lane, TileRegs& R) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool in = i0 + j < te;
-                    rr[j] = in ? A.rid[i0 + j] : 0u; ll[j] = in ? A.loc[i0 + j] : 0u; hh[j] = in ? A.hf[i0 + j] : 0x4u;
-                }
-            }
-            u32 prev = (i0 == 0) ? A.prev_rid : (i0 <= te ? A.rid[i0 - 1] : 0u);
+    for (int g = 0; g < 2; ++g) {
+        const u64 i0 = tb + (u64)g * (WT / 2) + 4u * lane;
+        if (i0 + 4 <= te) {
+            uint4 v = *reinterpret_cast<const uint4*>(A.rid + i0);
+            R.rr[4 * g] = v.x; R.rr[4 * g + 1] = v.y; R.rr[4 * g + 2] = v.z; R.rr[4 * g + 3] = v.w;
+            v = *reinterpret_cast<const uint4*>(A.loc + i0);
+            R.ll[4 * g] = v.x; R.ll[4 * g + 1] = v.y; R.ll[4 * g + 2] = v.z; R.ll[4 * g + 3] = v.w;
+            v = *reinterpret_cast<const uint4*>(A.hf + i0);
+            R.hh[4 * g] = v.x; R.hh[4 * g + 1] = v.y; R.hh[4 * g + 2] = v.z; R.hh[4 * g + 3] = v.w;
+        } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const u64 i = i0 + j;
-                const int k = g * 4 + j;
-                const bool in = (i >= p) && (i < te);
-                const bool ok = rec_valid(hh[j]);
-                const u32 step = rr[j] - prev;
-                const u32 rl = rr[j] - base;
-                r_loc[k] = ll[j]; r_hf[k] = hh[j]; r_rl[k] = rl;
-                if (in) {
-                    if (step > 1u || (step == 1u && !ok)) bad |= ERR_CONTRACT;
-                    if (step == 1u && rl <= (u32)TILE) seg[rl] = (unsigned short)(i - tb);
-                    if (ok) {
-                        const u32 hap = (hh[j] >> ECB_HAP_SHIFT) & 0xFFu;
-                        if (ll[j] >= A.n_loci || hap >= A.n_haps) bad |= ERR_RANGE;
-                        else if (rl < nproc) r_ok |= 1u << k;
-                    }
-                    if (i >= counted && i < cnt_hi) {
-                        my_all += 1;
-                        if (ok) {
-                            my_valid += 1;
-                            if (A.rng_min && !(bad & ERR_RANGE)) {
-                                const u32 hap = (hh[j] >> ECB_HAP_SHIFT) & 0xFFu;
-                                const u64 sl = (u64)ll[j] * A.n_haps + hap;
-                                const int ps = A.pos[i];
-                                atomicMin(A.rng_min + sl, ps);
-                                atomicMax(A.rng_max + sl, ps);
+                const bool in = i0 + j < te;
+                R.rr[4 * g + j] = in ? A.rid[i0 + j] : 0u;
+                R.ll[4 * g + j] = in ? A.loc[i0 + j] : 0u;
+                R.hh[4 * g + j] = in ? A.hf[i0 + j] : 0x4u;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_stream(StreamArgs A) {
+    __shared__ WaveLds wl[NWAVE];
+
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    WaveLds& L = wl[w];
+    const u64 wid = (u64)blockIdx.x * NWAVE + w;
+    const u64 c0 = wid * A.chunk;
+    const u64 c1 = min(c0 + A.chunk, A.n);
+    const bool have = c0 < A.n;
+
+
+    u64 my_all = 0, my_valid = 0;
+    u64 p = 0, counted = 0;
+    if (have) {
+        p = A.resume[2 * wid]; counted = A.resume[2 * wid + 1];
+    }
+    if (have && p < c1) {
+        u32 base = (p == 0 ? A.prev_rid : A.rid[p - 1]) + 1u;     // read index of the first head >= p
+        TileRegs R;
+        load_tile(A, p & ~(u64)3, min((p & ~(u64)3) + (u64)WT, A.n), lane, R);
+        u32 parked = __hip_atomic_load(&A.ctr->full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+        while (p < c1) {
+            if (parked) break;            // the EC table filled up somewhere: the host grows it and relaunches
+            const u64 tb = p & ~(u64)3;
+            const u64 te = min(tb + (u64)WT, A.n);
+            const u64 cnt_hi = min(te, c1);
+            // clear this wave's per-tile LDS state
+            {
+                uint4* z = reinterpret_cast<uint4*>(L.tkey);
+#pragma unroll
+                for (int t = 0; t < (2 * WT) / (4 * 64); ++t) z[t * 64 + lane] = make_uint4(0, 0, 0, 0);
+                L.acc_a[lane] = 0; L.acc_b[lane] = 0;
+            }
+            // ---- (a) filter, heads ---------------------------------------------------------------
+            u32 r_key[8], r_rl[8];
+            u32 m_ok = 0, m_head = 0, m_own = 0;   // bit k: valid & in range / head / head of a read we own
+            u32 bad = 0;
+            {
+                const u32 up0 = __shfl_up(R.rr[3], 1), up1 = __shfl_up(R.rr[7], 1), last0 = __shfl(R.rr[3], 63);
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const u64 i0 = tb + (u64)g * (WT / 2) + 4u * lane;
+                    u32 prev = g == 0 ? (lane == 0 ? base - 1u : up0) : (lane == 0 ? last0 : up1);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = 4 * g + j;
+                        const u64 i = i0 + j;
+                        const bool in = (i >= p) && (i < te);
+                        const u32 f = R.hh[k];
+                        const bool ok = rec_valid(f);
+                        const u32 hap = (f >> ECB_HAP_SHIFT) & 0xFFu;
+                        const u32 step = R.rr[k] - prev;
+                        r_rl[k] = R.rr[k] - base;
+                        r_key[k] = target_key(R.ll[k], hap);
+                        if (in) {
+                            if (step > 1u || (step == 1u && !ok)) bad |= ERR_CONTRACT;
+                            if (step == 1u) { m_head |= 1u << k; if (i < c1) m_own |= 1u << k; }
+                            if (ok) {
+                                if (R.ll[k] >= A.n_loci || hap >= A.n_haps) bad |= ERR_RANGE;
+                                else m_ok |= 1u << k;
                             }
+                            if (i >= counted && i < cnt_hi) {
+                                my_all += 1;
+                                if (ok) {
+                                    my_valid += 1;
+                                    if (A.rng_min && R.ll[k] < A.n_loci && hap < A.n_haps) {
+                                        const u64 sl = (u64)R.ll[k] * A.n_haps + hap;
+                                        const int ps = A.pos[i];
+                                        atomicMin(A.rng_min + sl, ps);
+                                        atomicMax(A.rng_max + sl, ps);
+                                    }
+                                }
+                            }
+                        }
+                        prev = R.rr[k];
+                    }
+                }
+            }
+            if (__ballot(bad != 0u)) {               // never index LDS with a broken run counter
+                if (bad) atomicOr(&A.ctr->err, bad);
+                p = c1;
+                break;
+            }
+            const u32 nr = wave_sum(__popc(m_head));                 // heads in [p, te)
+            const u32 nown = wave_sum(__popc(m_own));                // heads in [p, c1): ours
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (m_head >> k & 1u) L.seg[r_rl[k]] = (unsigned short)(4u * lane + (k & 3) + (k >> 2) * (WT / 2));
+            if (lane == 0) L.seg[nr] = (unsigned short)(te - tb);    // end sentinel
+            wave_sync();
+            const bool last_complete = (te == A.n);                  // batches end on a read boundary
+            const u32 nrc = last_complete ? nr : (nr ? nr - 1u : 0u);
+            const u32 nproc = min(min(nrc, nown), (u32)WMAXR);
+            const bool done = (te >= c1 && nown <= nproc);           // every read that starts in our slice
+            u64 p_next = te;
+            u32 base_next = base + nr;
+            bool giant = false;
+            if (!done && nproc < nr) {
+                const u64 h = tb + L.seg[nproc];                     // first read not finished here
+                if (h == p) giant = true;                            // one read fills the whole tile: k_slow
+                else { p_next = h; base_next = base + nproc; }
+            }
+            if (done) p_next = c1;
+            // ---- prefetch the next tile while this one is hashed and looked up ----------------------
+            TileRegs N;
+            u32 parked_next = 0;
+            if (p_next < c1) {
+                load_tile(A, p_next & ~(u64)3, min((p_next & ~(u64)3) + (u64)WT, A.n), lane, N);
+                parked_next = __hip_atomic_load(&A.ctr->full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (giant && lane == 0) {
+                const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
+                if (qi < A.queue_cap) A.queue[qi] = p; else atomicOr(&A.ctr->err, ERR_QUEUE);
+            }
+
+            // ---- (b) per-read target sets in LDS; first occurrences feed the read's set hash ------
+            if (!(A.ablate & 1u)) {
+                u64 ca = 0, cb = 0;
+                u32 crl = PENDING;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if ((m_ok >> k & 1u) && r_rl[k] < nproc) {
+                        const u32 rl = r_rl[k];
+                        const u32 s2 = 2u * L.seg[rl], len2 = 2u * L.seg[rl + 1] - s2;
+                        const u32 key = r_key[k] + 1u;
+                        u32 q = s2 + __umulhi(r_key[k] * 0x9E3779B1u, len2);
+                        bool fresh;
+                        for (;;) {
+                            const u32 old = atomicCAS(&L.tkey[q], 0u, key);
+                            if (old == 0u) { fresh = true; break; }
+                            if (old == key) { fresh = false; break; }   // duplicate (read, target): bam_utils.py:322-325
+                            if (++q == s2 + len2) q = s2;
+                        }
+                        if (fresh) {
+                            if (rl != crl) {
+                                if (crl != PENDING) { atomicAdd(&L.acc_a[crl], ca); atomicAdd(&L.acc_b[crl], cb); }
+                                crl = rl; ca = 0; cb = 0;
+                            }
+                            u64 a, b; target_hash(r_key[k], a, b); ca += a; cb += b;
                         }
                     }
                 }
-                prev = rr[j];
+                if (crl != PENDING) { atomicAdd(&L.acc_a[crl], ca); atomicAdd(&L.acc_b[crl], cb); }
             }
-        }
-        if (tid == 0) seg[nr] = (unsigned short)(te - tb);      // end sentinel (nr <= TILE)
-        if (bad) atomicOr(&s_err, bad);
-        __syncthreads();
-        if (s_err) {                                            // never index LDS with a broken run counter
-            if (tid == 0) atomicOr(&A.ctr->err, s_err);
-            return;
-        }
-        const u32 next_head = (nrc < nr) ? seg[nrc] : 0u;       // head of the read left incomplete
+            wave_sync();
 
-        // ---- (b) per-read locus tables in LDS ----------------------------------------------
-#pragma unroll
-        for (int k = 0; k < RPL; ++k) {
-            if ((r_ok >> k & 1u) && !(A.ablate & 1u)) {
-                const u32 s2 = 2u * seg[r_rl[k]], len2 = 2u * seg[r_rl[k] + 1] - s2;
-                const u32 key = r_loc[k] + 1u;
-                const u32 bit = 1u << ((r_hf[k] >> ECB_HAP_SHIFT) & 0xFFu);
-                u32 q = s2 + __umulhi(r_loc[k] * 0x9E3779B1u, len2);
-                for (;;) {
-                    const u32 old = atomicCAS(&tkey[q], 0u, key);
-                    if (old == 0u || old == key) { atomicOr(&tmask[q], bit); break; }
-                    if (++q == s2 + len2) q = s2;
-                }
-            }
-        }
-        __syncthreads();
-
-        // ---- (c) one lane per read: set hash, EC upsert ------------------------------------
-        if (A.ablate & 2u) {                                    // profiling only: just clear the tables
-            __syncthreads();
-            for (u32 q = tid; q < 2 * TILE; q += TPB) { tkey[q] = 0; tmask[q] = 0; }
-        }
-        for (u32 k0 = 0; k0 < nproc && !(A.ablate & 3u); k0 += TPB) {
-            const u32 k = k0 + tid;
-            const bool act = k < nproc;
-            u32 s2 = 0, e2 = 0, npairs = 0;
-            u64 s_a = 0, s_b = 0;
-            if (act) {
-                s2 = 2u * seg[k]; e2 = 2u * seg[k + 1];
-                for (u32 q = s2; q < e2; ++q) {
-                    const u32 key = tkey[q];
-                    if (key) { u64 a, b; pair_hash(key - 1u, tmask[q], a, b); s_a += a; s_b += b; ++npairs; }
-                }
-            }
-            bool created = false;
-            u64 slot = ~0ull;
-            if (act) {
+            // ---- (c) one lane per read: EC lookup; the read's slot is all that is recorded ----------
+            if (lane < nproc && !(A.ablate & 3u)) {
                 u64 lo, hi;
-                finish_hash(s_a, s_b, npairs, lo, hi);
-                if (A.ablate & 4u) slot = lo & A.cap_mask;
-                else if (A.ablate & 8u) {                       // profiling only: same atomics, uncontended random slots
-                    slot = (lo ^ mix64(base + k)) & A.cap_mask;
-                    atomicAdd(&A.table[slot].count, 1u); atomicMax(&A.table[slot].first_inv, ~(base + k));
-                } else if (A.ablate & 16u) {                    // profiling only: lookup without the two atomics
-                    slot = table_upsert(A.table, A.cap_mask, lo, hi, 0u, 0xFFFFFFFFu, &created);
-                } else slot = table_upsert(A.table, A.cap_mask, lo, hi, 1u, base + k, &created);
-                if (slot == ~0ull) {                            // table too full here: defer the read
-                    atomicExch(&A.ctr->full, 1u);
-                    const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
-                    if (qi < A.queue_cap) A.queue[qi] = tb + seg[k]; else atomicOr(&A.ctr->err, ERR_QUEUE);
+                finish_hash(L.acc_a[lane], L.acc_b[lane], lo, hi);
+                const u32 rd = base + lane;
+                if (A.ablate & 4u) {
+                    A.read_slot[rd] = (u32)(lo & A.cap_mask);
                 } else {
-                    A.read_slot[base + k] = (u32)slot;
-                }
-            }
-            // key arena: one allocation per wave for all the ECs its lanes created
-            const u32 want = created ? npairs : 0u;
-            u32 incl = want;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(incl, d); if (lane >= (u32)d) incl += t; }
-            const u32 total = __shfl(incl, 63);
-            const u64 n_created = __popcll(__ballot(created));
-            u64 wbase = 0;
-            if (total) {
-                if (lane == 63) {
-                    wbase = atomicAdd(&A.ctr->arena_top, (u64)total);
-                    atomicAdd(&A.ctr->n_ecs, n_created);
-                }
-                wbase = __shfl(wbase, 63);
-            }
-            u64 off = wbase + incl - want;
-            const bool fits = off + want <= A.arena_cap;
-            if (created) {
-                if (fits) { A.table[slot].off = (u32)off; A.table[slot].n = npairs; }
-                else atomicOr(&A.ctr->err, ERR_ARENA);
-            }
-            if (act) {                                          // second walk: save the key, clear the range
-                for (u32 q = s2; q < e2; ++q) {
-                    const u32 key = tkey[q];
-                    if (key) {
-                        if (created && fits) A.arena[off++] = make_uint2(key - 1u, tmask[q]);
-                        tkey[q] = 0; tmask[q] = 0;
+                    bool created = false;
+                    const u64 j = table_find_or_insert(A.table, A.cap_mask, lo, hi, &created);
+                    const u64 h = tb + L.seg[lane];
+                    if (j == ~0ull) {                               // table too full here: defer the read, park
+                        atomicExch(&A.ctr->full, 1u);
+                        const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
+                        if (qi < A.queue_cap) A.queue[qi] = h; else atomicOr(&A.ctr->err, ERR_QUEUE);
+                    } else {
+                        if (created) {                              // key extraction is deferred to k_keys
+                            A.table[j].off = (u32)h;
+                            A.table[j].n = KEY_PENDING | (u32)(h >> 32);
+                        }
+                        A.read_slot[rd] = (u32)j;
                     }
                 }
             }
-        }
+            wave_sync();
 
-        counted = max(counted, cnt_hi);
-        if (te >= c1 && nown <= nrc) { p = c1; break; }         // every read that starts in our slice is done
-        if (nrc < nr) {
-            const u64 h = tb + next_head;
-            if (h == p) {                                       // a single read fills the whole tile
-                if (tid == 0) {
-                    const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
-                    if (qi < A.queue_cap) A.queue[qi] = p; else atomicOr(&A.ctr->err, ERR_QUEUE);
-                }
-                p = te;
-            } else {
-                p = h;
-            }
-        } else {
-            p = te;
+            counted = max(counted, cnt_hi);
+            p = p_next; base = base_next; R = N; parked = parked_next;
         }
-        __syncthreads();
+        if (lane == 0) { A.resume[2 * wid] = p; A.resume[2 * wid + 1] = counted; }
+        // records offered / valid: one atomic pair per wave
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { my_all += __shfl_xor(my_all, d); my_valid += __shfl_xor(my_valid, d); }
+        if (lane == 0) { atomicAdd(&A.ctr->all, my_all); atomicAdd(&A.ctr->valid, my_valid); }
     }
 
-    if (tid == 0) { A.resume[2 * blockIdx.x] = p; A.resume[2 * blockIdx.x + 1] = counted; }
-    // records offered / valid: one atomic pair per workgroup
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { my_all += __shfl_down(my_all, d); my_valid += __shfl_down(my_valid, d); }
-    if (lane == 0) { s_red[2 * (tid >> 6)] = my_all; s_red[2 * (tid >> 6) + 1] = my_valid; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_keys: extract the (locus, mask) key of every EC that k_stream created, from the records of the
+// read that created it.  Pass 1 counts pairs per EC, an exclusive scan places them, pass 2 writes.
+// One wave per EC; reads longer than KEYS_SMALL records go to the workgroup-wide variant.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_collect_new(const Slot* table, u64 cap, u32* list, u64 max_list, u64* n_list) {
+    __shared__ u32 s_cnt;
+    __shared__ u64 s_base;
+    for (u64 b = (u64)blockIdx.x * TPB; b < cap; b += (u64)gridDim.x * TPB) {
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        const u64 i = b + threadIdx.x;
+        const bool pend = i < cap && table[i].hi != 0ull && (table[i].n & KEY_PENDING);
+        u32 my = 0;
+        if (pend) my = atomicAdd(&s_cnt, 1u);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(n_list, (u64)s_cnt);
+        __syncthreads();
+        if (pend && s_base + my < max_list) list[s_base + my] = (u32)i;
+        __syncthreads();
+    }
+}
+
+constexpr int KEYS_WT = 1024;        // entries of one wave's LDS table in k_keys
+constexpr u32 KEYS_MAXL = KEYS_WT / 2;   // longer reads take the k_slow route (key-only mode)
+
+template <bool WRITE>
+__global__ __launch_bounds__(TPB) void k_keys(const u32* rid, const u32* loc, const u32* hf, u64 n,
+                                              Slot* table, const u32* list, u64 n_list,
+                                              u32* nlen, const u32* noff, u64 arena_base, uint2* arena,
+                                              u64* slowq, u32* slowslot, u64* n_slow) {
+    __shared__ u32 wk[TPB / 64][KEYS_WT], wm[TPB / 64][KEYS_WT];
+    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const u64 e = (u64)blockIdx.x * (TPB / 64) + w;
+    const bool act = e < n_list;
+    u32* K = wk[w];
+    u32* M = wm[w];
+    for (u32 q = lane; q < KEYS_WT; q += 64) { K[q] = 0; M[q] = 0; }
+    Slot* s = act ? table + list[e] : table;
+    u64 head = 0;
+    u32 L = 0;
+    if (act) {
+        head = (u64)s->off | ((u64)(s->n & ~KEY_PENDING) << 32);
+        const u32 r0 = rid[head];
+        for (u64 i0 = head;; i0 += 64) {                 // length of the creating read, in records
+            const u64 i = i0 + lane;
+            const u64 m = __ballot(i < n && rid[i] == r0);
+            L += __popcll(m);
+            if (m != ~0ull) break;
+        }
+    }
+    const bool small = act && L <= KEYS_MAXL;
     __syncthreads();
-    if (tid == 0) {
-        u64 a = 0, v = 0;
-        for (int w = 0; w < TPB / 64; ++w) { a += s_red[2 * w]; v += s_red[2 * w + 1]; }
-        atomicAdd(&A.ctr->all, a);
-        atomicAdd(&A.ctr->valid, v);
+    if (small) {
+        for (u32 t = lane; t < L; t += 64) {
+            const u32 f = hf[head + t];
+            if (!rec_valid(f)) continue;
+            const u32 lc = loc[head + t], key = lc + 1u, bit = 1u << ((f >> ECB_HAP_SHIFT) & 0xFFu);
+            u32 q = __umulhi(lc * 0x9E3779B1u, (u32)KEYS_WT);
+            for (;;) {
+                const u32 old = atomicCAS(&K[q], 0u, key);
+                if (old == 0u || old == key) { atomicOr(&M[q], bit); break; }
+                if (++q == KEYS_WT) q = 0;
+            }
+        }
+    }
+    __syncthreads();
+    if (!act) return;
+    if (!small) {
+        if (!WRITE && lane == 0) {
+            const u64 qi = atomicAdd(n_slow, 1ull);
+            slowq[qi] = head; slowslot[qi] = list[e];
+            nlen[e] = 0;
+        }
+        return;
+    }
+    u32 cnt = 0;
+    const u64 dst = WRITE ? arena_base + noff[e] : 0;
+    for (u32 q0 = 0; q0 < KEYS_WT; q0 += 64) {
+        const u32 q = q0 + lane;
+        const bool occ = K[q] != 0u;
+        const u64 m = __ballot(occ);
+        if (WRITE && occ) arena[dst + cnt + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2(K[q] - 1u, M[q]);
+        cnt += __popcll(m);
+    }
+    if (lane == 0) {
+        if (WRITE) { s->off = (u32)dst; s->n = cnt; }
+        else nlen[e] = cnt;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_count: reads per EC and first appearance per EC (bam_utils.py:309-312, 688-698), reduced from the
+// per-read slot ids without global atomics: partition the (slot, read) pairs by slot range (LDS
+// histogram, scan, scatter), then one workgroup per range counts in LDS and owns its slots' counters.
+// ---------------------------------------------------------------------------------------------
+constexpr u32 BIN_BITS = 13;                   // slots per range = LDS bins of one k_count_bins workgroup
+constexpr u32 N_BINS = 1u << BIN_BITS;
+constexpr u32 MAX_BUCKETS = 8192;              // LDS histogram of the partition passes
+
+__global__ __launch_bounds__(TPB) void k_part_hist(const u32* read_slot, u64 n_reads, u32 n_buckets, u32* hist) {
+    extern __shared__ u32 sh[];
+    const u64 G = gridDim.x, g = blockIdx.x, per = (n_reads + G - 1) / G;
+    const u64 r0 = g * per, r1 = min(r0 + per, n_reads);
+    for (u32 b = threadIdx.x; b < n_buckets; b += TPB) sh[b] = 0;
+    __syncthreads();
+    for (u64 r = r0 + threadIdx.x; r < r1; r += TPB) {
+        const u32 s = read_slot[r];
+        if (s != PENDING) atomicAdd(&sh[s >> BIN_BITS], 1u);
+    }
+    __syncthreads();
+    for (u32 b = threadIdx.x; b < n_buckets; b += TPB) hist[(u64)b * G + g] = sh[b];
+}
+
+__global__ __launch_bounds__(TPB) void k_part_scatter(const u32* read_slot, u64 n_reads, u32 n_buckets, const u32* offs,
+                                                      uint2* pairs) {
+    extern __shared__ u32 sh[];
+    const u64 G = gridDim.x, g = blockIdx.x, per = (n_reads + G - 1) / G;
+    const u64 r0 = g * per, r1 = min(r0 + per, n_reads);
+    for (u32 b = threadIdx.x; b < n_buckets; b += TPB) sh[b] = offs[(u64)b * G + g];
+    __syncthreads();
+    for (u64 r = r0 + threadIdx.x; r < r1; r += TPB) {
+        const u32 s = read_slot[r];
+        if (s != PENDING) pairs[atomicAdd(&sh[s >> BIN_BITS], 1u)] = make_uint2(s, (u32)r);
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_count_bins(const uint2* pairs, const u32* offs, u32 G, u32 n_buckets, u32 total,
+                                                    Slot* table) {
+    __shared__ u32 cnt[N_BINS], fst[N_BINS];
+    const u32 b = blockIdx.x, lane = threadIdx.x & 63u;
+    const u32 start = offs[(u64)b * G], end = (b + 1 < n_buckets) ? offs[(u64)(b + 1) * G] : total;
+    for (u32 q = threadIdx.x; q < N_BINS; q += TPB) { cnt[q] = 0; fst[q] = 0xFFFFFFFFu; }
+    __syncthreads();
+    for (u32 i0 = start; i0 < end; i0 += TPB) {
+        const u32 i = i0 + threadIdx.x;
+        const bool have = i < end;
+        uint2 pr = have ? pairs[i] : make_uint2(0, 0xFFFFFFFFu);
+        const u32 bin = pr.x & (N_BINS - 1);
+        // a hot EC fills most lanes of a wave: add it once per wave, the rest go one by one
+        const u32 v = __shfl(bin, __ffsll((long long)__ballot(have)) - 1);
+        const bool same = have && bin == v;
+        const u64 m = __ballot(same);
+        if (__popcll(m) >= 8) {
+            u32 mn = same ? pr.y : 0xFFFFFFFFu;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) mn = min(mn, (u32)__shfl_xor(mn, d));
+            if (lane == (u32)(__ffsll((long long)m) - 1)) { atomicAdd(&cnt[v], (u32)__popcll(m)); atomicMin(&fst[v], mn); }
+            if (have && !same) { atomicAdd(&cnt[bin], 1u); atomicMin(&fst[bin], pr.y); }
+        } else if (have) {
+            atomicAdd(&cnt[bin], 1u); atomicMin(&fst[bin], pr.y);
+        }
+    }
+    __syncthreads();
+    for (u32 q = threadIdx.x; q < N_BINS; q += TPB) {
+        const u32 c = cnt[q];
+        if (c) {                                           // this workgroup is the only writer of its slots
+            Slot* s = table + (((u64)b << BIN_BITS) | q);
+            s->count += c;
+            s->first_inv = max(s->first_inv, ~fst[q]);
+        }
     }
 }
 
@@ -389,6 +573,7 @@ struct SlowArgs {
     Counters* ctr;
     u32* read_slot;
     u64* requeue; u64* n_requeue;                           // reads that still found no slot
+    const u32* key_slot;                                    // non-null: the EC exists (slot given); only extract its key
 };
 
 __global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
@@ -421,8 +606,12 @@ __global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
     for (u64 p = tid; p < cap2; p += TPB) {
         const u32 k = __hip_atomic_load(&key[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (k) {
-            const u32 m = __hip_atomic_load(&msk[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            u64 x, y; pair_hash(k - 1u, m, x, y); a += x; b += y; ++np;
+            u32 m = __hip_atomic_load(&msk[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ++np;
+            while (m) {                                     // same set hash as k_stream: sum over distinct targets
+                const u32 hp = __ffs(m) - 1; m &= m - 1;
+                u64 x, y; target_hash(target_key(k - 1u, hp), x, y); a += x; b += y;
+            }
         }
     }
 #pragma unroll
@@ -432,18 +621,20 @@ __global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
     if (tid == 0) {
         a = b = 0; np = 0;
         for (int w = 0; w < TPB / 64; ++w) { a += s_a[w]; b += s_b[w]; np += s_n[w]; }
-        u64 lo, hi; finish_hash(a, b, np, lo, hi);
+        u64 lo, hi; finish_hash(a, b, lo, hi);
         bool created = false;
         const u32 r0 = A.rid[h];
-        const u64 slot = table_upsert(A.table, A.cap_mask, lo, hi, 1u, r0, &created);
+        u64 slot;
+        if (A.key_slot) { slot = A.key_slot[q]; created = true; }
+        else slot = table_find_or_insert(A.table, A.cap_mask, lo, hi, &created);
         s_created = 0; s_cnt = 0; s_fits = 0; s_off = 0;
         if (slot == ~0ull) {
             A.requeue[atomicAdd(A.n_requeue, 1ull)] = h;
         } else {
-            A.read_slot[r0] = (u32)slot;
+            if (!A.key_slot) A.read_slot[r0] = (u32)slot;
             if (created) {
                 const u64 off = atomicAdd(&A.ctr->arena_top, (u64)np);
-                atomicAdd(&A.ctr->n_ecs, 1ull);
+                if (!A.key_slot) atomicAdd(&A.ctr->n_ecs, 1ull);
                 s_created = 1; s_off = off; s_fits = (off + np <= A.arena_cap);
                 if (s_fits) { A.table[slot].off = (u32)off; A.table[slot].n = np; }
                 else atomicOr(&A.ctr->err, ERR_ARENA);
@@ -527,8 +718,10 @@ __global__ void k_merge(const Slot* ent, u64 n, const uint2* pairs, u64 n_pairs,
     const Slot s = ent[e];
     if ((u64)s.off + s.n > n_pairs) { atomicOr(&ctr->err, ERR_CONTRACT); return; }
     bool created = false;
-    const u64 j = table_upsert(table, cap_mask, s.lo, s.hi, s.count, ~s.first_inv, &created);
+    const u64 j = table_find_or_insert(table, cap_mask, s.lo, s.hi, &created);
     if (j == ~0ull) { atomicAdd(&ctr->n_queue, 1ull); return; }   // host sizes the table so this cannot happen
+    atomicAdd(&table[j].count, s.count);                           // one pair of atomics per merged EC, not per read
+    atomicMax(&table[j].first_inv, s.first_inv);
     if (created) {
         const u64 off = atomicAdd(&ctr->arena_top, (u64)s.n);
         atomicAdd(&ctr->n_ecs, 1ull);
@@ -654,6 +847,7 @@ struct ecb_handle {
     hipStream_t stream = nullptr;
     std::string err;
     bool finalized = false;
+    bool counted = false;             // Slot::count / first_inv hold the reads pushed so far (k_count ran)
 
     Slot* table = nullptr; u64 cap = 0;
     uint2* arena = nullptr; u64 arena_cap = 0;
@@ -662,6 +856,9 @@ struct ecb_handle {
     u32* read_slot = nullptr; u64 read_slot_cap = 0;
     int *rng_min = nullptr, *rng_max = nullptr;
     u64* queue = nullptr; u64 queue_cap = 0;
+    u32* newlist = nullptr; u64 newlist_cap = 0;   // slots whose key is pending (k_collect_new)
+    u64 n_ecs_stream = 0;             // ECs created by k_stream launches (counted when their keys are extracted)
+    u64 n_ecs() const { return hctr.n_ecs + n_ecs_stream; }
     u32 prev_rid = 0xFFFFFFFFu;       // read_id of the last record pushed so far
     u64 n_reads = 0;
     u64 reads_hi = 0;                 // read_slot entries [0, reads_hi) may be set (n_reads, or more mid-batch)
@@ -738,9 +935,8 @@ int ensure_read_slot(ecb_handle* h, u64 need) {
 }
 
 // deferred reads: measure, scratch, k_slow; grow the table and repeat while reads bounce
-int run_slow(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf, u64 n) {
-    u64 nq = std::min<u64>(h->hctr.n_queue, h->queue_cap);
-    u64* d_q = h->queue;
+int run_slow(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf, u64 n,
+             u64* d_q, u64 nq, const u32* d_key_slot) {
     u64* d_requeue = nullptr;
     int rc = ECB_OK;
     while (nq) {
@@ -764,7 +960,7 @@ int run_slow(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf,
         HIPCHK(h, hipMemsetAsync(sm, 0, tot * sizeof(u32), h->stream));
         HIPCHK(h, hipMemcpyAsync(d_off, off.data(), nq * sizeof(u64), hipMemcpyHostToDevice, h->stream));
         SlowArgs a{d_rid, d_loc, d_hf, d_q, d_len, d_off, sk, sm, h->cfg.n_loci, h->cfg.n_haplotypes,
-                   h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr, h->read_slot, nre_buf, d_nre};
+                   h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr, h->read_slot, nre_buf, d_nre, d_key_slot};
         k_slow<<<(unsigned)nq, TPB, 0, h->stream>>>(a);
         u64 nre = 0;
         HIPCHK(h, hipMemcpyAsync(&nre, d_nre, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
@@ -776,6 +972,58 @@ int run_slow(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf,
         if (nq) { rc = grow_table(h, h->cap * 4); if (rc != ECB_OK) break; }
     }
     if (d_requeue) hipFree(d_requeue);
+    return rc;
+}
+
+int excl_scan(ecb_handle* h, const u32* in, u64 n, u32* out, u32* total);
+
+// keys of the ECs the last k_stream launch created: collect, count, scan, write (k_keys)
+int extract_keys(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf, u64 n) {
+    u64* d_cnt = nullptr;                       // [0] = new ECs, [1] = ECs routed to k_slow
+    HIPCHK(h, hipMalloc(&d_cnt, 2 * sizeof(u64)));
+    HIPCHK(h, hipMemsetAsync(d_cnt, 0, 2 * sizeof(u64), h->stream));
+    if (h->newlist_cap < h->cap) {
+        if (h->newlist) hipFree(h->newlist);
+        h->newlist_cap = h->cap;
+        HIPCHK(h, hipMalloc(&h->newlist, h->newlist_cap * sizeof(u32)));
+    }
+    k_collect_new<<<(unsigned)std::min<u64>(4096, (h->cap + TPB - 1) / TPB), TPB, 0, h->stream>>>(
+        h->table, h->cap, h->newlist, h->newlist_cap, d_cnt);
+    u64 n_new = 0;
+    HIPCHK(h, hipMemcpyAsync(&n_new, d_cnt, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int rc = ECB_OK;
+    if (n_new) {
+        u32 *nlen = nullptr, *noff = nullptr, *slowslot = nullptr;
+        u64* slowq = nullptr;
+        HIPCHK(h, hipMalloc(&nlen, n_new * 4)); HIPCHK(h, hipMalloc(&noff, n_new * 4));
+        HIPCHK(h, hipMalloc(&slowslot, n_new * 4)); HIPCHK(h, hipMalloc(&slowq, n_new * 8));
+        const unsigned gb = nblk(n_new, TPB / 64);
+        k_keys<false><<<gb, TPB, 0, h->stream>>>(d_rid, d_loc, d_hf, n, h->table, h->newlist, n_new, nlen, noff, 0,
+                                                 h->arena, slowq, slowslot, d_cnt + 1);
+        u32 total = 0;
+        rc = excl_scan(h, nlen, n_new, noff, &total);
+        if (rc == ECB_OK) rc = sync_counters(h);
+        if (rc == ECB_OK) {
+            const u64 base = h->hctr.arena_top;
+            if (base + total > h->arena_cap)
+                rc = fail(h, ECB_ERR_TABLE_FULL, "EC key arena exhausted (%llu pairs): raise arena_capacity",
+                          (unsigned long long)h->arena_cap);
+            else {
+                const u64 top = base + total;
+                hipMemcpyAsync(&h->ctr->arena_top, &top, sizeof(u64), hipMemcpyHostToDevice, h->stream);
+                k_keys<true><<<gb, TPB, 0, h->stream>>>(d_rid, d_loc, d_hf, n, h->table, h->newlist, n_new, nlen, noff,
+                                                        base, h->arena, slowq, slowslot, d_cnt + 1);
+                u64 n_slowk = 0;
+                hipMemcpyAsync(&n_slowk, d_cnt + 1, sizeof(u64), hipMemcpyDeviceToHost, h->stream);
+                rc = sync_counters(h);
+                if (rc == ECB_OK && n_slowk) rc = run_slow(h, d_rid, d_loc, d_hf, n, slowq, n_slowk, slowslot);
+                if (rc == ECB_OK) h->n_ecs_stream += n_new;
+            }
+        }
+        hipFree(nlen); hipFree(noff); hipFree(slowslot); hipFree(slowq);
+    }
+    hipFree(d_cnt);
     return rc;
 }
 
@@ -791,31 +1039,33 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     if (rc != ECB_OK) return rc;
     h->reads_hi = reads_after;
     // keep the table at most half full before a batch (it grows again, via k_slow, if a batch overfills it)
-    while (h->hctr.n_ecs * 2 > h->cap) { rc = grow_table(h, h->cap * 4); if (rc != ECB_OK) return rc; }
+    while (h->n_ecs() * 2 > h->cap) { rc = grow_table(h, h->cap * 4); if (rc != ECB_OK) return rc; }
     int cus = 256;
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
-    u64 blocks = std::min<u64>((u64)cus * 4, (n + 4 * TILE - 1) / (4 * TILE));
-    blocks = std::max<u64>(blocks, 1);
-    u64 chunk = (n + blocks - 1) / blocks;
+    // one contiguous slice per wave; enough waves to fill every CU a few times over
+    u64 waves = std::min<u64>((u64)cus * 5 * NWAVE, (n + 2 * WT - 1) / (2 * WT));
+    waves = std::max<u64>(waves, 1);
+    u64 chunk = (n + waves - 1) / waves;
     chunk = (chunk + 3) & ~(u64)3;
-    blocks = (n + chunk - 1) / chunk;
+    waves = (n + chunk - 1) / chunk;
+    const u64 blocks = (waves + NWAVE - 1) / NWAVE;
     // a parked launch defers at most the reads of the tiles in flight
-    const u64 need_q = blocks * (u64)TILE + 16;
+    const u64 need_q = waves * (u64)(WMAXR + 1) + 16;
     if (h->queue_cap < need_q) {
         if (h->queue) hipFree(h->queue);
         h->queue_cap = need_q;
         HIPCHK(h, hipMalloc(&h->queue, h->queue_cap * sizeof(u64)));
     }
     u64* d_resume = nullptr;
-    HIPCHK(h, hipMalloc(&d_resume, 2 * blocks * sizeof(u64)));
+    HIPCHK(h, hipMalloc(&d_resume, 2 * waves * sizeof(u64)));
     {
-        std::vector<u64> r0(2 * blocks);
-        for (u64 b = 0; b < blocks; ++b) r0[2 * b] = r0[2 * b + 1] = b * chunk;
-        HIPCHK(h, hipMemcpyAsync(d_resume, r0.data(), 2 * blocks * sizeof(u64), hipMemcpyHostToDevice, h->stream));
+        std::vector<u64> r0(2 * waves);
+        for (u64 b = 0; b < waves; ++b) r0[2 * b] = r0[2 * b + 1] = b * chunk;
+        HIPCHK(h, hipMemcpyAsync(d_resume, r0.data(), 2 * waves * sizeof(u64), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     StreamArgs a{d_rid, d_loc, d_hf, d_pos, n, chunk, h->prev_rid, h->cfg.n_loci, h->cfg.n_haplotypes,
-                 h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr, h->read_slot,
+                 h->table, h->cap - 1, h->ctr, h->read_slot,
                  h->rng_min, h->rng_max, h->queue, h->queue_cap, d_resume,
                  getenv("ECB_ABLATE") ? (u32)atoi(getenv("ECB_ABLATE")) : 0u};
     for (;;) {
@@ -833,7 +1083,12 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
         }
         if (rc != ECB_OK) break;
         const bool parked = h->hctr.full != 0;
-        if (h->hctr.n_queue) { rc = run_slow(h, d_rid, d_loc, d_hf, n); if (rc != ECB_OK) break; }
+        if (h->hctr.n_queue) {
+            rc = run_slow(h, d_rid, d_loc, d_hf, n, h->queue, std::min<u64>(h->hctr.n_queue, h->queue_cap), nullptr);
+            if (rc != ECB_OK) break;
+        }
+        rc = extract_keys(h, d_rid, d_loc, d_hf, n);
+        if (rc != ECB_OK) break;
         if (!parked) break;
         rc = grow_table(h, h->cap * 4);                 // some workgroups stopped early: more room, then resume
         if (rc != ECB_OK) break;
@@ -902,18 +1157,46 @@ int excl_scan(ecb_handle* h, const u32* in, u64 n, u32* out, u32* total) {
     return ECB_OK;
 }
 
+// reads per EC / first appearance, from read_slot[0, n_reads) (once, when the stream is closed)
+int ensure_counts(ecb_handle* h) {
+    if (h->counted) return ECB_OK;
+    const u64 R = h->n_reads;
+    if (R) {
+        const u32 nb = (u32)std::max<u64>(1, h->cap >> BIN_BITS);
+        if (nb > MAX_BUCKETS) return fail(h, ECB_ERR_LIMIT, "EC table larger than 2^26 slots is not supported yet");
+        const u32 G = (u32)std::min<u64>(1024, (R + 4095) / 4096);
+        u32 *hist = nullptr, *offs = nullptr;
+        uint2* pairs = nullptr;
+        HIPCHK(h, hipMalloc(&hist, (u64)nb * G * 4)); HIPCHK(h, hipMalloc(&offs, (u64)nb * G * 4));
+        HIPCHK(h, hipMalloc(&pairs, R * sizeof(uint2)));
+        k_part_hist<<<G, TPB, nb * 4, h->stream>>>(h->read_slot, R, nb, hist);
+        u32 total = 0;
+        int rc = excl_scan(h, hist, (u64)nb * G, offs, &total);
+        if (rc == ECB_OK) {
+            k_part_scatter<<<G, TPB, nb * 4, h->stream>>>(h->read_slot, R, nb, offs, pairs);
+            k_count_bins<<<nb, TPB, 0, h->stream>>>(pairs, offs, G, nb, total, h->table);
+            hipError_t e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) rc = fail(h, ECB_ERR_HIP, "k_count: %s", hipGetErrorString(e));
+        }
+        hipFree(hist); hipFree(offs); hipFree(pairs);
+        if (rc != ECB_OK) return rc;
+    }
+    h->counted = true;
+    return ECB_OK;
+}
+
 int compact_table(ecb_handle* h) {
     if (h->list) { hipFree(h->list); h->list = nullptr; }
     u64* d_n = nullptr;
     HIPCHK(h, hipMalloc(&d_n, sizeof(u64)));
     HIPCHK(h, hipMemsetAsync(d_n, 0, sizeof(u64), h->stream));
-    HIPCHK(h, hipMalloc(&h->list, std::max<u64>(h->hctr.n_ecs, 1) * sizeof(u32)));
-    k_compact<<<(unsigned)std::min<u64>(4096, (h->cap + TPB - 1) / TPB), TPB, 0, h->stream>>>(h->table, h->cap, h->list, std::max<u64>(h->hctr.n_ecs, 1), d_n);
+    HIPCHK(h, hipMalloc(&h->list, std::max<u64>(h->n_ecs(), 1) * sizeof(u32)));
+    k_compact<<<(unsigned)std::min<u64>(4096, (h->cap + TPB - 1) / TPB), TPB, 0, h->stream>>>(h->table, h->cap, h->list, std::max<u64>(h->n_ecs(), 1), d_n);
     HIPCHK(h, hipMemcpyAsync(&h->n_list, d_n, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipFree(d_n));
-    if (h->n_list != h->hctr.n_ecs) return fail(h, ECB_ERR_HIP, "internal: %llu occupied slots but %llu ECs created",
-                                                (unsigned long long)h->n_list, (unsigned long long)h->hctr.n_ecs);
+    if (h->n_list != h->n_ecs()) return fail(h, ECB_ERR_HIP, "internal: %llu occupied slots but %llu ECs created",
+                                             (unsigned long long)h->n_list, (unsigned long long)h->n_ecs());
     return ECB_OK;
 }
 
@@ -933,7 +1216,7 @@ const char* ecb_last_error(const ecb_handle* h) { return h ? h->err.c_str() : g_
 
 int ecb_create(const ecb_config* cfg, ecb_handle** out) {
     if (!cfg || !out || cfg->struct_size != sizeof(ecb_config)) return fail(nullptr, ECB_ERR_ARG, "bad ecb_config (struct_size)");
-    if (cfg->n_loci == 0 || cfg->n_loci >= (1u << 31)) return fail(nullptr, ECB_ERR_ARG, "n_loci out of range");
+    if (cfg->n_loci == 0 || cfg->n_loci >= MAX_LOCI) return fail(nullptr, ECB_ERR_ARG, "n_loci out of range (1 .. 2^27-1)");
     if (cfg->n_haplotypes == 0 || cfg->n_haplotypes > 31) return fail(nullptr, ECB_ERR_ARG, "n_haplotypes must be 1..31 (A stores a bitmask in int32)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, ECB_ERR_NO_DEVICE, "no HIP device: libecb has no CPU path");
@@ -978,7 +1261,7 @@ void ecb_destroy(ecb_handle* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     free_results(h);
     hipFree(h->table); hipFree(h->arena); hipFree(h->ctr); hipFree(h->read_slot);
-    hipFree(h->rng_min); hipFree(h->rng_max); hipFree(h->queue);
+    hipFree(h->rng_min); hipFree(h->rng_max); hipFree(h->queue); hipFree(h->newlist);
     hipFree(h->st_rid); hipFree(h->st_loc); hipFree(h->st_hf); hipFree(h->st_pos);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -1000,17 +1283,18 @@ int ecb_reset(ecb_handle* h) {
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->hctr = Counters{};
+    h->n_ecs_stream = 0;
     h->prev_rid = 0xFFFFFFFFu; h->n_reads = 0; h->reads_hi = 0;
     h->extra_all = h->extra_valid = h->extra_reads = 0;
     h->c_rid.clear(); h->c_loc.clear(); h->c_hf.clear(); h->c_pos.clear();
-    h->finalized = false; h->sizes = ecb_sizes{}; h->n_list = 0;
+    h->finalized = false; h->counted = false; h->sizes = ecb_sizes{}; h->n_list = 0;
     return ECB_OK;
 }
 
 int ecb_push_device(ecb_handle* h, const void* d_read_id, const void* d_locus, const void* d_hapflag,
                     const void* d_pos, size_t n) {
     if (!h) return ECB_ERR_ARG;
-    if (h->finalized) return fail(h, ECB_ERR_STATE, "push after finalize");
+    if (h->finalized || h->counted) return fail(h, ECB_ERR_STATE, "push after finalize / table export");
     if (n && (!d_read_id || !d_locus || !d_hapflag)) return fail(h, ECB_ERR_ARG, "null tuple stream");
     if ((h->cfg.flags & ECB_F_RANGES) && n && !d_pos) return fail(h, ECB_ERR_ARG, "ECB_F_RANGES needs pos");
     if (((uintptr_t)d_read_id | (uintptr_t)d_locus | (uintptr_t)d_hapflag) & 15) return fail(h, ECB_ERR_ARG, "device streams must be 16-byte aligned");
@@ -1021,7 +1305,7 @@ int ecb_push_device(ecb_handle* h, const void* d_read_id, const void* d_locus, c
 
 int ecb_push(ecb_handle* h, const uint32_t* rid, const uint32_t* loc, const uint32_t* hf, const int32_t* pos, size_t n) {
     if (!h) return ECB_ERR_ARG;
-    if (h->finalized) return fail(h, ECB_ERR_STATE, "push after finalize");
+    if (h->finalized || h->counted) return fail(h, ECB_ERR_STATE, "push after finalize / table export");
     if (n && (!rid || !loc || !hf)) return fail(h, ECB_ERR_ARG, "null tuple stream");
     const bool rg = (h->cfg.flags & ECB_F_RANGES) != 0;
     if (rg && n && !pos) return fail(h, ECB_ERR_ARG, "ECB_F_RANGES needs pos");
@@ -1069,8 +1353,10 @@ int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
         }
         int rc = sync_counters(h);
         if (rc != ECB_OK) return rc;
+        rc = ensure_counts(h);
+        if (rc != ECB_OK) return rc;
     }
-    const u64 E = h->hctr.n_ecs;
+    const u64 E = h->n_ecs();
     const u64 valid = h->hctr.valid + h->extra_valid;
     if (E == 0 || valid == 0) return fail(h, ECB_ERR_EMPTY, "no valid alignments: nothing to build (the reference fails here too)");
     if (E >= (1ull << 31) - 1) return fail(h, ECB_ERR_LIMIT, "more than 2^31-2 equivalence classes");
@@ -1181,7 +1467,9 @@ int ecb_table_sizes(ecb_handle* h, uint64_t* n_entries, uint64_t* n_pairs, uint6
     }
     int rc = sync_counters(h);
     if (rc != ECB_OK) return rc;
-    if (n_entries) *n_entries = h->hctr.n_ecs;
+    rc = ensure_counts(h);
+    if (rc != ECB_OK) return rc;
+    if (n_entries) *n_entries = h->n_ecs();
     if (n_pairs) *n_pairs = h->hctr.arena_top;
     if (n_reads) *n_reads = h->n_reads;
     return ECB_OK;
@@ -1193,9 +1481,11 @@ int ecb_table_export_device(ecb_handle* h, void* d_entries, void* d_pairs, uint6
     int rc = sync_counters(h);
     if (rc != ECB_OK) return rc;
     if (read_base + h->n_reads >= (1ull << 32) - 1) return fail(h, ECB_ERR_LIMIT, "more than 2^32-2 reads in total");
+    rc = ensure_counts(h);
+    if (rc != ECB_OK) return rc;
     rc = compact_table(h);
     if (rc != ECB_OK) return rc;
-    const u64 E = h->hctr.n_ecs;
+    const u64 E = h->n_ecs();
     if (E) k_export_entries<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->table, h->list, E, (Slot*)d_entries, (u32)read_base);
     HIPCHK(h, hipMemcpyAsync(d_pairs, h->arena, h->hctr.arena_top * sizeof(uint2), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1210,7 +1500,9 @@ int ecb_table_merge_device(ecb_handle* h, const void* d_entries, uint64_t n_entr
     HIPCHK(h, hipSetDevice(h->device));
     int rc = sync_counters(h);
     if (rc != ECB_OK) return rc;
-    while ((h->hctr.n_ecs + n_entries) * 2 > h->cap) { rc = grow_table(h, h->cap * 4); if (rc != ECB_OK) return rc; }
+    rc = ensure_counts(h);                       // own reads first: merged counts are added on top
+    if (rc != ECB_OK) return rc;
+    while ((h->n_ecs() + n_entries) * 2 > h->cap) { rc = grow_table(h, h->cap * 4); if (rc != ECB_OK) return rc; }
     HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));
     k_merge<<<nblk(n_entries, TPB), TPB, 0, h->stream>>>((const Slot*)d_entries, n_entries, (const uint2*)d_pairs, n_pairs,
                                                           h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr);

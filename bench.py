@@ -119,7 +119,7 @@ def main():
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
 
-    ec_cap = 1 << 22
+    ec_cap = 1 << int(os.environ.get("ECB_EC_CAP_LOG2", "22"))
     b = ecb.EcBuilder(T, H, device=local, ec_capacity=ec_cap, arena_capacity=1 << 26)
     eng = ecdist.GpuEngine(b, device)
     root_eng = None
