@@ -47,7 +47,7 @@ constexpr int TILE = TPB * RPL;      // records per tile
 constexpr int MAXR = 512;            // reads finished per tile (more heads than this: the next tile starts there)
 constexpr u32 MAX_PROBE = 256;       // EC-table probes before a read is deferred to k_slow
 constexpr u32 PENDING = 0xFFFFFFFFu;
-constexpr u32 KEY_PENDING = 0x80000000u;   // Slot::n bit: key not extracted yet, (off, n) hold the head record index
+constexpr u32 ARENA_CHUNK = 512;     // pairs a wave reserves from the key arena per global atomic
 constexpr u32 MAX_LOCI = 1u << 27;   // (locus << 5 | hap) + 1 must fit 32 bits
 
 constexpr u32 ERR_CONTRACT = 1u;     // device error bits (Counters::err)
@@ -59,7 +59,7 @@ struct Slot {                        // 32 bytes, one EC
     u64 lo, hi;                      // 126-bit set hash, both non-zero once claimed
     u32 count;                       // reads in this EC
     u32 first_inv;                   // ~(smallest read index)  (atomicMax on zero-initialised memory)
-    u32 off, n;                      // key = arena[off .. off+n); or, while n & KEY_PENDING, the creating read's head index
+    u32 off, n;                      // key = arena[off .. off+n): (locus, haplotype mask) pairs
 };
 
 struct Counters {
@@ -73,8 +73,9 @@ struct Counters {
 
 // ---------------------------------------------------------------------------------------------
 // hashing: EC identity = the SET of (locus, haplotype) targets of a read (bam_utils.py:307 builds a
-// sorted string for the same purpose).  Set hash = sum over distinct targets of a 2 x 64-bit mix,
-// finalised; commutative, so records need no sorting and duplicates are dropped before summing.
+// sorted string for the same purpose).  The set is held as {locus -> haplotype mask}; its hash is the sum
+// over loci of four 32-bit mixes of (locus, mask), finalised to 2 x 63 bits.  The sum commutes, so records
+// need no sorting, and OR-ing haplotype bits makes duplicate (read, target) records vanish by itself.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ u64 mix64(u64 z) {
     z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
@@ -82,15 +83,28 @@ __device__ __forceinline__ u64 mix64(u64 z) {
     z ^= z >> 31;
     return z;
 }
-__device__ __forceinline__ u32 target_key(u32 locus, u32 hap) { return (locus << 5) | hap; }
-__device__ __forceinline__ void target_hash(u32 tkey, u64& a, u64& b) {
-    const u64 x = tkey;
-    a = mix64(x + 0x9E3779B97F4A7C15ull);
-    b = mix64((x ^ 0xD6E8FEB86659FD93ull) * 0xFF51AFD7ED558CCDull + 0xC4CEB9FE1A85EC53ull);
+__device__ __forceinline__ u32 fmix32(u32 h) {           // murmur3 finaliser: a bijection with full avalanche
+    h ^= h >> 16; h *= 0x85EBCA6Bu;
+    h ^= h >> 13; h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
 }
-__device__ __forceinline__ void finish_hash(u64 s1, u64 s2, u64& lo, u64& hi) {
-    lo = mix64(s1) | 1ull;
-    hi = mix64(s2 ^ 0xA0761D6478BD642Full) | 1ull;
+// four 32-bit hashes of one (locus, haplotype mask) pair of a read's target set
+__device__ __forceinline__ void pair_hash(u32 locus, u32 mask, u32* h) {
+    const u32 x = fmix32(locus ^ 0x9E3779B9u), y = fmix32(mask * 0x9E3779B1u + 0x7F4A7C15u);
+    h[0] = fmix32(x + y);
+    h[1] = fmix32((x ^ 0x85EBCA77u) - (y << 7 | y >> 25));
+    h[2] = fmix32((x << 13 | x >> 19) ^ (y + 0xC2B2AE3Du));
+    h[3] = fmix32(~x + (y << 19 | y >> 13) * 0x27D4EB2Fu);
+}
+__device__ __forceinline__ void finish_hash(u64 s0, u64 s1, u32 n, u64& lo, u64& hi) {
+    lo = mix64(s0 + n) | 1ull;
+    hi = mix64(s1 ^ 0xA0761D6478BD642Full) | 1ull;
+}
+__device__ __forceinline__ void pair_hash64(u32 locus, u32 mask, u64& a, u64& b) {
+    u32 h[4];
+    pair_hash(locus, mask, h);
+    a = ((u64)h[1] << 32) | h[0]; b = ((u64)h[3] << 32) | h[2];
 }
 
 // record filter, bam_utils.py:264-270 (host bits 12/13 carry the two non-flag terms)
@@ -128,28 +142,37 @@ __device__ __forceinline__ u64 table_find_or_insert(Slot* table, u64 cap_mask, u
 
 // ---------------------------------------------------------------------------------------------
 // k_stream -- wave-autonomous: every wave owns a contiguous slice of the record stream and walks it in
-// tiles of WT records with wave-private LDS and no workgroup barriers, so the 16-20 waves of a CU
-// overlap each other's HBM and EC-table latency.  The workgroup only shares the hot-EC cache.
+// tiles of WT records with wave-private LDS and no workgroup barriers, so the 16 waves of a CU overlap
+// each other's HBM and EC-table latency.  Per tile and lane: 8 records (2 x 16-byte loads per stream).
 // ---------------------------------------------------------------------------------------------
-constexpr int WT = 512;              // records per wave tile (8 per lane: 2 x 16-byte loads per stream)
+// tuning switches (A/B-tested on MI355X)
+#ifndef V_BALLOT_SUMS
+#define V_BALLOT_SUMS 1
+#endif
+#ifndef V_MERGE
+#define V_MERGE 0
+#endif
+constexpr int WT = 512;              // records per wave tile
 constexpr int WMAXR = 64;            // reads finished per wave tile (one lane each in phase (c))
 constexpr int NWAVE = TPB / 64;
 
 struct WaveLds {
-    unsigned short seg[WT + 4];      // tile-relative start of every read in the tile (+ end sentinel)
-    u32 tkey[2 * WT];                // per-read sets of targets: 2 slots per record of the read, 0 = empty
-    u64 acc_a[WMAXR], acc_b[WMAXR];  // per-read set-hash accumulators
+    u32 seg[WT + 4];                 // per read of the tile: tile-relative start | end << 16
+    u32 tkey[2 * WT];                // per-read {locus -> mask} tables: 2 slots per record of the read; key = locus + 1
+    u32 tmask[2 * WT];
+    u64 acc[WMAXR][2];               // per read: set-hash sums (2 x 64 bits)
+    u32 npair[WMAXR];                // per read: number of (locus, mask) pairs
 };
 
 struct StreamArgs {
-    const u32* rid; const u32* loc; const u32* hf; const int* pos;
+    const u32* rid; const u32* loc; const u32* hf;
     u64 n, chunk;
     u32 prev_rid;                    // read_id of the record before this batch (0xFFFFFFFF at stream start)
     u32 n_loci, n_haps;
     Slot* table; u64 cap_mask;
+    uint2* arena; u64 arena_cap;
     Counters* ctr;
     u32* read_slot;                  // slot of every read (indexed by read_id)
-    int* rng_min; int* rng_max;      // per (locus*H + hap), or null
     u64* queue; u64 queue_cap;       // head record index of deferred reads
     u64* resume;                     // per wave {next record to process, records counted up to}
     u32 ablate;                      // profiling only (env ECB_ABLATE): 1 = stop after (a), 2 = after (b), 4 = no EC table
@@ -163,6 +186,11 @@ __device__ __forceinline__ u32 wave_sum(u32 v) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
     return v;
+}
+// bits [lo, hi) of a 4-record group, lo/hi given relative to the group's first record
+__device__ __forceinline__ u32 group_mask(int lo, int hi) {
+    lo = max(lo, 0); hi = min(hi, 4);
+    return hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
 }
 
 struct TileRegs { u32 rr[8], ll[8], hh[8]; };
@@ -192,277 +220,260 @@ __device__ __forceinline__ void load_tile(const StreamArgs& A, u64 tb, u64 te, u
 
 __global__ __launch_bounds__(TPB) void k_stream(StreamArgs A) {
     __shared__ WaveLds wl[NWAVE];
-
-    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     WaveLds& L = wl[w];
     const u64 wid = (u64)blockIdx.x * NWAVE + w;
     const u64 c0 = wid * A.chunk;
+    if (c0 >= A.n) return;
     const u64 c1 = min(c0 + A.chunk, A.n);
-    const bool have = c0 < A.n;
+    u64 p = A.resume[2 * wid], counted = A.resume[2 * wid + 1];
+    if (p >= c1) return;
 
+    u32 my_all = 0, my_valid = 0;                 // per lane; a slice is far below 2^32 records
+    u32 base = (p == 0 ? A.prev_rid : A.rid[p - 1]) + 1u;     // read index of the first head >= p
+    TileRegs R;
+    load_tile(A, p & ~(u64)3, min((p & ~(u64)3) + (u64)WT, A.n), lane, R);
+    u32 parked = __hip_atomic_load(&A.ctr->full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u32 bad = 0;
+    u64 chunk_at = 0;                 // this wave's reservation in the key arena
+    u32 chunk_left = 0, my_new = 0;
 
-    u64 my_all = 0, my_valid = 0;
-    u64 p = 0, counted = 0;
-    if (have) {
-        p = A.resume[2 * wid]; counted = A.resume[2 * wid + 1];
-    }
-    if (have && p < c1) {
-        u32 base = (p == 0 ? A.prev_rid : A.rid[p - 1]) + 1u;     // read index of the first head >= p
-        TileRegs R;
-        load_tile(A, p & ~(u64)3, min((p & ~(u64)3) + (u64)WT, A.n), lane, R);
-        u32 parked = __hip_atomic_load(&A.ctr->full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
-        while (p < c1) {
-            if (parked) break;            // the EC table filled up somewhere: the host grows it and relaunches
-            const u64 tb = p & ~(u64)3;
-            const u64 te = min(tb + (u64)WT, A.n);
-            const u64 cnt_hi = min(te, c1);
-            // clear this wave's per-tile LDS state
-            {
-                uint4* z = reinterpret_cast<uint4*>(L.tkey);
+    while (p < c1) {
+        if (parked) break;            // the EC table filled up somewhere: the host grows it and relaunches
+        const u64 tb = p & ~(u64)3;
+        const u64 te = min(tb + (u64)WT, A.n);
+        // tile-relative bounds (all below 2^31)
+        const int p_rel = (int)(p - tb), te_rel = (int)(te - tb);
+        const int c1_rel = (int)min(c1 - tb, (u64)WT), cnt_lo = (int)(max(counted, tb) - tb), cnt_hi = min(te_rel, c1_rel);
+        // clear this wave's per-tile LDS state
+        {
+            uint4* z = reinterpret_cast<uint4*>(L.tkey);      // tkey and tmask are contiguous
 #pragma unroll
-                for (int t = 0; t < (2 * WT) / (4 * 64); ++t) z[t * 64 + lane] = make_uint4(0, 0, 0, 0);
-                L.acc_a[lane] = 0; L.acc_b[lane] = 0;
-            }
-            // ---- (a) filter, heads ---------------------------------------------------------------
-            u32 r_key[8], r_rl[8];
-            u32 m_ok = 0, m_head = 0, m_own = 0;   // bit k: valid & in range / head / head of a read we own
-            u32 bad = 0;
-            {
-                const u32 up0 = __shfl_up(R.rr[3], 1), up1 = __shfl_up(R.rr[7], 1), last0 = __shfl(R.rr[3], 63);
+            for (int t = 0; t < (4 * WT) / (4 * 64); ++t) z[t * 64 + lane] = make_uint4(0, 0, 0, 0);
+            L.acc[lane][0] = 0; L.acc[lane][1] = 0; L.npair[lane] = 0;
+        }
+        // ---- (a) filter, heads -------------------------------------------------------------------
+        u32 r_key[8], r_bit[8], r_rl[8];          // locus, haplotype bit, read index within the tile
+        u32 m_ok = 0, m_head = 0, m_own = 0;       // bit k: valid & in range / head / head of a read we own
+        {
+            const u32 up0 = __shfl_up(R.rr[3], 1), up1 = __shfl_up(R.rr[7], 1), last0 = __shfl(R.rr[3], 63);
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    const u64 i0 = tb + (u64)g * (WT / 2) + 4u * lane;
-                    u32 prev = g == 0 ? (lane == 0 ? base - 1u : up0) : (lane == 0 ? last0 : up1);
+            for (int g = 0; g < 2; ++g) {
+                const int i0 = g * (WT / 2) + 4 * (int)lane;
+                const u32 in4 = group_mask(p_rel - i0, te_rel - i0);
+                const u32 own4 = group_mask(p_rel - i0, c1_rel - i0);
+                const u32 cnt4 = group_mask(cnt_lo - i0, cnt_hi - i0);
+                u32 prev = g == 0 ? (lane == 0 ? base - 1u : up0) : (lane == 0 ? last0 : up1);
+                u32 ok4 = 0, head4 = 0;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int k = 4 * g + j;
-                        const u64 i = i0 + j;
-                        const bool in = (i >= p) && (i < te);
-                        const u32 f = R.hh[k];
-                        const bool ok = rec_valid(f);
-                        const u32 hap = (f >> ECB_HAP_SHIFT) & 0xFFu;
-                        const u32 step = R.rr[k] - prev;
-                        r_rl[k] = R.rr[k] - base;
-                        r_key[k] = target_key(R.ll[k], hap);
-                        if (in) {
-                            if (step > 1u || (step == 1u && !ok)) bad |= ERR_CONTRACT;
-                            if (step == 1u) { m_head |= 1u << k; if (i < c1) m_own |= 1u << k; }
-                            if (ok) {
-                                if (R.ll[k] >= A.n_loci || hap >= A.n_haps) bad |= ERR_RANGE;
-                                else m_ok |= 1u << k;
-                            }
-                            if (i >= counted && i < cnt_hi) {
-                                my_all += 1;
-                                if (ok) {
-                                    my_valid += 1;
-                                    if (A.rng_min && R.ll[k] < A.n_loci && hap < A.n_haps) {
-                                        const u64 sl = (u64)R.ll[k] * A.n_haps + hap;
-                                        const int ps = A.pos[i];
-                                        atomicMin(A.rng_min + sl, ps);
-                                        atomicMax(A.rng_max + sl, ps);
-                                    }
-                                }
-                            }
-                        }
-                        prev = R.rr[k];
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 4 * g + j;
+                    const u32 f = R.hh[k];
+                    const bool ok = ((f & 0x4u) == 0u) & (((f & 0x1u) == 0u) | ((f & 0x3082u) == 0x2u));
+                    const u32 hap = (f >> ECB_HAP_SHIFT) & 0xFFu;
+                    const u32 step = R.rr[k] - prev;
+                    prev = R.rr[k];
+                    r_rl[k] = R.rr[k] - base;
+                    r_key[k] = R.ll[k]; r_bit[k] = 1u << (hap & 31u);
+                    const bool inr = (in4 >> j) & 1u;
+                    if (inr & ((step > 1u) | ((step == 1u) & !ok))) bad |= ERR_CONTRACT;
+                    if (inr & ok & ((R.ll[k] >= A.n_loci) | (hap >= A.n_haps))) bad |= ERR_RANGE;
+                    ok4 |= (u32)ok << j;
+                    head4 |= (u32)(step == 1u) << j;
                 }
+                ok4 &= in4; head4 &= in4;
+                my_all += __popc(cnt4); my_valid += __popc(cnt4 & ok4);
+                m_ok |= ok4 << (4 * g); m_head |= head4 << (4 * g); m_own |= (head4 & own4) << (4 * g);
             }
-            if (__ballot(bad != 0u)) {               // never index LDS with a broken run counter
-                if (bad) atomicOr(&A.ctr->err, bad);
-                p = c1;
-                break;
-            }
-            const u32 nr = wave_sum(__popc(m_head));                 // heads in [p, te)
-            const u32 nown = wave_sum(__popc(m_own));                // heads in [p, c1): ours
+        }
+        if (__ballot(bad != 0u)) break;            // never index LDS with a broken run counter
+#if V_BALLOT_SUMS
+        u32 nr = 0, nown = 0;                                    // heads in [p, te) / in [p, c1): ours
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            nr += (u32)__popcll(__ballot(m_head >> k & 1u));
+            nown += (u32)__popcll(__ballot(m_own >> k & 1u));
+        }
+#else
+        const u32 nr = wave_sum(__popc(m_head)), nown = wave_sum(__popc(m_own));
+#endif
+        {   // a head at position x starts its read and ends the one before it
+            unsigned short* sh = reinterpret_cast<unsigned short*>(L.seg);
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-                if (m_head >> k & 1u) L.seg[r_rl[k]] = (unsigned short)(4u * lane + (k & 3) + (k >> 2) * (WT / 2));
-            if (lane == 0) L.seg[nr] = (unsigned short)(te - tb);    // end sentinel
-            wave_sync();
-            const bool last_complete = (te == A.n);                  // batches end on a read boundary
-            const u32 nrc = last_complete ? nr : (nr ? nr - 1u : 0u);
-            const u32 nproc = min(min(nrc, nown), (u32)WMAXR);
-            const bool done = (te >= c1 && nown <= nproc);           // every read that starts in our slice
-            u64 p_next = te;
-            u32 base_next = base + nr;
-            bool giant = false;
-            if (!done && nproc < nr) {
-                const u64 h = tb + L.seg[nproc];                     // first read not finished here
-                if (h == p) giant = true;                            // one read fills the whole tile: k_slow
-                else { p_next = h; base_next = base + nproc; }
-            }
-            if (done) p_next = c1;
-            // ---- prefetch the next tile while this one is hashed and looked up ----------------------
-            TileRegs N;
-            u32 parked_next = 0;
-            if (p_next < c1) {
-                load_tile(A, p_next & ~(u64)3, min((p_next & ~(u64)3) + (u64)WT, A.n), lane, N);
-                parked_next = __hip_atomic_load(&A.ctr->full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (giant && lane == 0) {
-                const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
-                if (qi < A.queue_cap) A.queue[qi] = p; else atomicOr(&A.ctr->err, ERR_QUEUE);
-            }
-
-            // ---- (b) per-read target sets in LDS; first occurrences feed the read's set hash ------
-            if (!(A.ablate & 1u)) {
-                u64 ca = 0, cb = 0;
-                u32 crl = PENDING;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if ((m_ok >> k & 1u) && r_rl[k] < nproc) {
-                        const u32 rl = r_rl[k];
-                        const u32 s2 = 2u * L.seg[rl], len2 = 2u * L.seg[rl + 1] - s2;
-                        const u32 key = r_key[k] + 1u;
-                        u32 q = s2 + __umulhi(r_key[k] * 0x9E3779B1u, len2);
-                        bool fresh;
-                        for (;;) {
-                            const u32 old = atomicCAS(&L.tkey[q], 0u, key);
-                            if (old == 0u) { fresh = true; break; }
-                            if (old == key) { fresh = false; break; }   // duplicate (read, target): bam_utils.py:322-325
-                            if (++q == s2 + len2) q = s2;
-                        }
-                        if (fresh) {
-                            if (rl != crl) {
-                                if (crl != PENDING) { atomicAdd(&L.acc_a[crl], ca); atomicAdd(&L.acc_b[crl], cb); }
-                                crl = rl; ca = 0; cb = 0;
-                            }
-                            u64 a, b; target_hash(r_key[k], a, b); ca += a; cb += b;
-                        }
-                    }
+                if (m_head >> k & 1u) {
+                    const unsigned short x = (unsigned short)(4u * lane + (k & 3) + (k >> 2) * (WT / 2));
+                    sh[2 * r_rl[k]] = x;
+                    if (r_rl[k]) sh[2 * r_rl[k] - 1] = x;
                 }
-                if (crl != PENDING) { atomicAdd(&L.acc_a[crl], ca); atomicAdd(&L.acc_b[crl], cb); }
-            }
-            wave_sync();
+            if (lane == 0) { if (nr) sh[2 * nr - 1] = (unsigned short)te_rel; sh[2 * nr] = (unsigned short)te_rel; }
+        }
+        wave_sync();
+        const bool last_complete = (te == A.n);                  // batches end on a read boundary
+        const u32 nrc = last_complete ? nr : (nr ? nr - 1u : 0u);
+        const u32 nproc = min(min(nrc, nown), (u32)WMAXR);
+        const bool done = (te >= c1 && nown <= nproc);           // every read that starts in our slice
+        u64 p_next = te;
+        u32 base_next = base + nr;
+        bool giant = false;
+        if (!done && nproc < nr) {
+            const u64 h = tb + (L.seg[nproc] & 0xFFFFu);         // first read not finished here
+            if (h == p) giant = true;                            // one read fills the whole tile: k_slow
+            else { p_next = h; base_next = base + nproc; }
+        }
+        if (done) p_next = c1;
+        // ---- prefetch the next tile while this one is hashed and looked up --------------------------
+        TileRegs N;
+        u32 parked_next = 0;
+        if (p_next < c1) {
+            load_tile(A, p_next & ~(u64)3, min((p_next & ~(u64)3) + (u64)WT, A.n), lane, N);
+            parked_next = __hip_atomic_load(&A.ctr->full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (giant && lane == 0) {
+            const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
+            if (qi < A.queue_cap) A.queue[qi] = p; else atomicOr(&A.ctr->err, ERR_QUEUE);
+        }
 
-            // ---- (c) one lane per read: EC lookup; the read's slot is all that is recorded ----------
-            if (lane < nproc && !(A.ablate & 3u)) {
+        // ---- (b) per-read {locus -> haplotype mask} tables in LDS ------------------------------------
+        // Runs of records with the same (read, locus) inside a lane are merged in registers first (the
+        // haplotypes of a locus usually arrive together); what remains is staged so that the LDS round
+        // trips overlap: segment reads, CAS on the locus, OR of the bits.  The lane whose CAS created an
+        // entry hashes it once all masks are final.
+        u32 act = 0, mine = 0, q[8];
+        if (!(A.ablate & 1u)) {
+            u32 s2[8], e2[8], old[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) act |= (u32)((m_ok >> k & 1u) && r_rl[k] < nproc) << k;
+#if V_MERGE
+#pragma unroll
+            for (int k = 1; k < 8; ++k) {
+                if ((k & 3) == 0) continue;                          // the two groups of a lane are 256 records apart
+                const bool join = (act >> k & 1u) && (act >> (k - 1) & 1u) && r_key[k] == r_key[k - 1] && r_rl[k] == r_rl[k - 1];
+                if (join) { r_bit[k] |= r_bit[k - 1]; act &= ~(1u << (k - 1)); }
+            }
+#endif
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const u32 sg = L.seg[(act >> k & 1u) ? r_rl[k] : 0u];
+                s2[k] = 2u * (sg & 0xFFFFu); e2[k] = 2u * (sg >> 16);
+                q[k] = s2[k] + (__umul24(__umul24(r_key[k] & 0xFFFFFFu, 0x9E3779u) >> 8 & 0xFFFFu, e2[k] - s2[k]) >> 16);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                old[k] = 0xFFFFFFFFu;
+                if (act >> k & 1u) old[k] = atomicCAS(&L.tkey[q[k]], 0u, r_key[k] + 1u);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (act >> k & 1u) {
+                    const u32 key = r_key[k] + 1u;
+                    u32 o = old[k];
+                    while (o != 0u && o != key) {                    // slot taken by another locus: probe on
+                        if (++q[k] == e2[k]) q[k] = s2[k];
+                        o = atomicCAS(&L.tkey[q[k]], 0u, key);
+                    }
+                    if (o == 0u) { mine |= 1u << k; atomicAdd(&L.npair[r_rl[k]], 1u); }   // this lane created the entry
+                    atomicOr(&L.tmask[q[k]], r_bit[k]);              // duplicate (read, target) records vanish here: bam_utils.py:322-325
+                }
+            }
+        }
+        wave_sync();
+        if (mine) {
+            u64 ca = 0, cb = 0;
+            u32 crl = PENDING;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (mine >> k & 1u) {
+                    const u32 rl = r_rl[k];
+                    if (rl != crl) {
+                        if (crl != PENDING) { atomicAdd(&L.acc[crl][0], ca); atomicAdd(&L.acc[crl][1], cb); }
+                        crl = rl; ca = 0; cb = 0;
+                    }
+                    u64 a, b;
+                    pair_hash64(r_key[k], L.tmask[q[k]], a, b);
+                    ca += a; cb += b;
+                }
+            }
+            if (crl != PENDING) { atomicAdd(&L.acc[crl][0], ca); atomicAdd(&L.acc[crl][1], cb); }
+        }
+        wave_sync();
+
+        // ---- (c) one lane per read: EC lookup; a new EC gets its key from the read's LDS table ---------
+        if (!(A.ablate & 3u)) {
+            const bool on = lane < nproc;
+            u64 slot = ~0ull;
+            bool created = false;
+            u32 np = 0;
+            const u32 rd = base + lane;
+            if (on) {
                 u64 lo, hi;
-                finish_hash(L.acc_a[lane], L.acc_b[lane], lo, hi);
-                const u32 rd = base + lane;
-                if (A.ablate & 4u) {
-                    A.read_slot[rd] = (u32)(lo & A.cap_mask);
-                } else {
-                    bool created = false;
-                    const u64 j = table_find_or_insert(A.table, A.cap_mask, lo, hi, &created);
-                    const u64 h = tb + L.seg[lane];
-                    if (j == ~0ull) {                               // table too full here: defer the read, park
+                np = L.npair[lane];
+                finish_hash(L.acc[lane][0], L.acc[lane][1], np, lo, hi);
+                if (A.ablate & 4u) { slot = lo & A.cap_mask; A.read_slot[rd] = (u32)slot; }
+                else {
+                    slot = table_find_or_insert(A.table, A.cap_mask, lo, hi, &created);
+                    if (slot == ~0ull) {                            // table too full here: defer the read, park
                         atomicExch(&A.ctr->full, 1u);
                         const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
-                        if (qi < A.queue_cap) A.queue[qi] = h; else atomicOr(&A.ctr->err, ERR_QUEUE);
+                        if (qi < A.queue_cap) A.queue[qi] = tb + (L.seg[lane] & 0xFFFFu); else atomicOr(&A.ctr->err, ERR_QUEUE);
                     } else {
-                        if (created) {                              // key extraction is deferred to k_keys
-                            A.table[j].off = (u32)h;
-                            A.table[j].n = KEY_PENDING | (u32)(h >> 32);
-                        }
-                        A.read_slot[rd] = (u32)j;
+                        A.read_slot[rd] = (u32)slot;
                     }
                 }
             }
-            wave_sync();
-
-            counted = max(counted, cnt_hi);
-            p = p_next; base = base_next; R = N; parked = parked_next;
-        }
-        if (lane == 0) { A.resume[2 * wid] = p; A.resume[2 * wid + 1] = counted; }
-        // records offered / valid: one atomic pair per wave
+            if (__ballot(created)) {                                // rare after the first tiles of a slice
+                const u32 want = created ? np : 0u;
+                u32 incl = want;
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) { my_all += __shfl_xor(my_all, d); my_valid += __shfl_xor(my_valid, d); }
-        if (lane == 0) { atomicAdd(&A.ctr->all, my_all); atomicAdd(&A.ctr->valid, my_valid); }
-    }
-
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_keys: extract the (locus, mask) key of every EC that k_stream created, from the records of the
-// read that created it.  Pass 1 counts pairs per EC, an exclusive scan places them, pass 2 writes.
-// One wave per EC; reads longer than KEYS_SMALL records go to the workgroup-wide variant.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_collect_new(const Slot* table, u64 cap, u32* list, u64 max_list, u64* n_list) {
-    __shared__ u32 s_cnt;
-    __shared__ u64 s_base;
-    for (u64 b = (u64)blockIdx.x * TPB; b < cap; b += (u64)gridDim.x * TPB) {
-        if (threadIdx.x == 0) s_cnt = 0;
-        __syncthreads();
-        const u64 i = b + threadIdx.x;
-        const bool pend = i < cap && table[i].hi != 0ull && (table[i].n & KEY_PENDING);
-        u32 my = 0;
-        if (pend) my = atomicAdd(&s_cnt, 1u);
-        __syncthreads();
-        if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(n_list, (u64)s_cnt);
-        __syncthreads();
-        if (pend && s_base + my < max_list) list[s_base + my] = (u32)i;
-        __syncthreads();
-    }
-}
-
-constexpr int KEYS_WT = 1024;        // entries of one wave's LDS table in k_keys
-constexpr u32 KEYS_MAXL = KEYS_WT / 2;   // longer reads take the k_slow route (key-only mode)
-
-template <bool WRITE>
-__global__ __launch_bounds__(TPB) void k_keys(const u32* rid, const u32* loc, const u32* hf, u64 n,
-                                              Slot* table, const u32* list, u64 n_list,
-                                              u32* nlen, const u32* noff, u64 arena_base, uint2* arena,
-                                              u64* slowq, u32* slowslot, u64* n_slow) {
-    __shared__ u32 wk[TPB / 64][KEYS_WT], wm[TPB / 64][KEYS_WT];
-    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    const u64 e = (u64)blockIdx.x * (TPB / 64) + w;
-    const bool act = e < n_list;
-    u32* K = wk[w];
-    u32* M = wm[w];
-    for (u32 q = lane; q < KEYS_WT; q += 64) { K[q] = 0; M[q] = 0; }
-    Slot* s = act ? table + list[e] : table;
-    u64 head = 0;
-    u32 L = 0;
-    if (act) {
-        head = (u64)s->off | ((u64)(s->n & ~KEY_PENDING) << 32);
-        const u32 r0 = rid[head];
-        for (u64 i0 = head;; i0 += 64) {                 // length of the creating read, in records
-            const u64 i = i0 + lane;
-            const u64 m = __ballot(i < n && rid[i] == r0);
-            L += __popcll(m);
-            if (m != ~0ull) break;
-        }
-    }
-    const bool small = act && L <= KEYS_MAXL;
-    __syncthreads();
-    if (small) {
-        for (u32 t = lane; t < L; t += 64) {
-            const u32 f = hf[head + t];
-            if (!rec_valid(f)) continue;
-            const u32 lc = loc[head + t], key = lc + 1u, bit = 1u << ((f >> ECB_HAP_SHIFT) & 0xFFu);
-            u32 q = __umulhi(lc * 0x9E3779B1u, (u32)KEYS_WT);
-            for (;;) {
-                const u32 old = atomicCAS(&K[q], 0u, key);
-                if (old == 0u || old == key) { atomicOr(&M[q], bit); break; }
-                if (++q == KEYS_WT) q = 0;
+                for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(incl, d); if (lane >= (u32)d) incl += t; }
+                const u32 total = __shfl(incl, 63);
+                if (total > chunk_left) {                           // reserve another stretch of the key arena
+                    const u32 take = max(total, ARENA_CHUNK);
+                    u64 at = 0;
+                    if (lane == 0) at = atomicAdd(&A.ctr->arena_top, (u64)take);
+                    chunk_at = __shfl(at, 0); chunk_left = take;
+                    if (chunk_at + take > A.arena_cap) { bad |= ERR_ARENA; chunk_left = 0; }
+                }
+                if (created && !(bad & ERR_ARENA)) {
+                    u64 off = chunk_at + (incl - want);
+                    A.table[slot].off = (u32)off; A.table[slot].n = np;
+                    const u32 b2 = 2u * (L.seg[lane] & 0xFFFFu), f2 = 2u * (L.seg[lane] >> 16);
+                    for (u32 t = b2; t < f2; ++t) {
+                        const u32 kk = L.tkey[t];
+                        if (kk) A.arena[off++] = make_uint2(kk - 1u, L.tmask[t]);
+                    }
+                }
+                if (!(bad & ERR_ARENA)) { chunk_at += total; chunk_left -= total; }
             }
+            my_new += (u32)__popcll(__ballot(created));
         }
+        wave_sync();
+
+        counted = max(counted, tb + (u64)cnt_hi);
+        p = p_next; base = base_next; R = N; parked = parked_next;
     }
-    __syncthreads();
-    if (!act) return;
-    if (!small) {
-        if (!WRITE && lane == 0) {
-            const u64 qi = atomicAdd(n_slow, 1ull);
-            slowq[qi] = head; slowslot[qi] = list[e];
-            nlen[e] = 0;
-        }
-        return;
-    }
-    u32 cnt = 0;
-    const u64 dst = WRITE ? arena_base + noff[e] : 0;
-    for (u32 q0 = 0; q0 < KEYS_WT; q0 += 64) {
-        const u32 q = q0 + lane;
-        const bool occ = K[q] != 0u;
-        const u64 m = __ballot(occ);
-        if (WRITE && occ) arena[dst + cnt + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2(K[q] - 1u, M[q]);
-        cnt += __popcll(m);
-    }
+    if (__ballot(bad != 0u)) { if (bad) atomicOr(&A.ctr->err, bad); p = c1; }
+    if (lane == 0) { A.resume[2 * wid] = p; A.resume[2 * wid + 1] = counted; }
+    // records offered / valid: one atomic pair per wave
+    const u32 wa = wave_sum(my_all), wv = wave_sum(my_valid);
     if (lane == 0) {
-        if (WRITE) { s->off = (u32)dst; s->n = cnt; }
-        else nlen[e] = cnt;
+        atomicAdd(&A.ctr->all, (u64)wa); atomicAdd(&A.ctr->valid, (u64)wv);
+        if (my_new) atomicAdd(&A.ctr->n_ecs, (u64)my_new);
+    }
+}
+
+// reference_start ranges per target (bam_utils.py:282-286): a separate pass, only with ECB_F_RANGES
+__global__ __launch_bounds__(TPB) void k_ranges(const u32* loc, const u32* hf, const int* pos, u64 n, u32 n_loci, u32 n_haps,
+                                                int* rng_min, int* rng_max) {
+    for (u64 i = (u64)blockIdx.x * TPB + threadIdx.x; i < n; i += (u64)gridDim.x * TPB) {
+        const u32 f = hf[i];
+        if (!rec_valid(f)) continue;
+        const u32 lc = loc[i], hap = (f >> ECB_HAP_SHIFT) & 0xFFu;
+        if (lc >= n_loci || hap >= n_haps) continue;          // k_stream reports these
+        const u64 sl = (u64)lc * n_haps + hap;
+        const int ps = pos[i];
+        if (ps < rng_min[sl]) atomicMin(rng_min + sl, ps);
+        if (ps > rng_max[sl]) atomicMax(rng_max + sl, ps);
     }
 }
 
@@ -573,7 +584,6 @@ struct SlowArgs {
     Counters* ctr;
     u32* read_slot;
     u64* requeue; u64* n_requeue;                           // reads that still found no slot
-    const u32* key_slot;                                    // non-null: the EC exists (slot given); only extract its key
 };
 
 __global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
@@ -583,7 +593,7 @@ __global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
     const u64 cap2 = 2 * L;
     u32* key = A.scr_key + A.scr_off[q];
     u32* msk = A.scr_mask + A.scr_off[q];
-    __shared__ u64 s_a[TPB / 64], s_b[TPB / 64];
+    __shared__ u64 s_acc[TPB / 64][2];
     __shared__ u32 s_n[TPB / 64];
     __shared__ u64 s_off;
     __shared__ u32 s_created, s_cnt, s_fits;
@@ -602,39 +612,37 @@ __global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
     }
     __threadfence();
     __syncthreads();
-    u64 a = 0, b = 0; u32 np = 0;
+    u64 a0 = 0, a1 = 0;
+    u32 np = 0;
     for (u64 p = tid; p < cap2; p += TPB) {
         const u32 k = __hip_atomic_load(&key[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (k) {
-            u32 m = __hip_atomic_load(&msk[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u32 m = __hip_atomic_load(&msk[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ++np;
-            while (m) {                                     // same set hash as k_stream: sum over distinct targets
-                const u32 hp = __ffs(m) - 1; m &= m - 1;
-                u64 x, y; target_hash(target_key(k - 1u, hp), x, y); a += x; b += y;
-            }
+            u64 x, y; pair_hash64(k - 1u, m, x, y);         // same set hash as k_stream
+            a0 += x; a1 += y;
         }
     }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { a += __shfl_down(a, d); b += __shfl_down(b, d); np += __shfl_down(np, d); }
-    if (lane == 0) { s_a[tid >> 6] = a; s_b[tid >> 6] = b; s_n[tid >> 6] = np; }
+    for (int d = 32; d > 0; d >>= 1) { a0 += __shfl_xor(a0, d); a1 += __shfl_xor(a1, d); }
+    np = wave_sum(np);
+    if (lane == 0) { s_acc[tid >> 6][0] = a0; s_acc[tid >> 6][1] = a1; s_n[tid >> 6] = np; }
     __syncthreads();
     if (tid == 0) {
-        a = b = 0; np = 0;
-        for (int w = 0; w < TPB / 64; ++w) { a += s_a[w]; b += s_b[w]; np += s_n[w]; }
-        u64 lo, hi; finish_hash(a, b, lo, hi);
+        a0 = a1 = 0; np = 0;
+        for (int w = 0; w < TPB / 64; ++w) { a0 += s_acc[w][0]; a1 += s_acc[w][1]; np += s_n[w]; }
+        u64 lo, hi; finish_hash(a0, a1, np, lo, hi);
         bool created = false;
         const u32 r0 = A.rid[h];
-        u64 slot;
-        if (A.key_slot) { slot = A.key_slot[q]; created = true; }
-        else slot = table_find_or_insert(A.table, A.cap_mask, lo, hi, &created);
+        const u64 slot = table_find_or_insert(A.table, A.cap_mask, lo, hi, &created);
         s_created = 0; s_cnt = 0; s_fits = 0; s_off = 0;
         if (slot == ~0ull) {
             A.requeue[atomicAdd(A.n_requeue, 1ull)] = h;
         } else {
-            if (!A.key_slot) A.read_slot[r0] = (u32)slot;
+            A.read_slot[r0] = (u32)slot;
             if (created) {
                 const u64 off = atomicAdd(&A.ctr->arena_top, (u64)np);
-                if (!A.key_slot) atomicAdd(&A.ctr->n_ecs, 1ull);
+                atomicAdd(&A.ctr->n_ecs, 1ull);
                 s_created = 1; s_off = off; s_fits = (off + np <= A.arena_cap);
                 if (s_fits) { A.table[slot].off = (u32)off; A.table[slot].n = np; }
                 else atomicOr(&A.ctr->err, ERR_ARENA);
@@ -856,9 +864,7 @@ struct ecb_handle {
     u32* read_slot = nullptr; u64 read_slot_cap = 0;
     int *rng_min = nullptr, *rng_max = nullptr;
     u64* queue = nullptr; u64 queue_cap = 0;
-    u32* newlist = nullptr; u64 newlist_cap = 0;   // slots whose key is pending (k_collect_new)
-    u64 n_ecs_stream = 0;             // ECs created by k_stream launches (counted when their keys are extracted)
-    u64 n_ecs() const { return hctr.n_ecs + n_ecs_stream; }
+    u64 n_ecs() const { return hctr.n_ecs; }
     u32 prev_rid = 0xFFFFFFFFu;       // read_id of the last record pushed so far
     u64 n_reads = 0;
     u64 reads_hi = 0;                 // read_slot entries [0, reads_hi) may be set (n_reads, or more mid-batch)
@@ -935,8 +941,7 @@ int ensure_read_slot(ecb_handle* h, u64 need) {
 }
 
 // deferred reads: measure, scratch, k_slow; grow the table and repeat while reads bounce
-int run_slow(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf, u64 n,
-             u64* d_q, u64 nq, const u32* d_key_slot) {
+int run_slow(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf, u64 n, u64* d_q, u64 nq) {
     u64* d_requeue = nullptr;
     int rc = ECB_OK;
     while (nq) {
@@ -960,7 +965,7 @@ int run_slow(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf,
         HIPCHK(h, hipMemsetAsync(sm, 0, tot * sizeof(u32), h->stream));
         HIPCHK(h, hipMemcpyAsync(d_off, off.data(), nq * sizeof(u64), hipMemcpyHostToDevice, h->stream));
         SlowArgs a{d_rid, d_loc, d_hf, d_q, d_len, d_off, sk, sm, h->cfg.n_loci, h->cfg.n_haplotypes,
-                   h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr, h->read_slot, nre_buf, d_nre, d_key_slot};
+                   h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr, h->read_slot, nre_buf, d_nre};
         k_slow<<<(unsigned)nq, TPB, 0, h->stream>>>(a);
         u64 nre = 0;
         HIPCHK(h, hipMemcpyAsync(&nre, d_nre, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
@@ -976,56 +981,6 @@ int run_slow(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf,
 }
 
 int excl_scan(ecb_handle* h, const u32* in, u64 n, u32* out, u32* total);
-
-// keys of the ECs the last k_stream launch created: collect, count, scan, write (k_keys)
-int extract_keys(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf, u64 n) {
-    u64* d_cnt = nullptr;                       // [0] = new ECs, [1] = ECs routed to k_slow
-    HIPCHK(h, hipMalloc(&d_cnt, 2 * sizeof(u64)));
-    HIPCHK(h, hipMemsetAsync(d_cnt, 0, 2 * sizeof(u64), h->stream));
-    if (h->newlist_cap < h->cap) {
-        if (h->newlist) hipFree(h->newlist);
-        h->newlist_cap = h->cap;
-        HIPCHK(h, hipMalloc(&h->newlist, h->newlist_cap * sizeof(u32)));
-    }
-    k_collect_new<<<(unsigned)std::min<u64>(4096, (h->cap + TPB - 1) / TPB), TPB, 0, h->stream>>>(
-        h->table, h->cap, h->newlist, h->newlist_cap, d_cnt);
-    u64 n_new = 0;
-    HIPCHK(h, hipMemcpyAsync(&n_new, d_cnt, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    int rc = ECB_OK;
-    if (n_new) {
-        u32 *nlen = nullptr, *noff = nullptr, *slowslot = nullptr;
-        u64* slowq = nullptr;
-        HIPCHK(h, hipMalloc(&nlen, n_new * 4)); HIPCHK(h, hipMalloc(&noff, n_new * 4));
-        HIPCHK(h, hipMalloc(&slowslot, n_new * 4)); HIPCHK(h, hipMalloc(&slowq, n_new * 8));
-        const unsigned gb = nblk(n_new, TPB / 64);
-        k_keys<false><<<gb, TPB, 0, h->stream>>>(d_rid, d_loc, d_hf, n, h->table, h->newlist, n_new, nlen, noff, 0,
-                                                 h->arena, slowq, slowslot, d_cnt + 1);
-        u32 total = 0;
-        rc = excl_scan(h, nlen, n_new, noff, &total);
-        if (rc == ECB_OK) rc = sync_counters(h);
-        if (rc == ECB_OK) {
-            const u64 base = h->hctr.arena_top;
-            if (base + total > h->arena_cap)
-                rc = fail(h, ECB_ERR_TABLE_FULL, "EC key arena exhausted (%llu pairs): raise arena_capacity",
-                          (unsigned long long)h->arena_cap);
-            else {
-                const u64 top = base + total;
-                hipMemcpyAsync(&h->ctr->arena_top, &top, sizeof(u64), hipMemcpyHostToDevice, h->stream);
-                k_keys<true><<<gb, TPB, 0, h->stream>>>(d_rid, d_loc, d_hf, n, h->table, h->newlist, n_new, nlen, noff,
-                                                        base, h->arena, slowq, slowslot, d_cnt + 1);
-                u64 n_slowk = 0;
-                hipMemcpyAsync(&n_slowk, d_cnt + 1, sizeof(u64), hipMemcpyDeviceToHost, h->stream);
-                rc = sync_counters(h);
-                if (rc == ECB_OK && n_slowk) rc = run_slow(h, d_rid, d_loc, d_hf, n, slowq, n_slowk, slowslot);
-                if (rc == ECB_OK) h->n_ecs_stream += n_new;
-            }
-        }
-        hipFree(nlen); hipFree(noff); hipFree(slowslot); hipFree(slowq);
-    }
-    hipFree(d_cnt);
-    return rc;
-}
 
 // one batch of whole reads, device-resident
 int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf, const int* d_pos, u64 n) {
@@ -1064,9 +1019,11 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
         HIPCHK(h, hipMemcpyAsync(d_resume, r0.data(), 2 * waves * sizeof(u64), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
-    StreamArgs a{d_rid, d_loc, d_hf, d_pos, n, chunk, h->prev_rid, h->cfg.n_loci, h->cfg.n_haplotypes,
-                 h->table, h->cap - 1, h->ctr, h->read_slot,
-                 h->rng_min, h->rng_max, h->queue, h->queue_cap, d_resume,
+    if (h->rng_min)
+        k_ranges<<<(unsigned)std::min<u64>(4096, (n + TPB - 1) / TPB), TPB, 0, h->stream>>>(
+            d_loc, d_hf, d_pos, n, h->cfg.n_loci, h->cfg.n_haplotypes, h->rng_min, h->rng_max);
+    StreamArgs a{d_rid, d_loc, d_hf, n, chunk, h->prev_rid, h->cfg.n_loci, h->cfg.n_haplotypes,
+                 h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr, h->read_slot, h->queue, h->queue_cap, d_resume,
                  getenv("ECB_ABLATE") ? (u32)atoi(getenv("ECB_ABLATE")) : 0u};
     for (;;) {
         HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));   // per launch
@@ -1084,11 +1041,9 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
         if (rc != ECB_OK) break;
         const bool parked = h->hctr.full != 0;
         if (h->hctr.n_queue) {
-            rc = run_slow(h, d_rid, d_loc, d_hf, n, h->queue, std::min<u64>(h->hctr.n_queue, h->queue_cap), nullptr);
+            rc = run_slow(h, d_rid, d_loc, d_hf, n, h->queue, std::min<u64>(h->hctr.n_queue, h->queue_cap));
             if (rc != ECB_OK) break;
         }
-        rc = extract_keys(h, d_rid, d_loc, d_hf, n);
-        if (rc != ECB_OK) break;
         if (!parked) break;
         rc = grow_table(h, h->cap * 4);                 // some workgroups stopped early: more room, then resume
         if (rc != ECB_OK) break;
@@ -1261,7 +1216,7 @@ void ecb_destroy(ecb_handle* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     free_results(h);
     hipFree(h->table); hipFree(h->arena); hipFree(h->ctr); hipFree(h->read_slot);
-    hipFree(h->rng_min); hipFree(h->rng_max); hipFree(h->queue); hipFree(h->newlist);
+    hipFree(h->rng_min); hipFree(h->rng_max); hipFree(h->queue);
     hipFree(h->st_rid); hipFree(h->st_loc); hipFree(h->st_hf); hipFree(h->st_pos);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -1283,7 +1238,6 @@ int ecb_reset(ecb_handle* h) {
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->hctr = Counters{};
-    h->n_ecs_stream = 0;
     h->prev_rid = 0xFFFFFFFFu; h->n_reads = 0; h->reads_hi = 0;
     h->extra_all = h->extra_valid = h->extra_reads = 0;
     h->c_rid.clear(); h->c_loc.clear(); h->c_hf.clear(); h->c_pos.clear();
@@ -1384,7 +1338,6 @@ int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
         rc = excl_scan(h, rowlen, E, h->indptr, &nnz);
         if (rc != ECB_OK) return rc;
         if (h->hctr.arena_top >= (1ull << 31)) return fail(h, ECB_ERR_LIMIT, "A has more than 2^31-1 non-zeros");
-        if ((u64)nnz != h->hctr.arena_top) return fail(h, ECB_ERR_HIP, "internal: nnz %u != arena %llu", nnz, (unsigned long long)h->hctr.arena_top);
         HIPCHK(h, hipMemcpyAsync(h->indptr + E, &nnz, 4, hipMemcpyHostToDevice, h->stream));
     }
     HIPCHK(h, hipMalloc(&h->indices, std::max<u64>(nnz, 1) * 4)); HIPCHK(h, hipMalloc(&h->data, std::max<u64>(nnz, 1) * 4));

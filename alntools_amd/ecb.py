@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libecb.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("ECB_LIB", "libecb.so"))   # ECB_LIB: A/B builds of the kernel
 
 F_RANGES = 1
 F_MULTISAMPLE = 2
