@@ -156,13 +156,16 @@ constexpr int WT = 512;              // records per wave tile
 constexpr int WMAXR = 64;            // reads finished per wave tile (one lane each in phase (c))
 constexpr int NWAVE = TPB / 64;
 
-struct WaveLds {
-    u32 seg[WT + 4];                 // per read of the tile: tile-relative start | end << 16
-    u32 tkey[2 * WT];                // per-read {locus -> mask} tables: 2 slots per record of the read; key = locus + 1
-    u32 tmask[2 * WT];
+constexpr int TSLOTS = WT + WT / 2;  // LDS table slots per wave tile: 1.5 per record
+struct alignas(16) WaveLds {
+    u32 tkey[TSLOTS];                // per-read {locus -> mask} tables, 1.5 slots per record of the read; key = locus + 1
+    u32 tmask[TSLOTS];               // (contiguous with tkey: cleared together with 16-byte stores)
     u64 acc[WMAXR][2];               // per read: set-hash sums (2 x 64 bits)
-    u32 npair[WMAXR];                // per read: number of (locus, mask) pairs
+    unsigned short ent[WT];          // table entries created in this tile: slot | read << 10
+    unsigned short npair[WMAXR];     // per read: number of (locus, mask) pairs
+    u32 seg[WMAXR + 2];              // per read finished in this tile: tile-relative start | end << 16
 };
+__device__ __forceinline__ u32 tslot(u32 rec) { return rec + (rec >> 1); }   // first table slot of a read starting at `rec`
 
 struct StreamArgs {
     const u32* rid; const u32* loc; const u32* hf;
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(TPB) void k_stream(StreamArgs A) {
         {
             uint4* z = reinterpret_cast<uint4*>(L.tkey);      // tkey and tmask are contiguous
 #pragma unroll
-            for (int t = 0; t < (4 * WT) / (4 * 64); ++t) z[t * 64 + lane] = make_uint4(0, 0, 0, 0);
+            for (int t = 0; t < (2 * TSLOTS) / (4 * 64); ++t) z[t * 64 + lane] = make_uint4(0, 0, 0, 0);
             L.acc[lane][0] = 0; L.acc[lane][1] = 0; L.npair[lane] = 0;
         }
         // ---- (a) filter, heads -------------------------------------------------------------------
@@ -301,12 +304,12 @@ __global__ __launch_bounds__(TPB) void k_stream(StreamArgs A) {
             unsigned short* sh = reinterpret_cast<unsigned short*>(L.seg);
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-                if (m_head >> k & 1u) {
+                if ((m_head >> k & 1u) && r_rl[k] <= (u32)WMAXR) {
                     const unsigned short x = (unsigned short)(4u * lane + (k & 3) + (k >> 2) * (WT / 2));
                     sh[2 * r_rl[k]] = x;
                     if (r_rl[k]) sh[2 * r_rl[k] - 1] = x;
                 }
-            if (lane == 0) { if (nr) sh[2 * nr - 1] = (unsigned short)te_rel; sh[2 * nr] = (unsigned short)te_rel; }
+            if (lane == 0 && nr <= (u32)WMAXR) { if (nr) sh[2 * nr - 1] = (unsigned short)te_rel; sh[2 * nr] = (unsigned short)te_rel; }
         }
         wave_sync();
         const bool last_complete = (te == A.n);                  // batches end on a read boundary
@@ -339,24 +342,16 @@ __global__ __launch_bounds__(TPB) void k_stream(StreamArgs A) {
         // haplotypes of a locus usually arrive together); what remains is staged so that the LDS round
         // trips overlap: segment reads, CAS on the locus, OR of the bits.  The lane whose CAS created an
         // entry hashes it once all masks are final.
-        u32 act = 0, mine = 0, q[8];
+        u32 act = 0, n_ent = 0;
         if (!(A.ablate & 1u)) {
-            u32 s2[8], e2[8], old[8];
+            u32 q[8], old[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) act |= (u32)((m_ok >> k & 1u) && r_rl[k] < nproc) << k;
-#if V_MERGE
-#pragma unroll
-            for (int k = 1; k < 8; ++k) {
-                if ((k & 3) == 0) continue;                          // the two groups of a lane are 256 records apart
-                const bool join = (act >> k & 1u) && (act >> (k - 1) & 1u) && r_key[k] == r_key[k - 1] && r_rl[k] == r_rl[k - 1];
-                if (join) { r_bit[k] |= r_bit[k - 1]; act &= ~(1u << (k - 1)); }
-            }
-#endif
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const u32 sg = L.seg[(act >> k & 1u) ? r_rl[k] : 0u];
-                s2[k] = 2u * (sg & 0xFFFFu); e2[k] = 2u * (sg >> 16);
-                q[k] = s2[k] + (__umul24(__umul24(r_key[k] & 0xFFFFFFu, 0x9E3779u) >> 8 & 0xFFFFu, e2[k] - s2[k]) >> 16);
+                const u32 s2 = tslot(sg & 0xFFFFu), len = tslot(sg >> 16) - s2;
+                q[k] = s2 + (__umul24(__umul24(r_key[k] & 0xFFFFFFu, 0x9E3779u) >> 8 & 0xFFFFu, len) >> 16);
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -365,36 +360,35 @@ __global__ __launch_bounds__(TPB) void k_stream(StreamArgs A) {
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
+                bool made = false;
                 if (act >> k & 1u) {
                     const u32 key = r_key[k] + 1u;
                     u32 o = old[k];
-                    while (o != 0u && o != key) {                    // slot taken by another locus: probe on
-                        if (++q[k] == e2[k]) q[k] = s2[k];
-                        o = atomicCAS(&L.tkey[q[k]], 0u, key);
+                    if (o != 0u && o != key) {                       // slot taken by another locus: probe on
+                        const u32 sg = L.seg[r_rl[k]];
+                        const u32 s2 = tslot(sg & 0xFFFFu), e2 = tslot(sg >> 16);
+                        do {
+                            if (++q[k] == e2) q[k] = s2;
+                            o = atomicCAS(&L.tkey[q[k]], 0u, key);
+                        } while (o != 0u && o != key);
                     }
-                    if (o == 0u) { mine |= 1u << k; atomicAdd(&L.npair[r_rl[k]], 1u); }   // this lane created the entry
+                    made = (o == 0u);                                // this lane created the (read, locus) entry
                     atomicOr(&L.tmask[q[k]], r_bit[k]);              // duplicate (read, target) records vanish here: bam_utils.py:322-325
                 }
+                // entries are queued so that each is hashed once, by any lane, when its mask is final
+                const u64 mm = __ballot(made);
+                if (made) L.ent[n_ent + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u))] =
+                    (unsigned short)(q[k] | (r_rl[k] << 10));
+                n_ent += (u32)__popcll(mm);
             }
         }
         wave_sync();
-        if (mine) {
-            u64 ca = 0, cb = 0;
-            u32 crl = PENDING;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (mine >> k & 1u) {
-                    const u32 rl = r_rl[k];
-                    if (rl != crl) {
-                        if (crl != PENDING) { atomicAdd(&L.acc[crl][0], ca); atomicAdd(&L.acc[crl][1], cb); }
-                        crl = rl; ca = 0; cb = 0;
-                    }
-                    u64 a, b;
-                    pair_hash64(r_key[k], L.tmask[q[k]], a, b);
-                    ca += a; cb += b;
-                }
-            }
-            if (crl != PENDING) { atomicAdd(&L.acc[crl][0], ca); atomicAdd(&L.acc[crl][1], cb); }
+        for (u32 e = lane; e < n_ent; e += 64) {
+            const u32 en = L.ent[e], qq = en & 0x3FFu, rl = en >> 10;
+            u64 a, b;
+            pair_hash64(L.tkey[qq] - 1u, L.tmask[qq], a, b);
+            atomicAdd(&L.acc[rl][0], a); atomicAdd(&L.acc[rl][1], b);
+            atomicAdd(reinterpret_cast<u32*>(&L.npair[rl & ~1u]), (rl & 1u) ? 0x10000u : 1u);   // two 16-bit counters per word
         }
         wave_sync();
 
@@ -437,7 +431,7 @@ __global__ __launch_bounds__(TPB) void k_stream(StreamArgs A) {
                 if (created && !(bad & ERR_ARENA)) {
                     u64 off = chunk_at + (incl - want);
                     A.table[slot].off = (u32)off; A.table[slot].n = np;
-                    const u32 b2 = 2u * (L.seg[lane] & 0xFFFFu), f2 = 2u * (L.seg[lane] >> 16);
+                    const u32 b2 = tslot(L.seg[lane] & 0xFFFFu), f2 = tslot(L.seg[lane] >> 16);
                     for (u32 t = b2; t < f2; ++t) {
                         const u32 kk = L.tkey[t];
                         if (kk) A.arena[off++] = make_uint2(kk - 1u, L.tmask[t]);
@@ -513,14 +507,15 @@ __global__ __launch_bounds__(TPB) void k_part_scatter(const u32* read_slot, u64 
     }
 }
 
-__global__ __launch_bounds__(TPB) void k_count_bins(const uint2* pairs, const u32* offs, u32 G, u32 n_buckets, u32 total,
-                                                    Slot* table) {
+constexpr int TPB_COUNT = 1024;                // a hot EC makes its range's workgroup the tail: give it 16 waves
+__global__ __launch_bounds__(TPB_COUNT) void k_count_bins(const uint2* pairs, const u32* offs, u32 G, u32 n_buckets, u32 total,
+                                                          Slot* table) {
     __shared__ u32 cnt[N_BINS], fst[N_BINS];
     const u32 b = blockIdx.x, lane = threadIdx.x & 63u;
     const u32 start = offs[(u64)b * G], end = (b + 1 < n_buckets) ? offs[(u64)(b + 1) * G] : total;
-    for (u32 q = threadIdx.x; q < N_BINS; q += TPB) { cnt[q] = 0; fst[q] = 0xFFFFFFFFu; }
+    for (u32 q = threadIdx.x; q < N_BINS; q += TPB_COUNT) { cnt[q] = 0; fst[q] = 0xFFFFFFFFu; }
     __syncthreads();
-    for (u32 i0 = start; i0 < end; i0 += TPB) {
+    for (u32 i0 = start; i0 < end; i0 += TPB_COUNT) {
         const u32 i = i0 + threadIdx.x;
         const bool have = i < end;
         uint2 pr = have ? pairs[i] : make_uint2(0, 0xFFFFFFFFu);
@@ -540,7 +535,7 @@ __global__ __launch_bounds__(TPB) void k_count_bins(const uint2* pairs, const u3
         }
     }
     __syncthreads();
-    for (u32 q = threadIdx.x; q < N_BINS; q += TPB) {
+    for (u32 q = threadIdx.x; q < N_BINS; q += TPB_COUNT) {
         const u32 c = cnt[q];
         if (c) {                                           // this workgroup is the only writer of its slots
             Slot* s = table + (((u64)b << BIN_BITS) | q);
@@ -880,6 +875,11 @@ struct ecb_handle {
     int *indices = nullptr, *data = nullptr, *counts = nullptr;
     ecb_sizes sizes{};
 
+    // device scratch reused across calls (grown on demand, freed at destroy)
+    enum { P_RESUME, P_SUMS, P_HIST, P_OFFS, P_PAIRS, P_CNT, P_LIST, P_BITMAP, P_WPOP, P_WPREFIX, P_ROWLEN, P_ORDER,
+           P_RANK, P_INDPTR, P_COUNTS, P_INDICES, P_DATA, P_N };
+    void* pool[P_N] = {}; u64 pool_bytes[P_N] = {};
+
     // profiling
     bool prof = false; double prof_ms = 0; u64 prof_launches = 0, prof_records = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -900,6 +900,21 @@ int fail(ecb_handle* h, int code, const char* fmt, ...) {
 
 u64 next_pow2(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 inline unsigned nblk(u64 n, unsigned per) { return (unsigned)((n + per - 1) / per); }
+
+template <class T>
+int pool_get(ecb_handle* h, int id, u64 count, T** out) {
+    const u64 need = std::max<u64>(count, 1) * sizeof(T);
+    if (h->pool_bytes[id] < need) {
+        if (h->pool[id]) hipFree(h->pool[id]);
+        h->pool[id] = nullptr; h->pool_bytes[id] = 0;
+        const u64 take = need + need / 4;
+        HIPCHK(h, hipMalloc(&h->pool[id], take));
+        h->pool_bytes[id] = take;
+    }
+    *out = reinterpret_cast<T*>(h->pool[id]);
+    return ECB_OK;
+}
+#define POOL(h, id, ptr, count) do { int rc_ = pool_get(h, ecb_handle::id, count, &(ptr)); if (rc_ != ECB_OK) return rc_; } while (0)
 
 int sync_counters(ecb_handle* h) {
     HIPCHK(h, hipMemcpyAsync(&h->hctr, h->ctr, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
@@ -1012,7 +1027,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
         HIPCHK(h, hipMalloc(&h->queue, h->queue_cap * sizeof(u64)));
     }
     u64* d_resume = nullptr;
-    HIPCHK(h, hipMalloc(&d_resume, 2 * waves * sizeof(u64)));
+    POOL(h, P_RESUME, d_resume, 2 * waves);
     {
         std::vector<u64> r0(2 * waves);
         for (u64 b = 0; b < waves; ++b) r0[2 * b] = r0[2 * b + 1] = b * chunk;
@@ -1048,7 +1063,6 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
         rc = grow_table(h, h->cap * 4);                 // some workgroups stopped early: more room, then resume
         if (rc != ECB_OK) break;
     }
-    hipFree(d_resume);
     if (rc != ECB_OK) return rc;
     if (h->prof) h->prof_records += n;
     h->prev_rid = last_rid;
@@ -1092,9 +1106,7 @@ int stage_and_process(ecb_handle* h, const u32* rid, const u32* loc, const u32* 
     return process_batch(h, h->st_rid, h->st_loc, h->st_hf, rg ? h->st_pos : nullptr, n);
 }
 
-void free_results(ecb_handle* h) {
-    hipFree(h->list); hipFree(h->order); hipFree(h->rank_of_slot); hipFree(h->indptr);
-    hipFree(h->indices); hipFree(h->data); hipFree(h->counts);
+void free_results(ecb_handle* h) {   // result buffers live in the pool: nothing to free, just forget them
     h->list = h->order = h->rank_of_slot = h->indptr = nullptr;
     h->indices = h->data = h->counts = nullptr;
 }
@@ -1102,13 +1114,12 @@ void free_results(ecb_handle* h) {
 int excl_scan(ecb_handle* h, const u32* in, u64 n, u32* out, u32* total) {
     const u64 nb = std::max<u64>(1, (n + SCAN_BLOCK - 1) / SCAN_BLOCK);
     u32* sums = nullptr;
-    HIPCHK(h, hipMalloc(&sums, (nb + 1) * sizeof(u32)));
+    POOL(h, P_SUMS, sums, nb + 1);
     k_scan_sums<<<(unsigned)nb, TPB, 0, h->stream>>>(in, n, sums);
     k_scan_top<<<1, TPB, 0, h->stream>>>(sums, nb, sums + nb);
     k_scan_apply<<<(unsigned)nb, TPB, 0, h->stream>>>(in, n, sums, out);
     HIPCHK(h, hipMemcpyAsync(total, sums + nb, sizeof(u32), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipFree(sums));
     return ECB_OK;
 }
 
@@ -1122,18 +1133,17 @@ int ensure_counts(ecb_handle* h) {
         const u32 G = (u32)std::min<u64>(1024, (R + 4095) / 4096);
         u32 *hist = nullptr, *offs = nullptr;
         uint2* pairs = nullptr;
-        HIPCHK(h, hipMalloc(&hist, (u64)nb * G * 4)); HIPCHK(h, hipMalloc(&offs, (u64)nb * G * 4));
-        HIPCHK(h, hipMalloc(&pairs, R * sizeof(uint2)));
+        POOL(h, P_HIST, hist, (u64)nb * G); POOL(h, P_OFFS, offs, (u64)nb * G);
+        POOL(h, P_PAIRS, pairs, R);
         k_part_hist<<<G, TPB, nb * 4, h->stream>>>(h->read_slot, R, nb, hist);
         u32 total = 0;
         int rc = excl_scan(h, hist, (u64)nb * G, offs, &total);
         if (rc == ECB_OK) {
             k_part_scatter<<<G, TPB, nb * 4, h->stream>>>(h->read_slot, R, nb, offs, pairs);
-            k_count_bins<<<nb, TPB, 0, h->stream>>>(pairs, offs, G, nb, total, h->table);
+            k_count_bins<<<nb, TPB_COUNT, 0, h->stream>>>(pairs, offs, G, nb, total, h->table);
             hipError_t e = hipStreamSynchronize(h->stream);
             if (e != hipSuccess) rc = fail(h, ECB_ERR_HIP, "k_count: %s", hipGetErrorString(e));
         }
-        hipFree(hist); hipFree(offs); hipFree(pairs);
         if (rc != ECB_OK) return rc;
     }
     h->counted = true;
@@ -1141,15 +1151,13 @@ int ensure_counts(ecb_handle* h) {
 }
 
 int compact_table(ecb_handle* h) {
-    if (h->list) { hipFree(h->list); h->list = nullptr; }
     u64* d_n = nullptr;
-    HIPCHK(h, hipMalloc(&d_n, sizeof(u64)));
+    POOL(h, P_CNT, d_n, 1);
     HIPCHK(h, hipMemsetAsync(d_n, 0, sizeof(u64), h->stream));
-    HIPCHK(h, hipMalloc(&h->list, std::max<u64>(h->n_ecs(), 1) * sizeof(u32)));
+    POOL(h, P_LIST, h->list, h->n_ecs());
     k_compact<<<(unsigned)std::min<u64>(4096, (h->cap + TPB - 1) / TPB), TPB, 0, h->stream>>>(h->table, h->cap, h->list, std::max<u64>(h->n_ecs(), 1), d_n);
     HIPCHK(h, hipMemcpyAsync(&h->n_list, d_n, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipFree(d_n));
     if (h->n_list != h->n_ecs()) return fail(h, ECB_ERR_HIP, "internal: %llu occupied slots but %llu ECs created",
                                              (unsigned long long)h->n_list, (unsigned long long)h->n_ecs());
     return ECB_OK;
@@ -1217,6 +1225,7 @@ void ecb_destroy(ecb_handle* h) {
     free_results(h);
     hipFree(h->table); hipFree(h->arena); hipFree(h->ctr); hipFree(h->read_slot);
     hipFree(h->rng_min); hipFree(h->rng_max); hipFree(h->queue);
+    for (int i = 0; i < ecb_handle::P_N; ++i) hipFree(h->pool[i]);
     hipFree(h->st_rid); hipFree(h->st_loc); hipFree(h->st_hf); hipFree(h->st_pos);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -1321,10 +1330,10 @@ int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
     const u64 total_reads = h->n_reads + h->extra_reads;
     const u64 words = (total_reads + 31) / 32 + 1;
     u32 *bitmap = nullptr, *wpop = nullptr, *wprefix = nullptr, *rowlen = nullptr;
-    HIPCHK(h, hipMalloc(&bitmap, words * 4)); HIPCHK(h, hipMalloc(&wpop, words * 4)); HIPCHK(h, hipMalloc(&wprefix, words * 4));
-    HIPCHK(h, hipMalloc(&rowlen, E * 4));
-    HIPCHK(h, hipMalloc(&h->order, E * 4)); HIPCHK(h, hipMalloc(&h->rank_of_slot, h->cap * 4));
-    HIPCHK(h, hipMalloc(&h->indptr, (E + 1) * 4)); HIPCHK(h, hipMalloc(&h->counts, E * 4));
+    POOL(h, P_BITMAP, bitmap, words); POOL(h, P_WPOP, wpop, words); POOL(h, P_WPREFIX, wprefix, words);
+    POOL(h, P_ROWLEN, rowlen, E);
+    POOL(h, P_ORDER, h->order, E); POOL(h, P_RANK, h->rank_of_slot, h->cap);
+    POOL(h, P_INDPTR, h->indptr, E + 1); POOL(h, P_COUNTS, h->counts, E);
     HIPCHK(h, hipMemsetAsync(bitmap, 0, words * 4, h->stream));
     k_mark_first<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->table, h->list, E, bitmap);
     k_popc<<<nblk(words, TPB), TPB, 0, h->stream>>>(bitmap, words, wpop);
@@ -1340,10 +1349,9 @@ int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
         if (h->hctr.arena_top >= (1ull << 31)) return fail(h, ECB_ERR_LIMIT, "A has more than 2^31-1 non-zeros");
         HIPCHK(h, hipMemcpyAsync(h->indptr + E, &nnz, 4, hipMemcpyHostToDevice, h->stream));
     }
-    HIPCHK(h, hipMalloc(&h->indices, std::max<u64>(nnz, 1) * 4)); HIPCHK(h, hipMalloc(&h->data, std::max<u64>(nnz, 1) * 4));
+    POOL(h, P_INDICES, h->indices, nnz); POOL(h, P_DATA, h->data, nnz);
     k_emit<<<nblk(E * 64, TPB), TPB, 0, h->stream>>>(h->table, h->order, E, h->arena, h->indptr, h->indices, h->data, h->counts);
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    hipFree(bitmap); hipFree(wpop); hipFree(wprefix); hipFree(rowlen);
     h->sizes.n_ecs = E; h->sizes.nnz_a = nnz; h->sizes.n_samples = 1; h->sizes.nnz_n = E;
     h->sizes.all_alignments = h->hctr.all + h->extra_all;
     h->sizes.valid_alignments = valid;
