@@ -1,0 +1,129 @@
+# -*- coding: utf-8 -*-
+"""EMASE ``.h5`` container (``Sparse3DMatrix.save`` / ``AlignmentPropertyMatrix.save``,
+``Sparse3DMatrix.py:325-342``, ``AlignmentPropertyMatrix.py:507-532``).
+
+Logical layout: root attrs ``incidence_only``, ``mtype='csc_matrix'``, ``shape=(T, H, E)``; groups
+``/h0../h{H-1}`` with uint32 ``indptr``/``indices`` (and float64 ``data`` unless incidence-only);
+``/lengths`` (T x H); ``/count`` (vector, or group indptr/indices/data when 2-D); attr ``hname``;
+arrays ``/lname``, ``/rname``, ``/sname``.
+
+PyTables (the reference's writer) and h5py are both absent from this image, so this module can only
+run where one of them is installed; the byte/attribute-level structure PyTables produces is NOT
+pinned by any fixture ("parity unpinned: .h5").
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def _backend():
+    try:
+        import tables  # noqa: F401
+        return "tables"
+    except ImportError:
+        pass
+    try:
+        import h5py  # noqa: F401
+        return "h5py"
+    except ImportError:
+        raise RuntimeError("EMASE .h5 I/O needs PyTables or h5py; neither is installed. "
+                           "Use the .bin (EC format 2) output, which is complete and byte-exact.")
+
+
+def save(h5file, m, title=None, incidence_only=True):
+    """Write :class:`alntools_amd.bin_utils.ECMatrices` ``m`` in the EMASE layout."""
+    be = _backend()
+    T, H, E = m.shape
+    mats = [m.haplotype_csc(h) for h in range(H)]
+    if be == "tables":
+        import tables
+        fil = tables.Filters(complevel=1, complib='zlib')
+        with tables.open_file(h5file, 'w', title=title or '') as f:
+            f.set_node_attr(f.root, 'incidence_only', incidence_only)
+            f.set_node_attr(f.root, 'mtype', 'csc_matrix')
+            f.set_node_attr(f.root, 'shape', (T, H, E))
+            for h, sp in enumerate(mats):
+                g = f.create_group(f.root, 'h%d' % h, 'Sparse matrix components for Haplotype %d' % h)
+                f.create_carray(g, 'indptr', obj=sp.indptr.astype('uint32'), filters=fil)
+                f.create_carray(g, 'indices', obj=sp.indices.astype('uint32'), filters=fil)
+                if not incidence_only:
+                    f.create_carray(g, 'data', obj=sp.data.astype(float), filters=fil)
+            f.create_carray(f.root, 'lengths', obj=np.asarray(m.lengths), title='Transcript Lengths', filters=fil)
+            if m.num_samples == 1:
+                f.create_carray(f.root, 'count', obj=m.dataN.astype(np.float64), title='Equivalence Class Counts', filters=fil)
+            else:
+                g = f.create_group(f.root, 'count', 'Sparse matrix components for N matrix')
+                f.create_carray(g, 'indptr', obj=m.indptrN.astype('uint32'), filters=fil)
+                f.create_carray(g, 'indices', obj=m.indicesN.astype('uint32'), filters=fil)
+                f.create_carray(g, 'data', obj=m.dataN.astype('uint32'), filters=fil)
+            f.set_node_attr(f.root, 'hname', m.hname)
+            f.create_carray(f.root, 'lname', obj=np.array(m.lname), title='Locus Names', filters=fil)
+            f.create_carray(f.root, 'rname', obj=np.arange(E).astype(str), title='Read Names', filters=fil)
+            f.create_carray(f.root, 'sname', obj=np.array(m.sname), title='Sample Names', filters=fil)
+        return
+    import h5py
+    with h5py.File(h5file, 'w') as f:
+        f.attrs['incidence_only'] = incidence_only
+        f.attrs['mtype'] = np.bytes_('csc_matrix')
+        f.attrs['shape'] = (T, H, E)
+        for h, sp in enumerate(mats):
+            g = f.create_group('h%d' % h)
+            g.create_dataset('indptr', data=sp.indptr.astype('uint32'), compression='gzip', compression_opts=1)
+            g.create_dataset('indices', data=sp.indices.astype('uint32'), compression='gzip', compression_opts=1)
+            if not incidence_only:
+                g.create_dataset('data', data=sp.data.astype(float), compression='gzip', compression_opts=1)
+        f.create_dataset('lengths', data=np.asarray(m.lengths))
+        if m.num_samples == 1:
+            f.create_dataset('count', data=m.dataN.astype(np.float64))
+        else:
+            g = f.create_group('count')
+            g.create_dataset('indptr', data=m.indptrN.astype('uint32'))
+            g.create_dataset('indices', data=m.indicesN.astype('uint32'))
+            g.create_dataset('data', data=m.dataN.astype('uint32'))
+        f.attrs['hname'] = [np.bytes_(x) for x in m.hname]
+        f.create_dataset('lname', data=np.array(m.lname, dtype='S'))
+        f.create_dataset('rname', data=np.arange(E).astype('S'))
+        f.create_dataset('sname', data=np.array(m.sname, dtype='S'))
+
+
+def load(h5file):
+    """EMASE ``.h5`` -> :class:`ECMatrices` (the inverse of :func:`save`; ``A = sum_h 2^h * M_h``)."""
+    from scipy.sparse import csc_matrix
+    from .bin_utils import ECMatrices
+    be = _backend()
+    if be == "tables":
+        import tables
+        with tables.open_file(h5file, 'r') as f:
+            T, H, E = (int(x) for x in f.get_node_attr('/', 'shape'))
+            parts = [(f.get_node('/h%d' % h, 'indptr').read(), f.get_node('/h%d' % h, 'indices').read()) for h in range(H)]
+            lengths = f.get_node('/', 'lengths').read()
+            hname = [x.decode() if isinstance(x, bytes) else str(x) for x in f.get_node_attr('/', 'hname')]
+            lname = [x.decode() if isinstance(x, bytes) else str(x) for x in f.get_node('/', 'lname').read()]
+            sname = [x.decode() if isinstance(x, bytes) else str(x) for x in f.get_node('/', 'sname').read()]
+            cnode = f.get_node('/', 'count')
+            if isinstance(cnode, tables.Group):
+                N = (cnode.indptr.read(), cnode.indices.read(), cnode.data.read())
+            else:
+                c = cnode.read()
+                N = (np.array([0, E]), np.arange(E), c)
+    else:
+        import h5py
+        with h5py.File(h5file, 'r') as f:
+            T, H, E = (int(x) for x in f.attrs['shape'])
+            parts = [(f['h%d/indptr' % h][()], f['h%d/indices' % h][()]) for h in range(H)]
+            lengths = f['lengths'][()]
+            hname = [x.decode() if isinstance(x, bytes) else str(x) for x in f.attrs['hname']]
+            lname = [x.decode() for x in f['lname'][()]]
+            sname = [x.decode() for x in f['sname'][()]]
+            if isinstance(f['count'], h5py.Group):
+                N = (f['count/indptr'][()], f['count/indices'][()], f['count/data'][()])
+            else:
+                N = (np.array([0, E]), np.arange(E), f['count'][()])
+    a = None
+    for h, (ip, ix) in enumerate(parts):
+        mh = csc_matrix((np.full(len(ix), float(2 ** h)), ix.astype(int), ip.astype(int)), shape=(E, T))
+        a = mh if a is None else a + mh
+    a = a.tocsr()
+    a.sort_indices()
+    return ECMatrices(hname, lname, lengths, sname, a.indptr, a.indices, a.data.astype(np.int64),
+                      np.asarray(N[0]).astype(np.int64), np.asarray(N[1]).astype(np.int64), np.asarray(N[2]).astype(np.int64))

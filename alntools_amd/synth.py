@@ -20,9 +20,10 @@ Workload model (BASELINE.json configs):
 * single-end: 0-2 unmapped records (flag 4) are interleaved into a read
   (~5 % of all records) and 4 % of reads are entirely unmapped;
 * paired-end: every alignment is a read1 record (0x43/0x53) followed by its
-  read2 mate (0x83/0x93); 3 % are not properly paired and 1 % have the mate on
-  another reference -- both are dropped by the reference's filter
-  (``bam_utils.py:268-270``);
+  read2 mate (0x83/0x93); 3 % of the reads are not properly paired and 1 % have
+  the mate on another reference (all their alignments, so the read vanishes),
+  and 0.2 % + 0.2 % of single alignments have the same problems -- all dropped
+  by the reference's filter (``bam_utils.py:268-270``);
 * the alignments of a read are rotated by a per-read offset so they do not
   arrive sorted by target.
 
@@ -34,7 +35,7 @@ from __future__ import annotations
 import numpy as np
 
 SEED = 20260101
-GEN_VERSION = 1  # bump when the stream changes: committed fixtures depend on it
+GEN_VERSION = 2  # bump when the stream changes: committed fixtures depend on it
 
 _NLOCI_CHOICES = (1, 1, 2, 3, 5)
 _MAXL = 5
@@ -317,9 +318,11 @@ def generate(spec, r0, r1, device=None, want_raw=False, read_id_base=0):
     pos = _pos(_rnd(seed, rr * 64 + a, 11)) % length
     rev = _pos(_rnd(seed, rr * 64 + a, 12)) & 1
     if spec.paired:
-        q = _pos(_rnd(seed, rr * 64 + a, 13)) % 100
-        improper = q < 3
-        other = (q >= 3) & (q < 4)
+        # pairing problems are mostly a property of the fragment (all its alignments), rarely of one alignment
+        qr = _pos(_rnd(seed, rr, 14)) % 100
+        q = _pos(_rnd(seed, rr * 64 + a, 13)) % 1000
+        improper = (qr < 3) | (q < 2)
+        other = ((qr >= 3) & (qr < 4)) | ((q >= 2) & (q < 4))
         flag = be.where(mate2, 0x81, 0x41) + be.where(improper, 0, 0x2) + \
             be.where(rev == 1, be.where(mate2, 0x20, 0x10), be.where(mate2, 0x10, 0x20))
         next_tid = be.where(other, (tid + 1) % (T * H), tid)

@@ -1,0 +1,118 @@
+# -*- coding: utf-8 -*-
+"""Host side of the record-tuple contract of ``include/ecb.h``: BAM header -> index maps, decoded
+records -> ``(read_id, locus, hapflag, pos)`` streams.
+
+What stays on the host is what only the host can know: names.  The reference derives targets and
+haplotypes from ``@SQ`` names (``bam_utils.py:561-633``) and groups records into reads by comparing
+space-trimmed query names of consecutive *valid* records (``bam_utils.py:289-320``).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+
+from .ecb import FLAG_MATE_OTHER_REF, FLAG_NEXT_POS_NEG, HAP_SHIFT
+
+
+def split_reference_name(name):
+    """Split at the last ``'_'`` if its index is > 0 (``bam_utils.py:584-591``)."""
+    i = name.rfind('_')
+    if i > 0:
+        return name[:i], name[i + 1:]
+    return name, ''
+
+
+class HeaderMaps(object):
+    """``tid -> (locus, haplotype)`` and the names/lengths the writers need (``bam_utils.py:561-633``)."""
+
+    def __init__(self, references, lengths, target_ids=None):
+        main_targets = OrderedDict((t, i) for i, t in enumerate(target_ids or []))   # target file first (:571-579)
+        first_tid = {}
+        for tid, name in enumerate(references):
+            first_tid.setdefault(name, tid)
+        parts = [split_reference_name(n) for n in references]
+        for target, _ in parts:                                      # then header order (:596-598)
+            if target not in main_targets:
+                main_targets[target] = len(main_targets)
+        self.haplotypes = sorted(set(h for _, h in parts))           # '' sorts first (:602)
+        hap_idx = {h: i for i, h in enumerate(self.haplotypes)}
+        self.main_targets = list(main_targets.keys())
+        T, H = len(self.main_targets), len(self.haplotypes)
+        self.lengths = np.zeros((T, H), dtype=np.int32)              # :605
+        self.tid2locus = np.zeros(len(references), dtype=np.uint32)
+        self.tid2hap = np.zeros(len(references), dtype=np.uint32)
+        self.slot2tid = np.full(T * H, -1, dtype=np.int64)           # gettid(target_hap), -1 if absent (:754, :809)
+        for tid, (target, hap) in enumerate(parts):
+            l, h = main_targets[target], hap_idx[hap]
+            self.lengths[l, h] = lengths[tid]                        # :615-633
+            self.tid2locus[tid], self.tid2hap[tid] = l, h
+            rebuilt = target if len(hap) == 0 else '{}_{}'.format(target, hap)   # :801-806
+            if first_tid.get(rebuilt, -1) != tid:
+                # The reference tests "gettid(target_hap) in key" per (EC, target, haplotype); that equals
+                # "this tid is in the key" only when names and (target, haplotype) correspond one to one.
+                raise ValueError("reference name %r does not round-trip through (target=%r, haplotype=%r): "
+                                 "such headers (duplicate names, or a trailing '_') are not supported" %
+                                 (references[tid], target, hap))
+            self.slot2tid[l * H + h] = tid
+        if H > 31:
+            raise ValueError("more than 31 haplotypes cannot be stored in the .bin bitmask (bin_utils.py:208-210)")
+        self.n_loci, self.n_haplotypes = T, H
+
+
+def record_valid(flag, tid, next_tid, next_pos):
+    """Vectorised record filter (``bam_utils.py:264-270``)."""
+    flag = flag.astype(np.int64)
+    paired = (flag & 0x1) != 0
+    bad = ((flag & 0x80) != 0) | ((flag & 0x2) == 0) | (tid != next_tid) | (next_pos < 0)
+    return ((flag & 0x4) == 0) & ~(paired & bad)
+
+
+def trim_name(q):
+    """Cut at the first space only if its index is > 0 (``bam_utils.py:292-294``)."""
+    i = q.find(' ')
+    return q[:i] if i > 0 else q
+
+
+class TupleEncoder(object):
+    """Streams decoded BAM records into device tuples; carries the open read across batches."""
+
+    def __init__(self, maps, trim=True):
+        self.maps = maps
+        self.cur = 0xFFFFFFFF            # id of the latest read started (none yet)
+        self.last_name = None            # its (trimmed) name
+        self.trim = trim
+        self.names_of_reads = None       # optional: first name of every read (multisample needs the cell)
+
+    def encode(self, qnames, flag, tid, pos, next_tid, next_pos):
+        n = len(qnames)
+        flag = np.asarray(flag)
+        tid = np.asarray(tid, dtype=np.int64)
+        valid = record_valid(flag, tid, np.asarray(next_tid, dtype=np.int64), np.asarray(next_pos, dtype=np.int64))
+        vi = np.nonzero(valid)[0]
+        names = [trim_name(qnames[i]) if self.trim else qnames[i] for i in vi]
+        # a read starts at a valid record whose name differs from the previous valid record's
+        head = np.zeros(len(vi), dtype=bool)
+        prev = self.last_name
+        for k, nm in enumerate(names):
+            if nm != prev:
+                head[k] = True
+                prev = nm
+        if names:
+            self.last_name = prev
+        if self.names_of_reads is not None:
+            self.names_of_reads.extend(qnames[vi[k]] for k in np.nonzero(head)[0])
+        starts = np.zeros(n, dtype=np.int64)
+        starts[vi[head]] = 1
+        rid = (np.cumsum(starts) + (np.int64(self.cur) if self.cur != 0xFFFFFFFF else -1))
+        if n:
+            last = int(rid[-1])
+            self.cur = last if last >= 0 else 0xFFFFFFFF
+        safe_tid = np.where(valid, tid, 0)
+        locus = self.maps.tid2locus[safe_tid]
+        hap = self.maps.tid2hap[safe_tid]
+        hostbits = np.where(tid != np.asarray(next_tid, dtype=np.int64), FLAG_MATE_OTHER_REF, 0) | \
+            np.where(np.asarray(next_pos, dtype=np.int64) < 0, FLAG_NEXT_POS_NEG, 0)
+        hapflag = (flag.astype(np.int64) & 0xFFF) | hostbits | (hap.astype(np.int64) << HAP_SHIFT)
+        return dict(read_id=(rid & 0xFFFFFFFF).astype(np.uint32), locus=locus.astype(np.uint32),
+                    hapflag=hapflag.astype(np.uint32), pos=np.asarray(pos, dtype=np.int32), n_valid=int(valid.sum()))

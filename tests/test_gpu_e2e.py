@@ -1,0 +1,66 @@
+"""End to end on the GPU: BAM file -> alntools_amd.bam_utils.convert() -> .bin / range file, compared byte for
+byte with what the reference wrote for the same BAM (tests/golden)."""
+import hashlib
+import json
+import os
+
+import pytest
+
+from alntools_amd import bamio, methods, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _bytes(p):
+    with open(p, "rb") as f:
+        return f.read()
+
+
+def test_edge_case_bam_matches_reference_bytes(golden_dir, tmp_path):
+    g = json.load(open(os.path.join(golden_dir, "g1_edge.json")))
+    bam = str(tmp_path / g["sample"])
+    bamio.write_bam(bam, [tuple(r) for r in g["references"]], [tuple(r) for r in g["records"]])
+    out, rng = str(tmp_path / "o.bin"), str(tmp_path / "o.range")
+    sizes = methods.bam2ec(bam, out, range_filename=rng)
+    assert _bytes(out) == _bytes(os.path.join(golden_dir, "g1_edge.bin"))
+    assert open(rng).read() == open(os.path.join(golden_dir, "g1_edge.range.txt")).read()
+    assert sizes["valid_alignments"] == g["counters"]["# Valid Alignments"]
+    tf = str(tmp_path / "targets.txt")
+    open(tf, "w").write(g["targets_txt"])
+    methods.bam2ec(bam, out, range_filename=rng, target_filename=tf)
+    assert _bytes(out) == _bytes(os.path.join(golden_dir, "g1_edge_targets.bin"))
+    assert open(rng).read() == open(os.path.join(golden_dir, "g1_edge_targets.range.txt")).read()
+
+
+def test_config1_bam_matches_reference_bytes(golden_dir, tmp_path):
+    g = json.load(open(os.path.join(golden_dir, "g2_c1.json")))
+    spec = synth.SynthSpec(**g["spec"])
+    bam = str(tmp_path / g["sample"])
+    bamio.write_bam(bam, spec.references(), synth.raw_records(spec, 0, spec.n_reads), level=1)
+    out, rng = str(tmp_path / "c1.bin"), str(tmp_path / "c1.range")
+    methods.bam2ec(bam, out, range_filename=rng)
+    assert _bytes(out) == _bytes(os.path.join(golden_dir, "g2_c1.bin"))
+    assert open(rng).read() == open(os.path.join(golden_dir, "g2_c1.range.txt")).read()
+
+
+@pytest.mark.parametrize("name", ["g3_pe", "g3_mid"])
+def test_8_haplotype_bams_match_reference_md5(golden_dir, tmp_path, name):
+    g = json.load(open(os.path.join(golden_dir, name + ".json")))
+    spec = synth.SynthSpec(**g["spec"])
+    bam = str(tmp_path / g["sample"])
+    bamio.write_bam(bam, spec.references(), synth.raw_records(spec, 0, spec.n_reads), level=1)
+    out, rng = str(tmp_path / "o.bin"), str(tmp_path / "o.range")
+    sizes = methods.bam2ec(bam, out, range_filename=rng)
+    b = _bytes(out)
+    assert len(b) == g["bin_len"] and hashlib.md5(b).hexdigest() == g["bin_md5"]
+    assert hashlib.md5(open(rng).read().encode()).hexdigest() == g["range_md5"]
+    assert sizes["n_ecs"] == g["counters"]["# Equivalence Classes"]
+
+
+def test_no_valid_alignment_fails_cleanly(tmp_path):
+    from alntools_amd.ecb import EcbError
+    bam = str(tmp_path / "u.bam")
+    bamio.write_bam(bam, [("T_A", 100)], [("r1", 4, -1, -1, -1, -1)])
+    with pytest.raises(EcbError) as e:
+        methods.bam2ec(bam, str(tmp_path / "u.bin"))
+    assert e.value.code == -7
