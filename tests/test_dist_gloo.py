@@ -1,0 +1,141 @@
+"""The multi-GPU exchange (alntools_amd/dist.py) at world size 2 on CPU / gloo, with an oracle-backed engine in
+place of libecb: contiguous read shards -> per-rank EC tables -> all-gather -> ordered merge on the root must
+equal the single-process oracle on the whole stream (EC order = global first appearance)."""
+import hashlib
+import os
+import socket
+import struct
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from alntools_amd import dist as ecdist
+from alntools_amd import synth
+from oracle import ec_oracle as orc
+
+
+class OracleEngine(object):
+    """EC table of one shard, built with the oracle; speaks the same table protocol as libecb."""
+    device = torch.device("cpu")
+
+    def __init__(self, n_haps):
+        self.n_haps = n_haps
+        self.table = {}              # (lo, hi) -> [count, first, pairs]
+        self.n_all = self.n_valid = self.n_reads = 0
+
+    @staticmethod
+    def _ident(pairs):
+        d = hashlib.md5(np.asarray(pairs, dtype=np.int64).tobytes()).digest()
+        lo, hi = struct.unpack("<qq", d)
+        return lo, hi
+
+    def build(self, t):
+        valid = orc.tuples_valid(t["hapflag"])
+        rid = t["read_id"].astype(np.int64)
+        loc = t["locus"].astype(np.int64)
+        hap = (t["hapflag"].astype(np.int64) >> 16) & 0xFF
+        cur, row = None, None
+
+        def close():
+            pairs = tuple(sorted(row.items()))
+            e = self.table.setdefault(self._ident(pairs), [0, cur, pairs])
+            e[0] += 1
+            e[1] = min(e[1], cur)
+
+        for i in np.nonzero(valid)[0]:
+            if rid[i] != cur:
+                if cur is not None:
+                    close()
+                cur, row = int(rid[i]), {}
+                self.n_reads += 1
+            row[int(loc[i])] = row.get(int(loc[i]), 0) | (1 << int(hap[i]))
+        if cur is not None:
+            close()
+        self.n_all, self.n_valid = len(rid), int(valid.sum())
+
+    # --- protocol -------------------------------------------------------------------------
+    def table_sizes(self):
+        return len(self.table), sum(len(v[2]) for v in self.table.values()), self.n_reads
+
+    def counters(self):
+        return self.n_all, self.n_valid, self.n_reads
+
+    def table_export(self, read_base):
+        ent, prs = [], []
+        for (lo, hi), (count, first, pairs) in self.table.items():
+            first_inv = (~(first + read_base)) & 0xFFFFFFFF
+            w2 = count | (first_inv << 32)
+            w3 = len(prs) | (len(pairs) << 32)
+            ent += [lo, hi, w2 - (1 << 64) if w2 >= (1 << 63) else w2, w3]
+            prs += [l | (m << 32) for l, m in pairs]
+        return (torch.tensor(ent or [0] * 4, dtype=torch.int64), torch.tensor(prs or [0], dtype=torch.int64))
+
+    def table_merge(self, ent, n_entries, prs, n_pairs):
+        e = ent.numpy().astype(np.uint64).reshape(-1, 4)[:n_entries]
+        p = prs.numpy().astype(np.uint64)
+        for lo, hi, w2, w3 in e.tolist():
+            count, first = w2 & 0xFFFFFFFF, (~(w2 >> 32)) & 0xFFFFFFFF
+            off, n = w3 & 0xFFFFFFFF, w3 >> 32
+            pairs = tuple((int(x) & 0xFFFFFFFF, int(x) >> 32) for x in p[off:off + n])
+            t = self.table.setdefault((lo, hi), [0, first, pairs])
+            assert t[2] == pairs
+            t[0] += count
+            t[1] = min(t[1], first)
+
+    def add_counters(self, a, v, r):
+        self.n_all += a
+        self.n_valid += v
+        self.n_reads += r
+
+    def csr(self):
+        rows = sorted(self.table.values(), key=lambda v: v[1])
+        indptr, indices, data = [0], [], []
+        for count, first, pairs in rows:
+            indices += [l for l, _ in pairs]
+            data += [m for _, m in pairs]
+            indptr.append(len(indices))
+        return dict(indptr=np.array(indptr), indices=np.array(indices), data=np.array(data),
+                    count=np.array([r[0] for r in rows]))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, spec_args, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = synth.SynthSpec(**spec_args)
+    R = spec.n_reads
+    t = synth.generate(spec, rank * R // world, (rank + 1) * R // world)      # local read ids from 0
+    eng = OracleEngine(spec.n_haps)
+    eng.build(t)
+    merged = ecdist.exchange_and_merge(eng, lambda: OracleEngine(spec.n_haps), root=0)
+    if rank == 0:
+        c = merged.csr()
+        np.savez(out_path, n_all=merged.n_all, n_valid=merged.n_valid, n_reads=merged.n_reads, **c)
+    else:
+        assert merged is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_two_rank_merge_equals_single_process(tmp_path, paired):
+    spec_args = dict(n_reads=3000, n_loci=300, n_haps=4, paired=paired)
+    out = str(tmp_path / "merged.npz")
+    mp.spawn(_worker, args=(2, _free_port(), spec_args, out), nprocs=2, join=True)
+    got = np.load(out)
+    spec = synth.SynthSpec(**spec_args)
+    t = synth.generate(spec, 0, spec.n_reads)
+    exp = orc.ec_from_tuples(t["read_id"], t["locus"], t["hapflag"], spec.n_loci, spec.n_haps)
+    for k in ("indptr", "indices", "data", "count"):
+        assert np.array_equal(got[k], exp[k]), k
+    assert int(got["n_all"]) == exp["n_all"] and int(got["n_valid"]) == exp["n_valid"]
+    assert int(got["n_reads"]) == t["n_reads"]

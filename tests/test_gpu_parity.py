@@ -204,3 +204,35 @@ def test_mid_size_device_vs_c_oracle_properties(paired):
     out2, s2 = _run_host(th, spec.n_loci, spec.n_haps, batch=1 << 20)
     for k in ("indptrA", "indicesA", "dataA", "dataN"):
         assert np.array_equal(out[k], out2[k]), k
+
+
+def test_shard_tables_merge_to_the_single_handle_result():
+    """Two handles over contiguous read shards, tables exported / merged on one GPU (the multi-GPU protocol
+    without the collective) == one handle over the whole stream, including EC order."""
+    import torch
+    from alntools_amd import dist as ecdist
+    spec = synth.SynthSpec(60000, 3000, 8, paired=True)
+    dev = torch.device("cuda:0")
+    whole = synth.generate(spec, 0, spec.n_reads)
+    exp = _expect(whole, spec.n_loci, spec.n_haps)
+    cuts = [0, 25000, spec.n_reads]
+    engines, sizes = [], []
+    for a, b_ in zip(cuts[:-1], cuts[1:]):
+        t = synth.generate(spec, a, b_, device=dev)
+        b = ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=1 << 12)
+        b.push_device(t["read_id"], t["locus"], t["hapflag"])
+        engines.append(ecdist.GpuEngine(b, dev))
+        sizes.append(b.table_sizes() + b.counters()[:2])
+    root = ecdist.GpuEngine(ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=1 << 12), dev)
+    base = 0
+    for eng, (ne, npairs, nreads, n_all, n_valid) in zip(engines, sizes):
+        ent, prs = eng.table_export(base)
+        root.table_merge(ent, ne, prs, npairs)
+        base += nreads
+    root.add_counters(sum(s[3] for s in sizes), sum(s[4] for s in sizes), base)
+    s = root.b.finalize()
+    out = root.b.export()
+    _check(out, s, exp)
+    assert s["n_reads"] == whole["n_reads"]
+    for e in engines + [root]:
+        e.b.close()
