@@ -34,6 +34,8 @@
 #include <string>
 #include <vector>
 
+#include <rocprim/rocprim.hpp>   // radix sort of the (EC, cell, file) keys of the multisample path only
+
 #include "../../include/ecb.h"
 
 namespace {
@@ -822,6 +824,26 @@ __global__ __launch_bounds__(TPB) void k_emit(const Slot* table, const u32* orde
     if (lane == 0) counts[e] = (int)s.count;
 }
 
+// multisample: key = EC rank << 32 | meta (cell, file) of every read
+__global__ void k_ms_keys(const u32* read_slot, const u32* rank_of_slot, const u32* meta, u64 n, u64* keys, u32* vals) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n) { keys[i] = ((u64)rank_of_slot[read_slot[i]] << 32) | meta[i]; vals[i] = (u32)i; }
+}
+__global__ void k_ms_heads(const u64* keys, u64 n, u32* flag) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+__global__ void k_ms_emit(const u64* keys, const u32* vals, const u32* flag, const u32* pos, u64 n, u32 n_out,
+                          u64* okey, u32* ofirst, u32* ostart) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) { okey[pos[i]] = keys[i]; ofirst[pos[i]] = vals[i]; ostart[pos[i]] = (u32)i; }
+    if (i == 0) ostart[n_out] = (u32)n;
+}
+__global__ void k_ms_split(const u64* okey, const u32* ostart, u64 n, u32* ec, u32* meta, u32* count) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n) { ec[i] = (u32)(okey[i] >> 32); meta[i] = (u32)okey[i]; count[i] = ostart[i + 1] - ostart[i]; }
+}
+
 __global__ void k_iota(int* out, u64 n) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i < n) out[i] = (int)i;
@@ -857,6 +879,8 @@ struct ecb_handle {
     Counters* ctr = nullptr;
     Counters hctr{};                  // last read-back
     u32* read_slot = nullptr; u64 read_slot_cap = 0;
+    u32* meta = nullptr; u64 meta_cap = 0, meta_hi = 0;   // multisample: cell | file << 22 per read
+    u64 n_triples = 0; u64* ms_okey = nullptr; u32 *ms_ofirst = nullptr, *ms_ostart = nullptr;
     int *rng_min = nullptr, *rng_max = nullptr;
     u64* queue = nullptr; u64 queue_cap = 0;
     u64 n_ecs() const { return hctr.n_ecs; }
@@ -877,7 +901,8 @@ struct ecb_handle {
 
     // device scratch reused across calls (grown on demand, freed at destroy)
     enum { P_RESUME, P_SUMS, P_HIST, P_OFFS, P_PAIRS, P_CNT, P_LIST, P_BITMAP, P_WPOP, P_WPREFIX, P_ROWLEN, P_ORDER,
-           P_RANK, P_INDPTR, P_COUNTS, P_INDICES, P_DATA, P_N };
+           P_RANK, P_INDPTR, P_COUNTS, P_INDICES, P_DATA, P_MS_KEYS, P_MS_KEYS2, P_MS_VALS, P_MS_VALS2, P_MS_TMP,
+           P_MS_FLAG, P_MS_POS, P_MS_OKEY, P_MS_OFIRST, P_MS_OSTART, P_MS_X, P_N };
     void* pool[P_N] = {}; u64 pool_bytes[P_N] = {};
 
     // profiling
@@ -1223,7 +1248,7 @@ void ecb_destroy(ecb_handle* h) {
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     free_results(h);
-    hipFree(h->table); hipFree(h->arena); hipFree(h->ctr); hipFree(h->read_slot);
+    hipFree(h->table); hipFree(h->arena); hipFree(h->ctr); hipFree(h->read_slot); hipFree(h->meta);
     hipFree(h->rng_min); hipFree(h->rng_max); hipFree(h->queue);
     for (int i = 0; i < ecb_handle::P_N; ++i) hipFree(h->pool[i]);
     hipFree(h->st_rid); hipFree(h->st_loc); hipFree(h->st_hf); hipFree(h->st_pos);
@@ -1247,7 +1272,7 @@ int ecb_reset(ecb_handle* h) {
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->hctr = Counters{};
-    h->prev_rid = 0xFFFFFFFFu; h->n_reads = 0; h->reads_hi = 0;
+    h->prev_rid = 0xFFFFFFFFu; h->n_reads = 0; h->reads_hi = 0; h->meta_hi = 0; h->n_triples = 0;
     h->extra_all = h->extra_valid = h->extra_reads = 0;
     h->c_rid.clear(); h->c_loc.clear(); h->c_hf.clear(); h->c_pos.clear();
     h->finalized = false; h->counted = false; h->sizes = ecb_sizes{}; h->n_list = 0;
@@ -1301,9 +1326,29 @@ int ecb_push(ecb_handle* h, const uint32_t* rid, const uint32_t* loc, const uint
     return ECB_OK;
 }
 
-int ecb_push_cells(ecb_handle* h, const uint32_t*, uint64_t, size_t) {
+int ecb_push_cells(ecb_handle* h, const uint32_t* meta, uint64_t first_read, size_t n) {
     if (!h) return ECB_ERR_ARG;
-    return fail(h, ECB_ERR_STATE, "multisample is not built into this libecb yet");
+    if (!(h->cfg.flags & ECB_F_MULTISAMPLE)) return fail(h, ECB_ERR_STATE, "handle was created without ECB_F_MULTISAMPLE");
+    if (h->finalized) return fail(h, ECB_ERR_STATE, "push after finalize");
+    if (!n) return ECB_OK;
+    if (!meta) return fail(h, ECB_ERR_ARG, "null meta");
+    HIPCHK(h, hipSetDevice(h->device));
+    const u64 need = first_read + n;
+    if (need > h->meta_cap) {
+        const u64 nc = std::max<u64>(need, h->meta_cap * 2);
+        u32* p = nullptr;
+        HIPCHK(h, hipMalloc(&p, nc * sizeof(u32)));
+        if (h->meta) {
+            HIPCHK(h, hipMemcpyAsync(p, h->meta, h->meta_hi * sizeof(u32), hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            HIPCHK(h, hipFree(h->meta));
+        }
+        h->meta = p; h->meta_cap = nc;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->meta + first_read, meta, n * sizeof(u32), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->meta_hi = std::max<u64>(h->meta_hi, need);
+    return ECB_OK;
 }
 
 int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
@@ -1353,6 +1398,33 @@ int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
     k_emit<<<nblk(E * 64, TPB), TPB, 0, h->stream>>>(h->table, h->order, E, h->arena, h->indptr, h->indices, h->data, h->counts);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->sizes.n_ecs = E; h->sizes.nnz_a = nnz; h->sizes.n_samples = 1; h->sizes.nnz_n = E;
+    if (h->cfg.flags & ECB_F_MULTISAMPLE) {
+        // distinct (EC, cell, file) triples: sort the per-read keys, run-length encode
+        const u64 R = h->n_reads;
+        if (h->extra_reads) return fail(h, ECB_ERR_STATE, "multisample is single-GPU in this build");
+        if (h->meta_hi < R) return fail(h, ECB_ERR_STATE, "ecb_push_cells covered %llu of %llu reads",
+                                        (unsigned long long)h->meta_hi, (unsigned long long)R);
+        u64 *keys = nullptr, *keys2 = nullptr; u32 *vals = nullptr, *vals2 = nullptr, *flag = nullptr, *pos = nullptr;
+        POOL(h, P_MS_KEYS, keys, R); POOL(h, P_MS_KEYS2, keys2, R); POOL(h, P_MS_VALS, vals, R); POOL(h, P_MS_VALS2, vals2, R);
+        POOL(h, P_MS_FLAG, flag, R); POOL(h, P_MS_POS, pos, R);
+        k_ms_keys<<<nblk(R, TPB), TPB, 0, h->stream>>>(h->read_slot, h->rank_of_slot, h->meta, R, keys, vals);
+        size_t tmp_bytes = 0;
+        if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, R, 0, 64, h->stream) != hipSuccess)
+            return fail(h, ECB_ERR_HIP, "rocprim::radix_sort_pairs (size query)");
+        char* tmp = nullptr;
+        POOL(h, P_MS_TMP, tmp, tmp_bytes);
+        if (rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, R, 0, 64, h->stream) != hipSuccess)
+            return fail(h, ECB_ERR_HIP, "rocprim::radix_sort_pairs");
+        k_ms_heads<<<nblk(R, TPB), TPB, 0, h->stream>>>(keys2, R, flag);
+        u32 nt = 0;
+        rc = excl_scan(h, flag, R, pos, &nt);
+        if (rc != ECB_OK) return rc;
+        POOL(h, P_MS_OKEY, h->ms_okey, nt); POOL(h, P_MS_OFIRST, h->ms_ofirst, nt); POOL(h, P_MS_OSTART, h->ms_ostart, (u64)nt + 1);
+        k_ms_emit<<<nblk(R, TPB), TPB, 0, h->stream>>>(keys2, vals2, flag, pos, R, nt, h->ms_okey, h->ms_ofirst, h->ms_ostart);
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->n_triples = nt;
+        h->sizes.n_samples = 0; h->sizes.nnz_n = nt;
+    }
     h->sizes.all_alignments = h->hctr.all + h->extra_all;
     h->sizes.valid_alignments = valid;
     h->sizes.n_reads = total_reads;
@@ -1379,6 +1451,8 @@ int ecb_export_device(ecb_handle* h, void* ia, void* ja, void* da, void* in_, vo
 int ecb_export(ecb_handle* h, int32_t* ia, int32_t* ja, int32_t* da, int32_t* in_, int32_t* jn, int32_t* dn) {
     if (!h) return ECB_ERR_ARG;
     if (!h->finalized) return fail(h, ECB_ERR_STATE, "export before finalize");
+    if ((h->cfg.flags & ECB_F_MULTISAMPLE) && (in_ || jn || dn))
+        return fail(h, ECB_ERR_STATE, "multisample: N comes from ecb_export_pairs");
     HIPCHK(h, hipSetDevice(h->device));
     const u64 E = h->sizes.n_ecs, nnz = h->sizes.nnz_a;
     if (ia) HIPCHK(h, hipMemcpyAsync(ia, h->indptr, (E + 1) * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1402,6 +1476,33 @@ int ecb_export_ranges(ecb_handle* h, int64_t* out) {
     HIPCHK(h, hipMemcpyAsync(out, d, ns * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipFree(d));
+    return ECB_OK;
+}
+
+int ecb_export_range_minmax(ecb_handle* h, int32_t* mn, int32_t* mx) {
+    if (!h || !mn || !mx) return ECB_ERR_ARG;
+    if (!(h->cfg.flags & ECB_F_RANGES)) return fail(h, ECB_ERR_STATE, "handle was created without ECB_F_RANGES");
+    HIPCHK(h, hipSetDevice(h->device));
+    const u64 ns = (u64)h->cfg.n_loci * h->cfg.n_haplotypes;
+    HIPCHK(h, hipMemcpyAsync(mn, h->rng_min, ns * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(mx, h->rng_max, ns * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ECB_OK;
+}
+
+int ecb_export_pairs(ecb_handle* h, uint32_t* ec, uint32_t* meta, uint32_t* count, uint32_t* first_read) {
+    if (!h || !ec || !meta || !count || !first_read) return ECB_ERR_ARG;
+    if (!h->finalized || !(h->cfg.flags & ECB_F_MULTISAMPLE)) return fail(h, ECB_ERR_STATE, "no multisample result");
+    HIPCHK(h, hipSetDevice(h->device));
+    const u64 nt = h->n_triples;
+    u32* x = nullptr;
+    POOL(h, P_MS_X, x, 3 * nt);
+    k_ms_split<<<nblk(nt, TPB), TPB, 0, h->stream>>>(h->ms_okey, h->ms_ostart, nt, x, x + nt, x + 2 * nt);
+    HIPCHK(h, hipMemcpyAsync(ec, x, nt * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(meta, x + nt, nt * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(count, x + 2 * nt, nt * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(first_read, h->ms_ofirst, nt * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return ECB_OK;
 }
 

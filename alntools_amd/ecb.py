@@ -25,7 +25,7 @@ FLAG_NEXT_POS_NEG = 0x2000
 #: every symbol include/ecb.h declares
 SYMBOLS = ("ecb_abi_version", "ecb_device_count", "ecb_create", "ecb_destroy", "ecb_reset", "ecb_last_error",
            "ecb_push", "ecb_push_device", "ecb_push_cells", "ecb_finalize", "ecb_export",
-           "ecb_export_device", "ecb_export_ranges", "ecb_export_read_ec", "ecb_table_sizes",
+           "ecb_export_device", "ecb_export_ranges", "ecb_export_range_minmax", "ecb_export_pairs", "ecb_export_read_ec", "ecb_table_sizes",
            "ecb_table_export_device", "ecb_table_merge_device", "ecb_counters", "ecb_add_counters", "ecb_profile",
            "ecb_profile_read")
 
@@ -85,6 +85,8 @@ def load():
     lib.ecb_export_device.argtypes = [vp] + [vp] * 6
     lib.ecb_export_ranges.argtypes = [vp, vp]
     lib.ecb_export_read_ec.argtypes = [vp, vp]
+    lib.ecb_export_pairs.argtypes = [vp, vp, vp, vp, vp]
+    lib.ecb_export_range_minmax.argtypes = [vp, vp, vp]
     lib.ecb_table_sizes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     lib.ecb_table_export_device.argtypes = [vp, vp, vp, u64]
     lib.ecb_table_merge_device.argtypes = [vp, vp, u64, vp, u64]
@@ -108,10 +110,11 @@ class EcBuilder(object):
     """One handle = one GPU.  Push record tuples, finalize, read back CSR A and N."""
 
     def __init__(self, n_loci, n_haplotypes, device=0, track_ranges=False, ec_capacity=0,
-                 arena_capacity=0, max_batch_records=0):
+                 arena_capacity=0, max_batch_records=0, multisample=False):
         self._lib = load()
         self._h = C.c_void_p()
-        flags = F_RANGES if track_ranges else 0
+        flags = (F_RANGES if track_ranges else 0) | (F_MULTISAMPLE if multisample else 0)
+        self.multisample = multisample
         cfg = Config(C.sizeof(Config), device, n_loci, n_haplotypes, flags, 0, ec_capacity,
                      arena_capacity, max_batch_records)
         rc = self._lib.ecb_create(C.byref(cfg), C.byref(self._h))
@@ -163,6 +166,11 @@ class EcBuilder(object):
         self._chk(self._lib.ecb_push_device(self._h, _dev_ptr(read_id), _dev_ptr(locus), _dev_ptr(hapflag),
                                             _dev_ptr(pos), n))
 
+    def push_cells(self, meta, first_read):
+        """Multisample: ``cell | file << 22`` of reads ``[first_read, first_read + len(meta))``."""
+        m = np.ascontiguousarray(meta, dtype=np.uint32)
+        self._chk(self._lib.ecb_push_cells(self._h, _ptr(m), first_read, len(m)))
+
     # -- results -------------------------------------------------------------
     def finalize(self):
         s = Sizes()
@@ -175,16 +183,35 @@ class EcBuilder(object):
         s = self.sizes or self.finalize()
         E, nnz, S, nnzn = s["n_ecs"], s["nnz_a"], s["n_samples"], s["nnz_n"]
         out = dict(indptrA=np.empty(E + 1, np.int32), indicesA=np.empty(nnz, np.int32),
-                   dataA=np.empty(nnz, np.int32), indptrN=np.empty(S + 1, np.int32),
-                   indicesN=np.empty(nnzn, np.int32), dataN=np.empty(nnzn, np.int32))
+                   dataA=np.empty(nnz, np.int32))
+        if self.multisample:
+            self._chk(self._lib.ecb_export(self._h, _ptr(out["indptrA"]), _ptr(out["indicesA"]), _ptr(out["dataA"]),
+                                           None, None, None))
+            return out
+        out.update(indptrN=np.empty(S + 1, np.int32), indicesN=np.empty(nnzn, np.int32), dataN=np.empty(nnzn, np.int32))
         self._chk(self._lib.ecb_export(self._h, *[_ptr(out[k]) for k in
                                                   ("indptrA", "indicesA", "dataA", "indptrN", "indicesN", "dataN")]))
         return out
+
+    def export_pairs(self):
+        """Multisample: distinct (EC, cell, file) triples -> dict(ec, cell, file, count, first), sorted by (ec, meta)."""
+        s = self.sizes or self.finalize()
+        n = s["nnz_n"]
+        ec, meta, cnt, first = (np.empty(n, np.uint32) for _ in range(4))
+        self._chk(self._lib.ecb_export_pairs(self._h, _ptr(ec), _ptr(meta), _ptr(cnt), _ptr(first)))
+        return dict(ec=ec.astype(np.int64), cell=(meta & ((1 << 22) - 1)).astype(np.int64), file=(meta >> 22).astype(np.int64),
+                    count=cnt.astype(np.int64), first=first.astype(np.int64))
 
     def export_ranges(self):
         out = np.empty((self.n_loci, self.n_haplotypes), np.int64)
         self._chk(self._lib.ecb_export_ranges(self._h, _ptr(out)))
         return out
+
+    def export_range_minmax(self):
+        mn = np.empty((self.n_loci, self.n_haplotypes), np.int32)
+        mx = np.empty((self.n_loci, self.n_haplotypes), np.int32)
+        self._chk(self._lib.ecb_export_range_minmax(self._h, _ptr(mn), _ptr(mx)))
+        return mn, mx
 
     def export_read_ec(self):
         s = self.sizes or self.finalize()

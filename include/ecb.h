@@ -107,10 +107,12 @@ int ecb_push(ecb_handle* h, const uint32_t* read_id, const uint32_t* locus, cons
 int ecb_push_device(ecb_handle* h, const void* d_read_id, const void* d_locus, const void* d_hapflag,
                     const void* d_pos, size_t n);
 
-/* Multisample only: cell id of reads [first_read, first_read + n) (dictionary-encoded by the host,
- * bam_utils_multisample.py:270-280), and the start of a new input file (the reference never counts
- * the last read of a file, bam_utils_multisample.py:306-321 -- the host drops it before pushing). */
-int ecb_push_cells(ecb_handle* h, const uint32_t* cell, uint64_t first_read, size_t n);
+/* Multisample only (ECB_F_MULTISAMPLE): per read, in read order, for reads [first_read, first_read + n):
+ *   meta = cell id (bits 0-21; dictionary-encoded by the host from the read name, bam_utils_multisample.py:270-280)
+ *        | input file index << 22 (bits 22-31; the reference scans one file per worker, :473-480).
+ * The host leaves out the last read of every file (the reference never counts it, :306-321). */
+int ecb_push_cells(ecb_handle* h, const uint32_t* meta, uint64_t first_read, size_t n);
+#define ECB_CELL_BITS 22
 
 /* Close the stream: rank ECs by first appearance (bam_utils.py:682-698), build CSR A and N. */
 int ecb_finalize(ecb_handle* h, ecb_sizes* out);
@@ -125,6 +127,13 @@ int ecb_export_device(ecb_handle* h, void* d_indptr_a, void* d_indices_a, void* 
 /* ECB_F_RANGES: per (locus, haplotype) max - min + 1 of reference_start over valid alignments, 0 if
  * none (the numbers of the reference's range file, bam_utils.py:756-763); n_loci * n_haplotypes values. */
 int ecb_export_ranges(ecb_handle* h, int64_t* range_len);
+/* The raw extremes behind ecb_export_ranges (min = INT32_MAX and max = INT32_MIN where nothing aligned). */
+int ecb_export_range_minmax(ecb_handle* h, int32_t* range_min, int32_t* range_max);
+/* Multisample, after ecb_finalize: the distinct (EC, cell, file) triples -- sizes.nnz_n of them, sorted by
+ * (EC, meta) -- with the number of reads and the first read index of each: what the reference keeps as
+ * ec[key][cell] per worker (bam_utils_multisample.py:288-290, 503-576).  Cell order, the minimum-count filter
+ * and the CSC N matrix (:596-636, 737-791) are metadata-sized work done by the host from these. */
+int ecb_export_pairs(ecb_handle* h, uint32_t* ec, uint32_t* meta, uint32_t* count, uint32_t* first_read);
 /* EC index of every read, in read order (n_reads values). */
 int ecb_export_read_ec(ecb_handle* h, int32_t* ec_of_read);
 

@@ -64,3 +64,23 @@ def test_no_valid_alignment_fails_cleanly(tmp_path):
     with pytest.raises(EcbError) as e:
         methods.bam2ec(bam, str(tmp_path / "u.bin"))
     assert e.value.code == -7
+
+
+@pytest.mark.parametrize("mc,tag", [(-1, "0"), (20, "20"), (60, "60")])
+def test_multisample_directory_matches_reference_bytes(golden_dir, tmp_path, mc, tag):
+    from alntools_amd import bam_utils_multisample as ms
+    g = json.load(open(os.path.join(golden_dir, "g4_multi.json")))
+    refs = [tuple(r) for r in g["references"]]
+    paths = []
+    for fname in g["glob_order"]:                      # the order the reference's glob returned when the golden was made
+        p = str(tmp_path / fname)
+        bamio.write_bam(p, refs, [tuple(r) for r in g["files"][fname]])
+        paths.append(p)
+    out, rng = str(tmp_path / "m.bin"), str(tmp_path / "m.range")
+    r = ms.convert_files(paths, out, None, minimum_count=mc, range_filename=rng)
+    assert _bytes(out) == _bytes(os.path.join(golden_dir, "g4_multi_min%s.bin" % tag))
+    c = g["counters"][str(mc)]
+    assert r["valid_alignments"] == c["Number of alignments"]
+    assert r["n_ecs"] == c["Number of ECs after filtering"] and r["n_cells"] == c["Number of cells after filtering"]
+    assert r["n_ecs_before"] == c["Number of ECs"] and r["n_cells_before"] == c["Number of cells"]
+    assert open(rng).read() == open(os.path.join(golden_dir, "g4_multi.range.txt")).read()
