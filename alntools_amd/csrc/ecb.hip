@@ -282,7 +282,6 @@ __global__ __launch_bounds__(TPB) void k_stream(StreamArgs A) {
                     r_key[k] = R.ll[k]; r_bit[k] = 1u << (hap & 31u);
                     const bool inr = (in4 >> j) & 1u;
                     if (inr & ((step > 1u) | ((step == 1u) & !ok))) bad |= ERR_CONTRACT;
-                    if (inr & ok & ((R.ll[k] >= A.n_loci) | (hap >= A.n_haps))) bad |= ERR_RANGE;
                     ok4 |= (u32)ok << j;
                     head4 |= (u32)(step == 1u) << j;
                 }
@@ -688,21 +687,35 @@ __global__ void k_remap_read_slot(u32* read_slot, u64 n_reads, const Slot* old_t
     }
 }
 
-// occupied slots -> dense list (order irrelevant: ranks come from `first`)
-__global__ __launch_bounds__(TPB) void k_compact(const Slot* table, u64 cap, u32* list, u64 max_list, u64* n_list) {
-    __shared__ u32 s_cnt;
+// occupied slots -> dense list (order irrelevant: ranks come from `first`); one global atomic per 4096 slots
+constexpr int TPB_COMPACT = 1024;
+__global__ __launch_bounds__(TPB_COMPACT) void k_compact(const Slot* table, u64 cap, u32* list, u64 max_list, u64* n_list) {
+    __shared__ u32 s_w[TPB_COMPACT / 64];
     __shared__ u64 s_base;
-    for (u64 b = (u64)blockIdx.x * TPB; b < cap; b += (u64)gridDim.x * TPB) {
-        if (threadIdx.x == 0) s_cnt = 0;
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    for (u64 b = (u64)blockIdx.x * 4 * TPB_COMPACT; b < cap; b += (u64)gridDim.x * 4 * TPB_COMPACT) {
+        u32 occ = 0, off[4], tot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const u64 i = b + (u64)k * TPB_COMPACT + tid;
+            const bool o = i < cap && table[i].hi != 0ull;
+            const u64 m = __ballot(o);
+            off[k] = tot + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+            tot += (u32)__popcll(m);
+            occ |= (u32)o << k;
+        }
+        if (lane == 0) s_w[w] = tot;
         __syncthreads();
-        const u64 i = b + threadIdx.x;
-        const bool occ = i < cap && table[i].hi != 0ull;
-        u32 my = 0;
-        if (occ) my = atomicAdd(&s_cnt, 1u);
+        if (tid == 0) {
+            u32 run = 0;
+            for (int k = 0; k < TPB_COMPACT / 64; ++k) { const u32 c = s_w[k]; s_w[k] = run; run += c; }
+            s_base = run ? atomicAdd(n_list, (u64)run) : 0ull;
+        }
         __syncthreads();
-        if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(n_list, (u64)s_cnt);
-        __syncthreads();
-        if (occ && s_base + my < max_list) list[s_base + my] = (u32)i;
+        const u64 base = s_base + s_w[w];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if ((occ >> k & 1u) && base + off[k] < max_list) list[base + off[k]] = (u32)(b + (u64)k * TPB_COMPACT + tid);
         __syncthreads();
     }
 }
@@ -805,23 +818,50 @@ __global__ void k_rank(const Slot* table, const u32* list, u64 n, const u32* bit
     rank_of_slot[si] = r;
 }
 
-// one wave per EC row: rank every (locus, mask) pair by locus and write it in place
-__global__ __launch_bounds__(TPB) void k_emit(const Slot* table, const u32* order, u64 n, const uint2* arena,
-                                               const u32* indptr, int* indices, int* data, int* counts) {
-    const u64 e = ((u64)blockIdx.x * TPB + threadIdx.x) >> 6;
-    const u32 lane = threadIdx.x & 63u;
+// CSR rows: every (locus, mask) pair of an EC is ranked by locus and written in place (columns ascending, as scipy's
+// csc -> csr leaves them: bin_utils.py:211).  Short rows: one thread each.  Long rows: queued, one wave each.
+// The indices the host supplied are validated here, once per EC instead of once per record.
+constexpr u32 EMIT_SMALL = 16;
+__global__ __launch_bounds__(TPB) void k_emit_small(const Slot* table, const u32* order, u64 n, const uint2* arena,
+                                                     const u32* indptr, int* indices, int* data, int* counts,
+                                                     u32 n_loci, u32 n_haps, u32* big, u32* n_big, Counters* ctr) {
+    const u64 e = (u64)blockIdx.x * TPB + threadIdx.x;
     if (e >= n) return;
     const Slot s = table[order[e]];
+    counts[e] = (int)s.count;
+    if (s.n > EMIT_SMALL) { big[atomicAdd(n_big, 1u)] = (u32)e; return; }
     const uint2* src = arena + s.off;
     const u32 dst = indptr[e];
-    for (u32 i = lane; i < s.n; i += 64) {
+    bool bad = false;
+    for (u32 i = 0; i < s.n; ++i) {
         const uint2 pi = src[i];
         u32 r = 0;
         for (u32 j = 0; j < s.n; ++j) r += src[j].x < pi.x;   // loci within a key are distinct
         indices[dst + r] = (int)pi.x;
         data[dst + r] = (int)pi.y;
+        bad |= pi.x >= n_loci || (pi.y >> n_haps) != 0u;
     }
-    if (lane == 0) counts[e] = (int)s.count;
+    if (bad) atomicOr(&ctr->err, ERR_RANGE);
+}
+__global__ __launch_bounds__(TPB) void k_emit_big(const Slot* table, const u32* order, const u32* big, u32 n_big,
+                                                   const uint2* arena, const u32* indptr, int* indices, int* data,
+                                                   u32 n_loci, u32 n_haps, Counters* ctr) {
+    const u32 b = (blockIdx.x * TPB + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    if (b >= n_big) return;
+    const u32 e = big[b];
+    const Slot s = table[order[e]];
+    const uint2* src = arena + s.off;
+    const u32 dst = indptr[e];
+    bool bad = false;
+    for (u32 i = lane; i < s.n; i += 64) {
+        const uint2 pi = src[i];
+        u32 r = 0;
+        for (u32 j = 0; j < s.n; ++j) r += src[j].x < pi.x;
+        indices[dst + r] = (int)pi.x;
+        data[dst + r] = (int)pi.y;
+        bad |= pi.x >= n_loci || (pi.y >> n_haps) != 0u;
+    }
+    if (bad) atomicOr(&ctr->err, ERR_RANGE);
 }
 
 // multisample: key = EC rank << 32 | meta (cell, file) of every read
@@ -1180,7 +1220,7 @@ int compact_table(ecb_handle* h) {
     POOL(h, P_CNT, d_n, 1);
     HIPCHK(h, hipMemsetAsync(d_n, 0, sizeof(u64), h->stream));
     POOL(h, P_LIST, h->list, h->n_ecs());
-    k_compact<<<(unsigned)std::min<u64>(4096, (h->cap + TPB - 1) / TPB), TPB, 0, h->stream>>>(h->table, h->cap, h->list, std::max<u64>(h->n_ecs(), 1), d_n);
+    k_compact<<<(unsigned)std::min<u64>(2048, (h->cap + 4 * TPB_COMPACT - 1) / (4 * TPB_COMPACT)), TPB_COMPACT, 0, h->stream>>>(h->table, h->cap, h->list, std::max<u64>(h->n_ecs(), 1), d_n);
     HIPCHK(h, hipMemcpyAsync(&h->n_list, d_n, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->n_list != h->n_ecs()) return fail(h, ECB_ERR_HIP, "internal: %llu occupied slots but %llu ECs created",
@@ -1395,8 +1435,22 @@ int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
         HIPCHK(h, hipMemcpyAsync(h->indptr + E, &nnz, 4, hipMemcpyHostToDevice, h->stream));
     }
     POOL(h, P_INDICES, h->indices, nnz); POOL(h, P_DATA, h->data, nnz);
-    k_emit<<<nblk(E * 64, TPB), TPB, 0, h->stream>>>(h->table, h->order, E, h->arena, h->indptr, h->indices, h->data, h->counts);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    {
+        u32 *big = nullptr, *d_nbig = nullptr, n_big = 0;
+        POOL(h, P_MS_X, big, E + 1);
+        d_nbig = big + E;
+        HIPCHK(h, hipMemsetAsync(d_nbig, 0, 4, h->stream));
+        k_emit_small<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->table, h->order, E, h->arena, h->indptr, h->indices, h->data,
+                                                           h->counts, h->cfg.n_loci, h->cfg.n_haplotypes, big, d_nbig, h->ctr);
+        HIPCHK(h, hipMemcpyAsync(&n_big, d_nbig, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (n_big)
+            k_emit_big<<<nblk((u64)n_big * 64, TPB), TPB, 0, h->stream>>>(h->table, h->order, big, n_big, h->arena, h->indptr,
+                                                                         h->indices, h->data, h->cfg.n_loci,
+                                                                         h->cfg.n_haplotypes, h->ctr);
+        rc = sync_counters(h);
+        if (rc != ECB_OK) return rc;
+    }
     h->sizes.n_ecs = E; h->sizes.nnz_a = nnz; h->sizes.n_samples = 1; h->sizes.nnz_n = E;
     if (h->cfg.flags & ECB_F_MULTISAMPLE) {
         // distinct (EC, cell, file) triples: sort the per-read keys, run-length encode
