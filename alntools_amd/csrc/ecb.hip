@@ -50,6 +50,7 @@ constexpr int MAXR = 512;            // reads finished per tile (more heads than
 constexpr u32 MAX_PROBE = 256;       // EC-table probes before a read is deferred to k_slow
 constexpr u32 PENDING = 0xFFFFFFFFu;
 constexpr u32 ARENA_CHUNK = 512;     // pairs a wave reserves from the key arena per global atomic
+constexpr u32 ARENA_FIRST = 128;     // pairs pre-assigned to every wave of a launch (no atomic at all for most waves)
 constexpr u32 MAX_LOCI = 1u << 27;   // (locus << 5 | hap) + 1 must fit 32 bits
 
 constexpr u32 ERR_CONTRACT = 1u;     // device error bits (Counters::err)
@@ -99,9 +100,10 @@ __device__ __forceinline__ void pair_hash(u32 locus, u32 mask, u32* h) {
     h[2] = fmix32((x << 13 | x >> 19) ^ (y + 0xC2B2AE3Du));
     h[3] = fmix32(~x + (y << 19 | y >> 13) * 0x27D4EB2Fu);
 }
+// the sums of fmix32 outputs are already uniformly spread: the table key is the pair of sums itself
 __device__ __forceinline__ void finish_hash(u64 s0, u64 s1, u32 n, u64& lo, u64& hi) {
-    lo = mix64(s0 + n) | 1ull;
-    hi = mix64(s1 ^ 0xA0761D6478BD642Full) | 1ull;
+    lo = (s0 + ((u64)n << 32) + n) | 1ull;
+    hi = s1 | 1ull;
 }
 __device__ __forceinline__ void pair_hash64(u32 locus, u32 mask, u64& a, u64& b) {
     u32 h[4];
@@ -168,6 +170,7 @@ struct alignas(16) WaveLds {
     u32 seg[WMAXR + 2];              // per read finished in this tile: tile-relative start | end << 16
 };
 __device__ __forceinline__ u32 tslot(u32 rec) { return rec + (rec >> 1); }   // first table slot of a read starting at `rec`
+__device__ __forceinline__ u32 unslot(u32 t) { const u32 m = (t * 683u) >> 11; return 2u * m + (t - 3u * m); }   // inverse, t < 1024
 
 struct StreamArgs {
     const u32* rid; const u32* loc; const u32* hf;
@@ -176,10 +179,12 @@ struct StreamArgs {
     u32 n_loci, n_haps;
     Slot* table; u64 cap_mask;
     uint2* arena; u64 arena_cap;
+    u64 arena_first;                 // wave w owns arena[arena_first + w * ARENA_FIRST, + ARENA_FIRST) without asking
     Counters* ctr;
     u32* read_slot;                  // slot of every read (indexed by read_id)
     u64* queue; u64 queue_cap;       // head record index of deferred reads
     u64* resume;                     // per wave {next record to process, records counted up to}
+    u32* wave_counts;                // per wave {records offered, records valid, ECs created}: summed by k_sum_counts
     u32 ablate;                      // profiling only (env ECB_ABLATE): 1 = stop after (a), 2 = after (b), 4 = no EC table
 };
 
@@ -192,6 +197,7 @@ __device__ __forceinline__ u32 wave_sum(u32 v) {
     for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
     return v;
 }
+__device__ __forceinline__ int clamp04(int x, int, int) { return min(max(x, 0), 4); }   // v_med3_i32
 // bits [lo, hi) of a 4-record group, lo/hi given relative to the group's first record
 __device__ __forceinline__ u32 group_mask(int lo, int hi) {
     lo = max(lo, 0); hi = min(hi, 4);
@@ -223,7 +229,7 @@ __device__ __forceinline__ void load_tile(const StreamArgs& A, u64 tb, u64 te, u
     }
 }
 
-__global__ __launch_bounds__(TPB) void k_stream(StreamArgs A) {
+__global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
     __shared__ WaveLds wl[NWAVE];
     const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     WaveLds& L = wl[w];
@@ -240,8 +246,8 @@ __global__ __launch_bounds__(TPB) void k_stream(StreamArgs A) {
     load_tile(A, p & ~(u64)3, min((p & ~(u64)3) + (u64)WT, A.n), lane, R);
     u32 parked = __hip_atomic_load(&A.ctr->full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     u32 bad = 0;
-    u64 chunk_at = 0;                 // this wave's reservation in the key arena
-    u32 chunk_left = 0, my_new = 0;
+    u64 chunk_at = A.arena_first + wid * ARENA_FIRST;   // this wave's reservation in the key arena (first one pre-assigned)
+    u32 chunk_left = A.arena_first + (wid + 1) * ARENA_FIRST <= A.arena_cap ? ARENA_FIRST : 0u, my_new = 0;
 
     while (p < c1) {
         if (parked) break;            // the EC table filled up somewhere: the host grows it and relaunches
@@ -258,59 +264,62 @@ __global__ __launch_bounds__(TPB) void k_stream(StreamArgs A) {
             L.acc[lane][0] = 0; L.acc[lane][1] = 0; L.npair[lane] = 0;
         }
         // ---- (a) filter, heads -------------------------------------------------------------------
-        u32 r_key[8], r_bit[8], r_rl[8];          // locus, haplotype bit, read index within the tile
+        // Written with integer bit arithmetic throughout: every instruction costs a 4-cycle issue slot, and
+        // compare -> mask -> select chains were a third of this kernel's instruction count.
+        u32 r_key[8], r_bit[8], r_rl[8];          // locus + 1, haplotype bit, read index within the tile
         u32 m_ok = 0, m_head = 0, m_own = 0;       // bit k: valid & in range / head / head of a read we own
         {
             const u32 up0 = __shfl_up(R.rr[3], 1), up1 = __shfl_up(R.rr[7], 1), last0 = __shfl(R.rr[3], 63);
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 const int i0 = g * (WT / 2) + 4 * (int)lane;
-                const u32 in4 = group_mask(p_rel - i0, te_rel - i0);
-                const u32 own4 = group_mask(p_rel - i0, c1_rel - i0);
-                const u32 cnt4 = group_mask(cnt_lo - i0, cnt_hi - i0);
+                const u32 lo_in = (1u << clamp04(p_rel - i0, 0, 4)) - 1u;        // records before p
+                const u32 in4 = ((1u << clamp04(te_rel - i0, 0, 4)) - 1u) & ~lo_in;
+                const u32 own4 = ((1u << clamp04(c1_rel - i0, 0, 4)) - 1u) & ~lo_in;
+                const u32 cnt4 = ((1u << clamp04(cnt_hi - i0, 0, 4)) - 1u) &
+                                 ~((1u << clamp04(cnt_lo - i0, 0, 4)) - 1u);
                 u32 prev = g == 0 ? (lane == 0 ? base - 1u : up0) : (lane == 0 ? last0 : up1);
-                u32 ok4 = 0, head4 = 0;
+                u32 ok4 = 0, head4 = 0, big4 = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int k = 4 * g + j;
-                    const u32 f = R.hh[k];
-                    const bool ok = ((f & 0x4u) == 0u) & (((f & 0x1u) == 0u) | ((f & 0x3082u) == 0x2u));
-                    const u32 hap = (f >> ECB_HAP_SHIFT) & 0xFFu;
+                    const u32 f = R.hh[k], nf = ~f;
+                    // record filter (bam_utils.py:264-270): not unmapped, and if paired: read1, proper, mate on the same
+                    // reference, next_pos >= 0  <=>  ((f ^ 2) & 0x3082) == 0
+                    const u32 pair_ok = ((((f ^ 0x2u) & 0x3082u) - 1u) >> 31);
+                    const u32 ok = (nf >> 2) & (nf | pair_ok) & 1u;
                     const u32 step = R.rr[k] - prev;
                     prev = R.rr[k];
                     r_rl[k] = R.rr[k] - base;
-                    r_key[k] = R.ll[k]; r_bit[k] = 1u << (hap & 31u);
-                    const bool inr = (in4 >> j) & 1u;
-                    if (inr & ((step > 1u) | ((step == 1u) & !ok))) bad |= ERR_CONTRACT;
-                    ok4 |= (u32)ok << j;
-                    head4 |= (u32)(step == 1u) << j;
+                    r_key[k] = R.ll[k] + 1u;
+                    r_bit[k] = 1u << ((f >> ECB_HAP_SHIFT) & 31u);
+                    ok4 |= ok << j;
+                    head4 |= (step & 1u) << j;
+                    big4 |= min(step >> 1, 1u) << j;                 // the run counter may only step by 0 or 1
                 }
                 ok4 &= in4; head4 &= in4;
+                bad |= ((big4 & in4) | (head4 & ~ok4)) ? ERR_CONTRACT : 0u;   // ... and only on a valid record
                 my_all += __popc(cnt4); my_valid += __popc(cnt4 & ok4);
                 m_ok |= ok4 << (4 * g); m_head |= head4 << (4 * g); m_own |= (head4 & own4) << (4 * g);
             }
         }
         if (__ballot(bad != 0u)) break;            // never index LDS with a broken run counter
-#if V_BALLOT_SUMS
-        u32 nr = 0, nown = 0;                                    // heads in [p, te) / in [p, c1): ours
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            nr += (u32)__popcll(__ballot(m_head >> k & 1u));
-            nown += (u32)__popcll(__ballot(m_own >> k & 1u));
-        }
-#else
-        const u32 nr = wave_sum(__popc(m_head)), nown = wave_sum(__popc(m_own));
-#endif
-        {   // a head at position x starts its read and ends the one before it
+        const u32 sums = wave_sum(__popc(m_head) | (__popc(m_own) << 16));
+        const u32 nr = sums & 0xFFFFu, nown = sums >> 16;         // heads in [p, te) / in [p, c1): ours
+        {   // a head at record x starts its read and ends the one before it; stored as table-slot offsets
             unsigned short* sh = reinterpret_cast<unsigned short*>(L.seg);
 #pragma unroll
             for (int k = 0; k < 8; ++k)
                 if ((m_head >> k & 1u) && r_rl[k] <= (u32)WMAXR) {
-                    const unsigned short x = (unsigned short)(4u * lane + (k & 3) + (k >> 2) * (WT / 2));
+                    const unsigned short x = (unsigned short)tslot(4u * lane + (k & 3) + (k >> 2) * (WT / 2));
                     sh[2 * r_rl[k]] = x;
                     if (r_rl[k]) sh[2 * r_rl[k] - 1] = x;
                 }
-            if (lane == 0 && nr <= (u32)WMAXR) { if (nr) sh[2 * nr - 1] = (unsigned short)te_rel; sh[2 * nr] = (unsigned short)te_rel; }
+            if (lane == 0 && nr <= (u32)WMAXR) {
+                const unsigned short x = (unsigned short)tslot((u32)te_rel);
+                if (nr) sh[2 * nr - 1] = x;
+                sh[2 * nr] = x;
+            }
         }
         wave_sync();
         const bool last_complete = (te == A.n);                  // batches end on a read boundary
@@ -321,7 +330,7 @@ __global__ __launch_bounds__(TPB) void k_stream(StreamArgs A) {
         u32 base_next = base + nr;
         bool giant = false;
         if (!done && nproc < nr) {
-            const u64 h = tb + (L.seg[nproc] & 0xFFFFu);         // first read not finished here
+            const u64 h = tb + unslot(L.seg[nproc] & 0xFFFFu);   // first read not finished here
             if (h == p) giant = true;                            // one read fills the whole tile: k_slow
             else { p_next = h; base_next = base + nproc; }
         }
@@ -339,48 +348,54 @@ __global__ __launch_bounds__(TPB) void k_stream(StreamArgs A) {
         }
 
         // ---- (b) per-read {locus -> haplotype mask} tables in LDS ------------------------------------
-        // Runs of records with the same (read, locus) inside a lane are merged in registers first (the
-        // haplotypes of a locus usually arrive together); what remains is staged so that the LDS round
-        // trips overlap: segment reads, CAS on the locus, OR of the bits.  The lane whose CAS created an
-        // entry hashes it once all masks are final.
-        u32 act = 0, n_ent = 0;
+        // Staged so that the 8 records' LDS round trips overlap: segment reads, CAS on the locus, OR of the bit.
+        // A lane whose CAS created an entry queues it; every entry is hashed once when all masks are final.
+        u32 n_ent = 0;
         if (!(A.ablate & 1u)) {
-            u32 q[8], old[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) act |= (u32)((m_ok >> k & 1u) && r_rl[k] < nproc) << k;
+            u32 q[8], old[8], act = 0, coll = 0;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const u32 sg = L.seg[(act >> k & 1u) ? r_rl[k] : 0u];
-                const u32 s2 = tslot(sg & 0xFFFFu), len = tslot(sg >> 16) - s2;
+                const u32 on = (m_ok >> k) & (u32)(r_rl[k] < nproc) & 1u;
+                act |= on << k;
+                const u32 sg = L.seg[on ? r_rl[k] : 0u];
+                const u32 s2 = sg & 0xFFFFu, len = (sg >> 16) - s2;
                 q[k] = s2 + (__umul24(__umul24(r_key[k] & 0xFFFFFFu, 0x9E3779u) >> 8 & 0xFFFFu, len) >> 16);
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                old[k] = 0xFFFFFFFFu;
-                if (act >> k & 1u) old[k] = atomicCAS(&L.tkey[q[k]], 0u, r_key[k] + 1u);
-            }
+            for (int k = 0; k < 8; ++k)
+                if (act >> k & 1u) old[k] = atomicCAS(&L.tkey[q[k]], 0u, r_key[k]);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                bool made = false;
-                if (act >> k & 1u) {
-                    const u32 key = r_key[k] + 1u;
-                    u32 o = old[k];
-                    if (o != 0u && o != key) {                       // slot taken by another locus: probe on
-                        const u32 sg = L.seg[r_rl[k]];
-                        const u32 s2 = tslot(sg & 0xFFFFu), e2 = tslot(sg >> 16);
-                        do {
-                            if (++q[k] == e2) q[k] = s2;
-                            o = atomicCAS(&L.tkey[q[k]], 0u, key);
-                        } while (o != 0u && o != key);
-                    }
-                    made = (o == 0u);                                // this lane created the (read, locus) entry
-                    atomicOr(&L.tmask[q[k]], r_bit[k]);              // duplicate (read, target) records vanish here: bam_utils.py:322-325
-                }
-                // entries are queued so that each is hashed once, by any lane, when its mask is final
+                const bool on = act >> k & 1u;
+                const bool made = on && old[k] == 0u;                // this lane created the (read, locus) entry
+                const bool hit = made || (on && old[k] == r_key[k]);
+                coll |= (u32)(on && !hit) << k;
+                if (hit) atomicOr(&L.tmask[q[k]], r_bit[k]);         // duplicate (read, target) records vanish here: bam_utils.py:322-325
                 const u64 mm = __ballot(made);
                 if (made) L.ent[n_ent + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u))] =
                     (unsigned short)(q[k] | (r_rl[k] << 10));
                 n_ent += (u32)__popcll(mm);
+            }
+            if (__ballot(coll != 0u)) {                              // slot taken by another locus of the read: probe on (rare)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    bool made = false;
+                    if (coll >> k & 1u) {
+                        const u32 sg = L.seg[r_rl[k]];
+                        const u32 s2 = sg & 0xFFFFu, e2 = sg >> 16;
+                        u32 o;
+                        do {
+                            if (++q[k] == e2) q[k] = s2;
+                            o = atomicCAS(&L.tkey[q[k]], 0u, r_key[k]);
+                        } while (o != 0u && o != r_key[k]);
+                        made = (o == 0u);
+                        atomicOr(&L.tmask[q[k]], r_bit[k]);
+                    }
+                    const u64 mm = __ballot(made);
+                    if (made) L.ent[n_ent + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u))] =
+                        (unsigned short)(q[k] | (r_rl[k] << 10));
+                    n_ent += (u32)__popcll(mm);
+                }
             }
         }
         wave_sync();
@@ -410,7 +425,7 @@ __global__ __launch_bounds__(TPB) void k_stream(StreamArgs A) {
                     if (slot == ~0ull) {                            // table too full here: defer the read, park
                         atomicExch(&A.ctr->full, 1u);
                         const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
-                        if (qi < A.queue_cap) A.queue[qi] = tb + (L.seg[lane] & 0xFFFFu); else atomicOr(&A.ctr->err, ERR_QUEUE);
+                        if (qi < A.queue_cap) A.queue[qi] = tb + unslot(L.seg[lane] & 0xFFFFu); else atomicOr(&A.ctr->err, ERR_QUEUE);
                     } else {
                         A.read_slot[rd] = (u32)slot;
                     }
@@ -432,7 +447,7 @@ __global__ __launch_bounds__(TPB) void k_stream(StreamArgs A) {
                 if (created && !(bad & ERR_ARENA)) {
                     u64 off = chunk_at + (incl - want);
                     A.table[slot].off = (u32)off; A.table[slot].n = np;
-                    const u32 b2 = tslot(L.seg[lane] & 0xFFFFu), f2 = tslot(L.seg[lane] >> 16);
+                    const u32 b2 = L.seg[lane] & 0xFFFFu, f2 = L.seg[lane] >> 16;
                     for (u32 t = b2; t < f2; ++t) {
                         const u32 kk = L.tkey[t];
                         if (kk) A.arena[off++] = make_uint2(kk - 1u, L.tmask[t]);
@@ -451,9 +466,22 @@ __global__ __launch_bounds__(TPB) void k_stream(StreamArgs A) {
     if (lane == 0) { A.resume[2 * wid] = p; A.resume[2 * wid + 1] = counted; }
     // records offered / valid: one atomic pair per wave
     const u32 wa = wave_sum(my_all), wv = wave_sum(my_valid);
-    if (lane == 0) {
-        atomicAdd(&A.ctr->all, (u64)wa); atomicAdd(&A.ctr->valid, (u64)wv);
-        if (my_new) atomicAdd(&A.ctr->n_ecs, (u64)my_new);
+    // per-wave totals go to their own words: thousands of waves adding to three shared counters serialise (~50 ns each)
+    if (lane == 0) { A.wave_counts[3 * wid] = wa; A.wave_counts[3 * wid + 1] = wv; A.wave_counts[3 * wid + 2] = my_new; }
+}
+
+__global__ __launch_bounds__(1024) void k_sum_counts(const u32* wave_counts, u64 waves, Counters* ctr) {
+    __shared__ u64 s[3][16];
+    u64 a = 0, v = 0, e = 0;
+    for (u64 i = threadIdx.x; i < waves; i += 1024) { a += wave_counts[3 * i]; v += wave_counts[3 * i + 1]; e += wave_counts[3 * i + 2]; }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { a += __shfl_xor(a, d); v += __shfl_xor(v, d); e += __shfl_xor(e, d); }
+    if ((threadIdx.x & 63u) == 0) { s[0][threadIdx.x >> 6] = a; s[1][threadIdx.x >> 6] = v; s[2][threadIdx.x >> 6] = e; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = v = e = 0;
+        for (int k = 0; k < 16; ++k) { a += s[0][k]; v += s[1][k]; e += s[2][k]; }
+        ctr->all += a; ctr->valid += v; ctr->n_ecs += e;
     }
 }
 
@@ -941,7 +969,7 @@ struct ecb_handle {
 
     // device scratch reused across calls (grown on demand, freed at destroy)
     enum { P_RESUME, P_SUMS, P_HIST, P_OFFS, P_PAIRS, P_CNT, P_LIST, P_BITMAP, P_WPOP, P_WPREFIX, P_ROWLEN, P_ORDER,
-           P_RANK, P_INDPTR, P_COUNTS, P_INDICES, P_DATA, P_MS_KEYS, P_MS_KEYS2, P_MS_VALS, P_MS_VALS2, P_MS_TMP,
+           P_WCOUNTS, P_RANK, P_INDPTR, P_COUNTS, P_INDICES, P_DATA, P_MS_KEYS, P_MS_KEYS2, P_MS_VALS, P_MS_VALS2, P_MS_TMP,
            P_MS_FLAG, P_MS_POS, P_MS_OKEY, P_MS_OFIRST, P_MS_OSTART, P_MS_X, P_N };
     void* pool[P_N] = {}; u64 pool_bytes[P_N] = {};
 
@@ -1077,8 +1105,12 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     while (h->n_ecs() * 2 > h->cap) { rc = grow_table(h, h->cap * 4); if (rc != ECB_OK) return rc; }
     int cus = 256;
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
-    // one contiguous slice per wave; enough waves to fill every CU a few times over
-    u64 waves = std::min<u64>((u64)cus * 5 * NWAVE, (n + 2 * WT - 1) / (2 * WT));
+    // One contiguous slice per wave; ECB_ROUNDS x as many waves as are resident at once (a launch of 1.25 rounds costs 2).
+    int bpc = 4;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_stream, TPB, 0);
+    const u64 rounds = getenv("ECB_ROUNDS") ? std::max(1, atoi(getenv("ECB_ROUNDS"))) : 4;
+    u64 waves = (u64)cus * std::max(bpc, 1) * NWAVE * rounds;
+    waves = std::min<u64>(waves, (n + 2 * WT - 1) / (2 * WT));
     waves = std::max<u64>(waves, 1);
     u64 chunk = (n + waves - 1) / waves;
     chunk = (chunk + 3) & ~(u64)3;
@@ -1102,16 +1134,27 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     if (h->rng_min)
         k_ranges<<<(unsigned)std::min<u64>(4096, (n + TPB - 1) / TPB), TPB, 0, h->stream>>>(
             d_loc, d_hf, d_pos, n, h->cfg.n_loci, h->cfg.n_haplotypes, h->rng_min, h->rng_max);
+    u32* d_wcounts = nullptr;
+    POOL(h, P_WCOUNTS, d_wcounts, 3 * waves);
     StreamArgs a{d_rid, d_loc, d_hf, n, chunk, h->prev_rid, h->cfg.n_loci, h->cfg.n_haplotypes,
-                 h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr, h->read_slot, h->queue, h->queue_cap, d_resume,
+                 h->table, h->cap - 1, h->arena, h->arena_cap, 0, h->ctr, h->read_slot, h->queue, h->queue_cap, d_resume, d_wcounts,
                  getenv("ECB_ABLATE") ? (u32)atoi(getenv("ECB_ABLATE")) : 0u};
     for (;;) {
         HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));   // per launch
         HIPCHK(h, hipMemsetAsync(&h->ctr->full, 0, sizeof(u32), h->stream));
         a.table = h->table; a.cap_mask = h->cap - 1;
+        {   // every wave of this launch gets ARENA_FIRST pairs of the key arena up front
+            rc = sync_counters(h);
+            if (rc != ECB_OK) break;
+            a.arena_first = h->hctr.arena_top;
+            const u64 top = std::min<u64>(a.arena_first + waves * ARENA_FIRST, h->arena_cap);
+            hipMemcpyAsync(&h->ctr->arena_top, &top, sizeof(u64), hipMemcpyHostToDevice, h->stream);
+        }
+        HIPCHK(h, hipMemsetAsync(d_wcounts, 0, 3 * waves * sizeof(u32), h->stream));
         if (h->prof) hipEventRecord(h->ev0, h->stream);
         k_stream<<<(unsigned)blocks, TPB, 0, h->stream>>>(a);
         if (h->prof) hipEventRecord(h->ev1, h->stream);
+        k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, waves, h->ctr);
         HIPCHK(h, hipGetLastError());
         rc = sync_counters(h);
         if (h->prof) {
