@@ -167,7 +167,7 @@ struct alignas(16) WaveLds {
     u64 acc[WMAXR][2];               // per read: set-hash sums (2 x 64 bits)
     unsigned short ent[WT];          // table entries created in this tile: slot | read << 10
     unsigned short npair[WMAXR];     // per read: number of (locus, mask) pairs
-    u32 seg[WMAXR + 2];              // per read finished in this tile: tile-relative start | end << 16
+    u32 seg[WMAXR + 3];              // seg[rl + 1] = first table slot of read rl | end slot << 16 (seg[0] absorbs a store)
 };
 __device__ __forceinline__ u32 tslot(u32 rec) { return rec + (rec >> 1); }   // first table slot of a read starting at `rec`
 __device__ __forceinline__ u32 unslot(u32 t) { const u32 m = (t * 683u) >> 11; return 2u * m + (t - 3u * m); }   // inverse, t < 1024
@@ -251,6 +251,8 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
 
     while (p < c1) {
         if (parked) break;            // the EC table filled up somewhere: the host grows it and relaunches
+        p = ((u64)__builtin_amdgcn_readfirstlane((u32)(p >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)p);
+        base = __builtin_amdgcn_readfirstlane(base);
         const u64 tb = p & ~(u64)3;
         const u64 te = min(tb + (u64)WT, A.n);
         // tile-relative bounds (all below 2^31)
@@ -311,14 +313,15 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
 #pragma unroll
             for (int k = 0; k < 8; ++k)
                 if ((m_head >> k & 1u) && r_rl[k] <= (u32)WMAXR) {
-                    const unsigned short x = (unsigned short)tslot(4u * lane + (k & 3) + (k >> 2) * (WT / 2));
-                    sh[2 * r_rl[k]] = x;
-                    if (r_rl[k]) sh[2 * r_rl[k] - 1] = x;
+                    // tslot(4*lane + c) = 6*lane + tslot(c): one add per record
+                    const unsigned short x = (unsigned short)(6u * lane + tslot((k & 3) + (k >> 2) * (WT / 2)));
+                    sh[2 * r_rl[k] + 2] = x;                           // start of read rl   (seg is indexed rl + 1)
+                    sh[2 * r_rl[k] + 1] = x;                           // end of read rl - 1 (lands in the unused seg[0] for rl = 0)
                 }
             if (lane == 0 && nr <= (u32)WMAXR) {
                 const unsigned short x = (unsigned short)tslot((u32)te_rel);
-                if (nr) sh[2 * nr - 1] = x;
-                sh[2 * nr] = x;
+                sh[2 * nr + 1] = x;
+                sh[2 * nr + 2] = x;
             }
         }
         wave_sync();
@@ -330,7 +333,8 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
         u32 base_next = base + nr;
         bool giant = false;
         if (!done && nproc < nr) {
-            const u64 h = tb + unslot(L.seg[nproc] & 0xFFFFu);   // first read not finished here
+            // (readfirstlane: the value is wave-uniform; saying so keeps the tile addressing in scalar registers)
+            const u64 h = tb + unslot(__builtin_amdgcn_readfirstlane(L.seg[nproc + 1]) & 0xFFFFu);   // first read not finished here
             if (h == p) giant = true;                            // one read fills the whole tile: k_slow
             else { p_next = h; base_next = base + nproc; }
         }
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
             for (int k = 0; k < 8; ++k) {
                 const u32 on = (m_ok >> k) & (u32)(r_rl[k] < nproc) & 1u;
                 act |= on << k;
-                const u32 sg = L.seg[on ? r_rl[k] : 0u];
+                const u32 sg = L.seg[on ? r_rl[k] + 1u : 0u];
                 const u32 s2 = sg & 0xFFFFu, len = (sg >> 16) - s2;
                 q[k] = s2 + (__umul24(__umul24(r_key[k] & 0xFFFFFFu, 0x9E3779u) >> 8 & 0xFFFFu, len) >> 16);
             }
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
                 for (int k = 0; k < 8; ++k) {
                     bool made = false;
                     if (coll >> k & 1u) {
-                        const u32 sg = L.seg[r_rl[k]];
+                        const u32 sg = L.seg[r_rl[k] + 1u];
                         const u32 s2 = sg & 0xFFFFu, e2 = sg >> 16;
                         u32 o;
                         do {
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
                     if (slot == ~0ull) {                            // table too full here: defer the read, park
                         atomicExch(&A.ctr->full, 1u);
                         const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
-                        if (qi < A.queue_cap) A.queue[qi] = tb + unslot(L.seg[lane] & 0xFFFFu); else atomicOr(&A.ctr->err, ERR_QUEUE);
+                        if (qi < A.queue_cap) A.queue[qi] = tb + unslot(L.seg[lane + 1] & 0xFFFFu); else atomicOr(&A.ctr->err, ERR_QUEUE);
                     } else {
                         A.read_slot[rd] = (u32)slot;
                     }
@@ -447,7 +451,7 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
                 if (created && !(bad & ERR_ARENA)) {
                     u64 off = chunk_at + (incl - want);
                     A.table[slot].off = (u32)off; A.table[slot].n = np;
-                    const u32 b2 = L.seg[lane] & 0xFFFFu, f2 = L.seg[lane] >> 16;
+                    const u32 b2 = L.seg[lane + 1] & 0xFFFFu, f2 = L.seg[lane + 1] >> 16;
                     for (u32 t = b2; t < f2; ++t) {
                         const u32 kk = L.tkey[t];
                         if (kk) A.arena[off++] = make_uint2(kk - 1u, L.tmask[t]);
