@@ -251,8 +251,8 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
 
     while (p < c1) {
         if (parked) break;            // the EC table filled up somewhere: the host grows it and relaunches
-        p = ((u64)__builtin_amdgcn_readfirstlane((u32)(p >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)p);
-        base = __builtin_amdgcn_readfirstlane(base);
+        p = ((u64)(u32)__builtin_amdgcn_readfirstlane((u32)(p >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((u32)p);   // (the builtin returns int: no sign extension)
+        base = (u32)__builtin_amdgcn_readfirstlane(base);
         const u64 tb = p & ~(u64)3;
         const u64 te = min(tb + (u64)WT, A.n);
         // tile-relative bounds (all below 2^31)
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
         bool giant = false;
         if (!done && nproc < nr) {
             // (readfirstlane: the value is wave-uniform; saying so keeps the tile addressing in scalar registers)
-            const u64 h = tb + unslot(__builtin_amdgcn_readfirstlane(L.seg[nproc + 1]) & 0xFFFFu);   // first read not finished here
+            const u64 h = tb + unslot((u32)__builtin_amdgcn_readfirstlane(L.seg[nproc + 1]) & 0xFFFFu);   // first read not finished here
             if (h == p) giant = true;                            // one read fills the whole tile: k_slow
             else { p_next = h; base_next = base + nproc; }
         }
@@ -534,9 +534,19 @@ __global__ __launch_bounds__(TPB) void k_part_scatter(const u32* read_slot, u64 
     const u64 r0 = g * per, r1 = min(r0 + per, n_reads);
     for (u32 b = threadIdx.x; b < n_buckets; b += TPB) sh[b] = offs[(u64)b * G + g];
     __syncthreads();
-    for (u64 r = r0 + threadIdx.x; r < r1; r += TPB) {
-        const u32 s = read_slot[r];
-        if (s != PENDING) pairs[atomicAdd(&sh[s >> BIN_BITS], 1u)] = make_uint2(s, (u32)r);
+    // four reads per thread and trip: their LDS cursor bumps are independent, so the round trips overlap
+    for (u64 rb = r0; rb < r1; rb += 4 * TPB) {
+        u32 s[4], pos[4];
+        u64 r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            r[k] = rb + (u64)k * TPB + threadIdx.x;
+            s[k] = r[k] < r1 ? read_slot[r[k]] : PENDING;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (s[k] != PENDING) pos[k] = atomicAdd(&sh[s[k] >> BIN_BITS], 1u);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (s[k] != PENDING) pairs[pos[k]] = make_uint2(s[k], (u32)r[k]);
     }
 }
 
@@ -548,23 +558,32 @@ __global__ __launch_bounds__(TPB_COUNT) void k_count_bins(const uint2* pairs, co
     const u32 start = offs[(u64)b * G], end = (b + 1 < n_buckets) ? offs[(u64)(b + 1) * G] : total;
     for (u32 q = threadIdx.x; q < N_BINS; q += TPB_COUNT) { cnt[q] = 0; fst[q] = 0xFFFFFFFFu; }
     __syncthreads();
-    for (u32 i0 = start; i0 < end; i0 += TPB_COUNT) {
-        const u32 i = i0 + threadIdx.x;
-        const bool have = i < end;
-        uint2 pr = have ? pairs[i] : make_uint2(0, 0xFFFFFFFFu);
-        const u32 bin = pr.x & (N_BINS - 1);
-        // a hot EC fills most lanes of a wave: add it once per wave, the rest go one by one
-        const u32 v = __shfl(bin, __ffsll((long long)__ballot(have)) - 1);
-        const bool same = have && bin == v;
-        const u64 m = __ballot(same);
-        if (__popcll(m) >= 8) {
-            u32 mn = same ? pr.y : 0xFFFFFFFFu;
+    for (u32 i0 = start; i0 < end; i0 += 4 * TPB_COUNT) {
+        uint2 pr[4];
 #pragma unroll
-            for (int d = 32; d > 0; d >>= 1) mn = min(mn, (u32)__shfl_xor(mn, d));
-            if (lane == (u32)(__ffsll((long long)m) - 1)) { atomicAdd(&cnt[v], (u32)__popcll(m)); atomicMin(&fst[v], mn); }
-            if (have && !same) { atomicAdd(&cnt[bin], 1u); atomicMin(&fst[bin], pr.y); }
-        } else if (have) {
-            atomicAdd(&cnt[bin], 1u); atomicMin(&fst[bin], pr.y);
+        for (int k = 0; k < 4; ++k) {                       // four independent loads in flight per thread
+            const u32 i = i0 + k * TPB_COUNT + threadIdx.x;
+            pr[k] = i < end ? pairs[i] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool have = pr[k].x != 0xFFFFFFFFu;
+            const u32 bin = pr[k].x & (N_BINS - 1);
+            const u64 hm = __ballot(have);
+            if (!hm) continue;
+            // a hot EC fills most lanes of a wave: add it once per wave, the rest go one by one
+            const u32 v = __shfl(bin, __ffsll((long long)hm) - 1);
+            const bool same = have && bin == v;
+            const u64 m = __ballot(same);
+            if (__popcll(m) >= 8) {
+                u32 mn = same ? pr[k].y : 0xFFFFFFFFu;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) mn = min(mn, (u32)__shfl_xor(mn, d));
+                if (lane == (u32)(__ffsll((long long)m) - 1)) { atomicAdd(&cnt[v], (u32)__popcll(m)); atomicMin(&fst[v], mn); }
+                if (have && !same) { atomicAdd(&cnt[bin], 1u); atomicMin(&fst[bin], pr[k].y); }
+            } else if (have) {
+                atomicAdd(&cnt[bin], 1u); atomicMin(&fst[bin], pr[k].y);
+            }
         }
     }
     __syncthreads();
@@ -950,6 +969,7 @@ struct ecb_handle {
     uint2* arena = nullptr; u64 arena_cap = 0;
     Counters* ctr = nullptr;
     Counters hctr{};                  // last read-back
+    u64 arena_top_host = 0;           // staging word for setting Counters::arena_top
     u32* read_slot = nullptr; u64 read_slot_cap = 0;
     u32* meta = nullptr; u64 meta_cap = 0, meta_hi = 0;   // multisample: cell | file << 22 per read
     u64 n_triples = 0; u64* ms_okey = nullptr; u32 *ms_ofirst = nullptr, *ms_ostart = nullptr;
@@ -1151,8 +1171,8 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
             rc = sync_counters(h);
             if (rc != ECB_OK) break;
             a.arena_first = h->hctr.arena_top;
-            const u64 top = std::min<u64>(a.arena_first + waves * ARENA_FIRST, h->arena_cap);
-            hipMemcpyAsync(&h->ctr->arena_top, &top, sizeof(u64), hipMemcpyHostToDevice, h->stream);
+            h->arena_top_host = std::min<u64>(a.arena_first + waves * ARENA_FIRST, h->arena_cap);   // (outlives the async copy)
+            hipMemcpyAsync(&h->ctr->arena_top, &h->arena_top_host, sizeof(u64), hipMemcpyHostToDevice, h->stream);
         }
         HIPCHK(h, hipMemsetAsync(d_wcounts, 0, 3 * waves * sizeof(u32), h->stream));
         if (h->prof) hipEventRecord(h->ev0, h->stream);

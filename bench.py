@@ -33,6 +33,8 @@ WORKLOADS = {
     "c2": (50_000_000, 40_000, 8, False, "BASELINE config 2: 50M single-end reads, 8 hap x 40k transcripts, bam2ec path"),
     "c1": (10_000, 1_000, 2, False, "BASELINE config 1: 10k single-end reads, 2 hap x 1k transcripts"),
     "tiny": (400_000, 4_000, 8, True, "smoke-sized paired-end workload"),
+    "c3h": (50_000_000, 80_000, 8, True, "half of config 3 (debug)"),
+    "c2x": (150_000_000, 40_000, 8, False, "3x config 2 (debug: > 2^31 records)"),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 

