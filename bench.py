@@ -121,7 +121,8 @@ def main():
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
 
-    ec_cap = 1 << int(os.environ.get("ECB_EC_CAP_LOG2", "22"))
+    # EC-table slots: sized for the workload's EC count (c3: 3.7 M ECs) so that the timed steps do not grow it
+    ec_cap = 1 << int(os.environ.get("ECB_EC_CAP_LOG2", "24" if args.workload in ("c3", "c3h") else "22"))
     b = ecb.EcBuilder(T, H, device=local, ec_capacity=ec_cap, arena_capacity=1 << 26)
     eng = ecdist.GpuEngine(b, device)
     root_eng = None
