@@ -780,20 +780,37 @@ __global__ void k_export_entries(const Slot* table, const u32* list, u64 n, Slot
     out[e] = s;
 }
 
-__global__ void k_merge(const Slot* ent, u64 n, const uint2* pairs, u64 n_pairs, Slot* table, u64 cap_mask,
-                        uint2* arena, u64 arena_cap, Counters* ctr) {
-    const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const Slot s = ent[e];
-    if ((u64)s.off + s.n > n_pairs) { atomicOr(&ctr->err, ERR_CONTRACT); return; }
+__global__ __launch_bounds__(TPB) void k_merge(const Slot* ent, u64 n, const uint2* pairs, u64 n_pairs, Slot* table, u64 cap_mask,
+                                               uint2* arena, u64 arena_cap, Counters* ctr) {
+    const u64 e = blockIdx.x * (u64)TPB + threadIdx.x;
+    const u32 lane = threadIdx.x & 63u;
+    const bool on = e < n;
+    Slot s{};
+    if (on) s = ent[e];
+    bool ok = on && (u64)s.off + s.n <= n_pairs;
+    if (on && !ok) atomicOr(&ctr->err, ERR_CONTRACT);
     bool created = false;
-    const u64 j = table_find_or_insert(table, cap_mask, s.lo, s.hi, &created);
-    if (j == ~0ull) { atomicAdd(&ctr->n_queue, 1ull); return; }   // host sizes the table so this cannot happen
-    atomicAdd(&table[j].count, s.count);                           // one pair of atomics per merged EC, not per read
-    atomicMax(&table[j].first_inv, s.first_inv);
+    u64 j = ~0ull;
+    if (ok) {
+        j = table_find_or_insert(table, cap_mask, s.lo, s.hi, &created);
+        if (j == ~0ull) atomicAdd(&ctr->n_queue, 1ull);            // host sizes the table so this cannot happen
+        else {
+            atomicAdd(&table[j].count, s.count);                     // one pair of atomics per merged EC, not per read
+            atomicMax(&table[j].first_inv, s.first_inv);
+        }
+    }
+    // key arena and EC count: one atomic each per wave, not per created EC
+    const u32 want = created ? s.n : 0u;
+    u32 incl = want;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(incl, d); if (lane >= (u32)d) incl += t; }
+    const u32 total = __shfl(incl, 63);
+    const u32 n_new = (u32)__popcll(__ballot(created));
+    u64 at = 0;
+    if (lane == 0 && n_new) { at = atomicAdd(&ctr->arena_top, (u64)total); atomicAdd(&ctr->n_ecs, (u64)n_new); }
+    at = __shfl(at, 0);
     if (created) {
-        const u64 off = atomicAdd(&ctr->arena_top, (u64)s.n);
-        atomicAdd(&ctr->n_ecs, 1ull);
+        const u64 off = at + (incl - want);
         if (off + s.n > arena_cap) { atomicOr(&ctr->err, ERR_ARENA); return; }
         for (u32 t = 0; t < s.n; ++t) arena[off + t] = pairs[s.off + t];
         table[j].off = (u32)off; table[j].n = s.n;

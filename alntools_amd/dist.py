@@ -4,8 +4,8 @@
 The reference parallelises over contiguous chunk ranges per process and merges the
 workers' ordered dicts in process order (``alntools/bam_utils.py:646-658, 680-724``), which
 makes EC rank = global first appearance.  Here every rank builds the table of its own
-contiguous read shard, the tables (tens of MB) are all-gathered once over RCCL/xGMI, and
-the root re-inserts them in rank order with ``first = read_base(rank) + local first``.
+contiguous read shard, the tables (tens of MB) are sent to the root over RCCL/xGMI (point to point),
+and the root re-inserts them in rank order with ``first = read_base(rank) + local first``.
 
 The functions only need an *engine* with ``table_sizes/counters/table_export/table_merge/
 add_counters`` -- :class:`GpuEngine` wraps an :class:`alntools_amd.ecb.EcBuilder`; the CPU
@@ -47,8 +47,10 @@ class GpuEngine(object):
 
 
 def exchange_and_merge(engine, make_root_engine, group=None, root=0):
-    """All ranks call this after pushing their shard.  Returns the merged engine on ``root``
-    (ready to finalize), ``None`` elsewhere.  One all-gather of sizes, one of tables."""
+    """All ranks call this after pushing their shard.  Returns the merged engine on ``root`` (ready to finalize),
+    ``None`` elsewhere.  One small all-gather (sizes), then every rank sends its table straight to the root
+    (point-to-point over xGMI: the 7 peers of an 8-GPU node use 7 different links at once; a ring all-gather would
+    push everything through every link)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     ne, npairs, nreads = engine.table_sizes()
@@ -60,20 +62,37 @@ def exchange_and_merge(engine, make_root_engine, group=None, root=0):
     sizes = sizes.view(world, 5).cpu().tolist()
     read_base = sum(s[2] for s in sizes[:rank])
     ent, prs = engine.table_export(read_base)
-    max_e = max(max(s[0] for s in sizes), 1) * ENTRY_WORDS
-    max_p = max(max(s[1] for s in sizes), 1) * PAIR_WORDS
-    send = torch.zeros(max_e + max_p, dtype=torch.int64, device=dev)
-    send[:ne * ENTRY_WORDS] = ent[:ne * ENTRY_WORDS]
-    send[max_e:max_e + npairs * PAIR_WORDS] = prs[:npairs * PAIR_WORDS]
-    recv = torch.empty(world * (max_e + max_p), dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(recv, send, group=group)
     if rank != root:
+        if ne:
+            ops = [dist.P2POp(dist.isend, ent[:ne * ENTRY_WORDS], root, group)]
+            if npairs:
+                ops.append(dist.P2POp(dist.isend, prs[:npairs * PAIR_WORDS], root, group))
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
         return None
+    bufs, ops = {}, []
+    for r in range(world):
+        e_r, p_r = sizes[r][0], sizes[r][1]
+        if r == root or not e_r:
+            continue
+        bufs[r] = (torch.empty(e_r * ENTRY_WORDS, dtype=torch.int64, device=dev),
+                   torch.empty(max(p_r, 1) * PAIR_WORDS, dtype=torch.int64, device=dev))
+        ops.append(dist.P2POp(dist.irecv, bufs[r][0], r, group))
+        if p_r:
+            ops.append(dist.P2POp(dist.irecv, bufs[r][1][:p_r * PAIR_WORDS], r, group))
+    reqs = dist.batch_isend_irecv(ops) if ops else []
     merged = make_root_engine()
-    recv = recv.view(world, max_e + max_p)
+    for req in reqs:
+        req.wait()
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
     for r in range(world):                      # rank order = stream order
         e_r, p_r = sizes[r][0], sizes[r][1]
-        if e_r:
-            merged.table_merge(recv[r, :max_e].contiguous(), e_r, recv[r, max_e:].contiguous(), p_r)
+        if not e_r:
+            continue
+        if r == root:
+            merged.table_merge(ent, e_r, prs, p_r)
+        else:
+            merged.table_merge(bufs[r][0], e_r, bufs[r][1], p_r)
     merged.add_counters(sum(s[3] for s in sizes), sum(s[4] for s in sizes), sum(s[2] for s in sizes))
     return merged
