@@ -84,3 +84,27 @@ def test_multisample_directory_matches_reference_bytes(golden_dir, tmp_path, mc,
     assert r["n_ecs"] == c["Number of ECs after filtering"] and r["n_cells"] == c["Number of cells after filtering"]
     assert r["n_ecs_before"] == c["Number of ECs"] and r["n_cells_before"] == c["Number of cells"]
     assert open(rng).read() == open(os.path.join(golden_dir, "g4_multi.range.txt")).read()
+
+
+def test_command_line_bam2ec(golden_dir, tmp_path):
+    from click.testing import CliRunner
+    from alntools_amd.cli import cli
+    g = json.load(open(os.path.join(golden_dir, "g1_edge.json")))
+    bam = str(tmp_path / g["sample"])
+    bamio.write_bam(bam, [tuple(r) for r in g["references"]], [tuple(r) for r in g["records"]])
+    out = str(tmp_path / "cli.bin")
+    r = CliRunner().invoke(cli, ["bam2ec", bam, out, "-v"])
+    assert r.exit_code == 0, r.output
+    assert _bytes(out) == _bytes(os.path.join(golden_dir, "g1_edge.bin"))
+
+
+def test_plain_c_program_runs_the_hot_path(tmp_path):
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.join(here, "..")
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.join(root, "alntools_amd")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-I", os.path.join(root, "include"), os.path.join(here, "abi_smoke.c"),
+                           "-o", exe, "-L", libdir, "-l:libecb.so", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "abi ok (device)" in out.stdout, (out.returncode, out.stdout, out.stderr)

@@ -113,3 +113,18 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(lib, s), s
     assert lib.ecb_abi_version() == 1
+
+
+def test_plain_c_program_links_against_the_abi(tmp_path):
+    import subprocess
+    from alntools_amd import ecb
+    ecb.load()
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.join(here, "..")
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.join(root, "alntools_amd")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-I", os.path.join(root, "include"), os.path.join(here, "abi_smoke.c"),
+                           "-o", exe, "-L", libdir, "-l:libecb.so", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert "abi ok" in out.stdout
