@@ -185,6 +185,7 @@ struct StreamArgs {
     u64* queue; u64 queue_cap;       // head record index of deferred reads
     u64* resume;                     // per wave {next record to process, records counted up to}
     u32* wave_counts;                // per wave {records offered, records valid, ECs created}: summed by k_sum_counts
+    u32 verify;                      // 1: do not insert; compare every read's set with the key of its recorded EC
     u32 ablate;                      // profiling only (env ECB_ABLATE): 1 = stop after (a), 2 = after (b), 4 = no EC table
 };
 
@@ -419,7 +420,22 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
             bool created = false;
             u32 np = 0;
             const u32 rd = base + lane;
-            if (on) {
+            if (on && A.verify) {                                   // exactness pass: set of this read == key of its EC ?
+                const Slot s = A.table[A.read_slot[rd]];
+                bool same = s.n == L.npair[lane];
+                const u32 b2 = L.seg[lane + 1] & 0xFFFFu, f2 = L.seg[lane + 1] >> 16;
+                for (u32 t = b2; t < f2 && same; ++t) {
+                    const u32 kk = L.tkey[t];
+                    if (!kk) continue;
+                    bool found = false;
+                    for (u32 i = 0; i < s.n; ++i) {
+                        const uint2 pr = A.arena[s.off + i];
+                        found |= (pr.x == kk - 1u) && (pr.y == L.tmask[t]);
+                    }
+                    same = found;
+                }
+                if (!same) my_new += 1;                             // (counted as "mismatches" in verify mode)
+            } else if (on) {
                 u64 lo, hi;
                 np = L.npair[lane];
                 finish_hash(L.acc[lane][0], L.acc[lane][1], np, lo, hi);
@@ -459,7 +475,7 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
                 }
                 if (!(bad & ERR_ARENA)) { chunk_at += total; chunk_left -= total; }
             }
-            my_new += (u32)__popcll(__ballot(created));
+            if (!A.verify) my_new += (u32)__popcll(__ballot(created));
         }
         wave_sync();
 
@@ -471,7 +487,8 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
     // records offered / valid: one atomic pair per wave
     const u32 wa = wave_sum(my_all), wv = wave_sum(my_valid);
     // per-wave totals go to their own words: thousands of waves adding to three shared counters serialise (~50 ns each)
-    if (lane == 0) { A.wave_counts[3 * wid] = wa; A.wave_counts[3 * wid + 1] = wv; A.wave_counts[3 * wid + 2] = my_new; }
+    const u32 wn = A.verify ? wave_sum(my_new) : my_new;
+    if (lane == 0) { A.wave_counts[3 * wid] = wa; A.wave_counts[3 * wid + 1] = wv; A.wave_counts[3 * wid + 2] = wn; }
 }
 
 __global__ __launch_bounds__(1024) void k_sum_counts(const u32* wave_counts, u64 waves, Counters* ctr) {
@@ -1178,7 +1195,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     u32* d_wcounts = nullptr;
     POOL(h, P_WCOUNTS, d_wcounts, 3 * waves);
     StreamArgs a{d_rid, d_loc, d_hf, n, chunk, h->prev_rid, h->cfg.n_loci, h->cfg.n_haplotypes,
-                 h->table, h->cap - 1, h->arena, h->arena_cap, 0, h->ctr, h->read_slot, h->queue, h->queue_cap, d_resume, d_wcounts,
+                 h->table, h->cap - 1, h->arena, h->arena_cap, 0, h->ctr, h->read_slot, h->queue, h->queue_cap, d_resume, d_wcounts, 0u,
                  getenv("ECB_ABLATE") ? (u32)atoi(getenv("ECB_ABLATE")) : 0u};
     for (;;) {
         HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));   // per launch
@@ -1380,6 +1397,54 @@ void ecb_destroy(ecb_handle* h) {
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
+}
+
+int ecb_verify_device(ecb_handle* h, const void* d_read_id, const void* d_locus, const void* d_hapflag, size_t n,
+                      uint64_t* n_mismatch, uint64_t* n_skipped) {
+    if (!h || !n_mismatch || !n_skipped) return ECB_ERR_ARG;
+    if (!n || !d_read_id || !d_locus || !d_hapflag) return fail(h, ECB_ERR_ARG, "null tuple stream");
+    if (((uintptr_t)d_read_id | (uintptr_t)d_locus | (uintptr_t)d_hapflag) & 15) return fail(h, ECB_ERR_ARG, "device streams must be 16-byte aligned");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = sync_counters(h);
+    if (rc != ECB_OK) return rc;
+    const Counters before = h->hctr;
+    int cus = 256, bpc = 4;
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_stream, TPB, 0);
+    u64 waves = std::min<u64>((u64)cus * std::max(bpc, 1) * NWAVE * 4, (n + 2 * WT - 1) / (2 * WT));
+    waves = std::max<u64>(waves, 1);
+    u64 chunk = ((n + waves - 1) / waves + 3) & ~(u64)3;
+    waves = (n + chunk - 1) / chunk;
+    const u64 blocks = (waves + NWAVE - 1) / NWAVE;
+    u64* d_resume = nullptr; u32* d_wcounts = nullptr;
+    POOL(h, P_RESUME, d_resume, 2 * waves); POOL(h, P_WCOUNTS, d_wcounts, 3 * waves);
+    std::vector<u64> r0(2 * waves);
+    for (u64 b = 0; b < waves; ++b) r0[2 * b] = r0[2 * b + 1] = b * chunk;
+    HIPCHK(h, hipMemcpyAsync(d_resume, r0.data(), 2 * waves * sizeof(u64), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(d_wcounts, 0, 3 * waves * sizeof(u32), h->stream));
+    HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));
+    const u64 need_q = waves * (u64)(WMAXR + 1) + 16;
+    if (h->queue_cap < need_q) {
+        if (h->queue) hipFree(h->queue);
+        h->queue_cap = need_q;
+        HIPCHK(h, hipMalloc(&h->queue, h->queue_cap * sizeof(u64)));
+    }
+    StreamArgs a{(const u32*)d_read_id, (const u32*)d_locus, (const u32*)d_hapflag, n, chunk, 0xFFFFFFFFu,
+                 h->cfg.n_loci, h->cfg.n_haplotypes, h->table, h->cap - 1, h->arena, h->arena_cap, h->arena_cap, h->ctr,
+                 h->read_slot, h->queue, h->queue_cap, d_resume, d_wcounts, 1u, 0u};
+    k_stream<<<(unsigned)blocks, TPB, 0, h->stream>>>(a);
+    k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, waves, h->ctr);
+    rc = sync_counters(h);
+    if (rc != ECB_OK) return rc;
+    *n_mismatch = h->hctr.n_ecs - before.n_ecs;
+    *n_skipped = h->hctr.n_queue;
+    // the pass re-counted the records: put the stream's own counters back
+    Counters fix = h->hctr;
+    fix.all = before.all; fix.valid = before.valid; fix.n_ecs = before.n_ecs; fix.n_queue = 0;
+    h->hctr = fix;
+    HIPCHK(h, hipMemcpyAsync(h->ctr, &h->hctr, sizeof(Counters), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ECB_OK;
 }
 
 int ecb_reset(ecb_handle* h) {

@@ -24,7 +24,7 @@ FLAG_NEXT_POS_NEG = 0x2000
 
 #: every symbol include/ecb.h declares
 SYMBOLS = ("ecb_abi_version", "ecb_device_count", "ecb_create", "ecb_destroy", "ecb_reset", "ecb_last_error",
-           "ecb_push", "ecb_push_device", "ecb_push_cells", "ecb_finalize", "ecb_export",
+           "ecb_push", "ecb_push_device", "ecb_push_cells", "ecb_verify_device", "ecb_finalize", "ecb_export",
            "ecb_export_device", "ecb_export_ranges", "ecb_export_range_minmax", "ecb_export_pairs", "ecb_export_read_ec", "ecb_table_sizes",
            "ecb_table_export_device", "ecb_table_merge_device", "ecb_counters", "ecb_add_counters", "ecb_profile",
            "ecb_profile_read")
@@ -80,6 +80,7 @@ def load():
     lib.ecb_push.argtypes = [vp, vp, vp, vp, vp, sz]
     lib.ecb_push_device.argtypes = [vp, vp, vp, vp, vp, sz]
     lib.ecb_push_cells.argtypes = [vp, vp, u64, sz]
+    lib.ecb_verify_device.argtypes = [vp, vp, vp, vp, sz, C.POINTER(u64), C.POINTER(u64)]
     lib.ecb_finalize.argtypes = [vp, C.POINTER(Sizes)]
     lib.ecb_export.argtypes = [vp] + [vp] * 6
     lib.ecb_export_device.argtypes = [vp] + [vp] * 6
@@ -165,6 +166,14 @@ class EcBuilder(object):
                 raise ValueError("device tuple streams must be contiguous 4-byte CUDA tensors of equal length")
         self._chk(self._lib.ecb_push_device(self._h, _dev_ptr(read_id), _dev_ptr(locus), _dev_ptr(hapflag),
                                             _dev_ptr(pos), n))
+
+    def verify_device(self, read_id, locus, hapflag):
+        """Exactness pass over the device-resident stream that was pushed: -> (reads whose target set differs from
+        their EC's stored key, reads too long to be re-checked)."""
+        bad, skipped = C.c_uint64(), C.c_uint64()
+        self._chk(self._lib.ecb_verify_device(self._h, _dev_ptr(read_id), _dev_ptr(locus), _dev_ptr(hapflag),
+                                              read_id.numel(), C.byref(bad), C.byref(skipped)))
+        return bad.value, skipped.value
 
     def push_cells(self, meta, first_read):
         """Multisample: ``cell | file << 22`` of reads ``[first_read, first_read + len(meta))``."""

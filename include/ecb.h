@@ -137,6 +137,14 @@ int ecb_export_pairs(ecb_handle* h, uint32_t* ec, uint32_t* meta, uint32_t* coun
 /* EC index of every read, in read order (n_reads values). */
 int ecb_export_read_ec(ecb_handle* h, int32_t* ec_of_read);
 
+/* Exactness check.  EC identity on the device is a 126-bit hash of the read's target set; this pass re-derives the
+ * {locus -> haplotype mask} set of every read from the records and compares it, pair by pair, with the key stored
+ * for the EC the read was assigned to.  The records must be the device-resident stream that was pushed (one
+ * ecb_push_device call covering the whole stream).  *n_mismatch counts reads whose set differs from their EC's key
+ * (0 = the grouping is exact); *n_skipped counts reads longer than a tile, which this pass does not re-check. */
+int ecb_verify_device(ecb_handle* h, const void* d_read_id, const void* d_locus, const void* d_hapflag, size_t n,
+                      uint64_t* n_mismatch, uint64_t* n_skipped);
+
 /* Multi-GPU: one handle per GPU over contiguous read shards (the reference's contiguous chunk
  * ranges per process, bam_utils.py:646-658).  A rank serialises its EC table (device buffers the
  * caller allocates: n_entries * 32 bytes and n_pairs * 8 bytes), the caller moves it (RCCL), and the

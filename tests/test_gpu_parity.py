@@ -193,6 +193,16 @@ def test_mid_size_device_vs_c_oracle_properties(paired):
         out = b.export()
     assert s["all_alignments"] == t["n_records"] and s["valid_alignments"] == t["n_valid"]
     assert s["n_reads"] == t["n_reads"] and int(out["dataN"].sum()) == t["n_reads"]
+    with ecb.EcBuilder(spec.n_loci, spec.n_haps) as b:          # exactness pass: every read's set == its EC's key
+        b.push_device(t["read_id"], t["locus"], t["hapflag"])
+        assert b.verify_device(t["read_id"], t["locus"], t["hapflag"]) == (0, 0)
+        assert b.finalize() == s                                 # the pass leaves the counters alone
+        # ... and it does notice a read whose records no longer match the EC it was given
+        hf2 = t["hapflag"].clone()
+        i = int(torch.nonzero((hf2 & 0x4) == 0)[1000]) if not paired else int(torch.nonzero((hf2 & 0xC3) == 0x43)[1000])
+        hf2[i] ^= (1 << 16)
+        bad, _ = b.verify_device(t["read_id"], t["locus"], hf2)
+        assert bad >= 1
     assert np.all(np.diff(out["indptrA"]) > 0)
     for e in (0, 1, s["n_ecs"] // 2, s["n_ecs"] - 1):            # columns ascending within a row
         row = out["indicesA"][out["indptrA"][e]:out["indptrA"][e + 1]]
@@ -259,6 +269,9 @@ def test_full_size_config3_properties():
         whole = b.export()
     assert s["all_alignments"] == st["records"] and s["valid_alignments"] == st["valid"] and s["n_reads"] == st["reads"]
     assert int(whole["dataN"].astype(np.int64).sum()) == st["reads"]
+    with ecb.EcBuilder(T, H, ec_capacity=1 << 24) as b:          # exact grouping at full size: 0 of 96 M reads differ
+        b.push_device(rid, loc, hf)
+        assert b.verify_device(rid, loc, hf) == (0, 0)
     assert np.all(np.diff(whole["indptrA"]) > 0) and whole["indptrA"][-1] == s["nnz_a"]
     assert whole["indicesA"].min() >= 0 and whole["indicesA"].max() < T
     assert whole["dataA"].min() >= 1 and whole["dataA"].max() < (1 << H)
