@@ -969,6 +969,69 @@ __global__ void k_ms_split(const u64* okey, const u32* ostart, u64 n, u32* ec, u
     if (i < n) { ec[i] = (u32)(okey[i] >> 32); meta[i] = (u32)okey[i]; count[i] = ostart[i + 1] - ostart[i]; }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// f-2: CSR(bitmask) <-> per-haplotype CSC (bin_utils.py:979-1028).  Expand to (key, value) pairs, stable radix sort
+// (rocprim), locate rows / columns by binary search on the sorted keys.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 lower_bound_u32(const u32* a, u64 n, u32 v) {
+    u64 lo = 0, hi = n;
+    while (lo < hi) { const u64 m = (lo + hi) >> 1; if (a[m] < v) lo = m + 1; else hi = m; }
+    return lo;
+}
+__device__ __forceinline__ u64 lower_bound_u64(const u64* a, u64 n, u64 v) {
+    u64 lo = 0, hi = n;
+    while (lo < hi) { const u64 m = (lo + hi) >> 1; if (a[m] < v) lo = m + 1; else hi = m; }
+    return lo;
+}
+__global__ void k_cv_popc(const int* data, u64 nnz, u32* cnt) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < nnz) cnt[i] = __popc((u32)data[i]);
+}
+__global__ void k_cv_expand(const int* indptr, u32 n_ecs, const int* indices, const int* data, u64 nnz, const u32* pos,
+                            u32 n_loci, u32* keys, u32* vals) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= nnz) return;
+    u32 lo = 0, hi = n_ecs;                                  // row of entry i: last e with indptr[e] <= i
+    while (lo < hi) { const u32 m = (lo + hi + 1) >> 1; if ((u64)indptr[m] <= i) lo = m; else hi = m - 1; }
+    u32 m = (u32)data[i], at = pos[i];
+    while (m) { const u32 h = __ffs(m) - 1; m &= m - 1; keys[at] = h * n_loci + (u32)indices[i]; vals[at] = lo; ++at; }
+}
+__global__ void k_cv_cscptr(const u32* keys, u64 total, u32 n_loci, u32 n_haps, int* cscptr) {
+    const u64 c = blockIdx.x * (u64)blockDim.x + threadIdx.x;          // c = h * (T + 1) + t
+    if (c >= (u64)n_haps * (n_loci + 1)) return;
+    const u32 h = (u32)(c / (n_loci + 1)), t = (u32)(c % (n_loci + 1));
+    cscptr[c] = (int)(lower_bound_u32(keys, total, h * n_loci + t) - lower_bound_u32(keys, total, h * n_loci));
+}
+__global__ void k_cv_back_expand(const int* cscptr, const int* cscidx, u64 total, u32 n_loci, u32 n_haps, const u64* hap_start,
+                                 u64* keys, u32* vals) {
+    const u64 g = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    u32 h = 0;
+    while (h + 1 < n_haps && hap_start[h + 1] <= g) ++h;
+    const int* ptr = cscptr + (u64)h * (n_loci + 1);
+    const u64 j = g - hap_start[h];
+    u32 lo = 0, hi = n_loci;                                 // column of entry j: last t with ptr[t] <= j
+    while (lo < hi) { const u32 m = (lo + hi + 1) >> 1; if ((u64)ptr[m] <= j) lo = m; else hi = m - 1; }
+    keys[g] = (u64)(u32)cscidx[g] * n_loci + lo;
+    vals[g] = 1u << h;
+}
+__global__ void k_cv_back_emit(const u64* keys, const u32* vals, const u32* flag, const u32* pos, u64 total, u32 n_loci,
+                               int* indices, int* data) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= total || !flag[i]) return;
+    u32 m = 0;
+    for (u64 j = i; j < total && keys[j] == keys[i]; ++j) m |= vals[j];
+    indices[pos[i]] = (int)(keys[i] % n_loci);
+    data[pos[i]] = (int)m;
+}
+__global__ void k_cv_back_rowptr(const u64* keys, const u32* pos, u64 total, u32 nnz, u32 n_ecs, u32 n_loci, int* indptr) {
+    const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (e > n_ecs) return;
+    const u64 at = lower_bound_u64(keys, total, (u64)e * n_loci);
+    indptr[e] = at < total ? (int)pos[at] : (int)nnz;       // pos[] = index of the run that starts at or after `at`
+}
+
 __global__ void k_iota(int* out, u64 n) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i < n) out[i] = (int)i;
@@ -1813,3 +1876,92 @@ int ecb_profile_read(ecb_handle* h, double* ms, uint64_t* launches, uint64_t* re
 }
 
 }  // extern "C"
+
+// ---- f-2 conversions (stateless; scratch is allocated per call: this is not the hot path) ------------------------
+namespace {
+struct Scratch {                       // frees what it allocated
+    std::vector<void*> p;
+    template <class T> T* get(u64 n) { void* q = nullptr; if (hipMalloc(&q, std::max<u64>(n, 1) * sizeof(T)) != hipSuccess) return nullptr; p.push_back(q); return (T*)q; }
+    ~Scratch() { for (void* q : p) hipFree(q); }
+};
+int cv_scan(hipStream_t st, const u32* in, u64 n, u32* out, u32* total, Scratch& sc) {
+    const u64 nb = std::max<u64>(1, (n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    u32* sums = sc.get<u32>(nb + 1);
+    if (!sums) return ECB_ERR_HIP;
+    k_scan_sums<<<(unsigned)nb, TPB, 0, st>>>(in, n, sums);
+    k_scan_top<<<1, TPB, 0, st>>>(sums, nb, sums + nb);
+    k_scan_apply<<<(unsigned)nb, TPB, 0, st>>>(in, n, sums, out);
+    if (hipMemcpyAsync(total, sums + nb, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return ECB_ERR_HIP;
+    return hipStreamSynchronize(st) == hipSuccess ? ECB_OK : ECB_ERR_HIP;
+}
+}  // namespace
+
+extern "C" int ecb_csr_to_hapcsc_device(int device, uint32_t n_ecs, uint32_t n_loci, uint32_t n_haps, const void* d_indptr,
+                                        const void* d_indices, const void* d_data, void* d_cscptr, void* d_cscidx,
+                                        uint64_t* total) {
+    if (!d_indptr || !d_indices || !d_data || !total || !n_ecs || !n_loci || !n_haps || n_haps > 31) return fail(nullptr, ECB_ERR_ARG, "bad argument");
+    if ((u64)n_haps * n_loci >= (1ull << 32)) return fail(nullptr, ECB_ERR_LIMIT, "haplotypes x loci does not fit 32 bits");
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, ECB_ERR_NO_DEVICE, "no such device");
+    hipStream_t st = nullptr;
+    int nnz_i = 0;
+    if (hipMemcpy(&nnz_i, (const int*)d_indptr + n_ecs, 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "read nnz");
+    const u64 nnz = (u64)nnz_i;
+    Scratch sc;
+    u32 *cnt = sc.get<u32>(nnz), *pos = sc.get<u32>(nnz);
+    if (!cnt || !pos) return fail(nullptr, ECB_ERR_HIP, "out of device memory");
+    k_cv_popc<<<nblk(nnz, TPB), TPB, 0, st>>>((const int*)d_data, nnz, cnt);
+    u32 tot = 0;
+    if (cv_scan(st, cnt, nnz, pos, &tot, sc) != ECB_OK) return fail(nullptr, ECB_ERR_HIP, "scan");
+    *total = tot;
+    if (!d_cscidx || !d_cscptr) return ECB_OK;
+    u32 *keys = sc.get<u32>(tot), *vals = sc.get<u32>(tot), *keys2 = sc.get<u32>(tot);
+    if (!keys || !vals || !keys2) return fail(nullptr, ECB_ERR_HIP, "out of device memory");
+    k_cv_expand<<<nblk(nnz, TPB), TPB, 0, st>>>((const int*)d_indptr, n_ecs, (const int*)d_indices, (const int*)d_data, nnz, pos,
+                                               n_loci, keys, vals);
+    size_t tb = 0;
+    unsigned bits = 1; while ((1ull << bits) < (u64)n_haps * n_loci) ++bits;
+    rocprim::radix_sort_pairs(nullptr, tb, keys, keys2, vals, (u32*)d_cscidx, tot, 0, bits, st);
+    char* tmp = sc.get<char>(tb);
+    if (!tmp) return fail(nullptr, ECB_ERR_HIP, "out of device memory");
+    if (rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, (u32*)d_cscidx, tot, 0, bits, st) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "sort");
+    const u64 nc = (u64)n_haps * (n_loci + 1);
+    k_cv_cscptr<<<nblk(nc, TPB), TPB, 0, st>>>(keys2, tot, n_loci, n_haps, (int*)d_cscptr);
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "csr -> csc");
+    return ECB_OK;
+}
+
+extern "C" int ecb_hapcsc_to_csr_device(int device, uint32_t n_ecs, uint32_t n_loci, uint32_t n_haps, const void* d_cscptr,
+                                        const void* d_cscidx, uint64_t total, void* d_indptr, void* d_indices, void* d_data,
+                                        uint64_t* nnz_out) {
+    if (!d_cscptr || !d_cscidx || !d_indptr || !d_indices || !d_data || !nnz_out || !n_ecs || !n_loci || !n_haps || n_haps > 31 || !total)
+        return fail(nullptr, ECB_ERR_ARG, "bad argument");
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, ECB_ERR_NO_DEVICE, "no such device");
+    hipStream_t st = nullptr;
+    // start of every haplotype's block = running sum of its last column pointer
+    std::vector<int> last(n_haps);
+    for (u32 h = 0; h < n_haps; ++h)
+        if (hipMemcpy(&last[h], (const int*)d_cscptr + (u64)h * (n_loci + 1) + n_loci, 4, hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(nullptr, ECB_ERR_HIP, "read csc pointers");
+    std::vector<u64> hs(n_haps + 1, 0);
+    for (u32 h = 0; h < n_haps; ++h) hs[h + 1] = hs[h] + (u64)last[h];
+    if (hs[n_haps] != total) return fail(nullptr, ECB_ERR_ARG, "total does not match the column pointers");
+    Scratch sc;
+    u64 *d_hs = sc.get<u64>(n_haps + 1), *keys = sc.get<u64>(total), *keys2 = sc.get<u64>(total);
+    u32 *vals = sc.get<u32>(total), *vals2 = sc.get<u32>(total), *flag = sc.get<u32>(total), *pos = sc.get<u32>(total);
+    if (!d_hs || !keys || !keys2 || !vals || !vals2 || !flag || !pos) return fail(nullptr, ECB_ERR_HIP, "out of device memory");
+    hipMemcpy(d_hs, hs.data(), (n_haps + 1) * 8, hipMemcpyHostToDevice);
+    k_cv_back_expand<<<nblk(total, TPB), TPB, 0, st>>>((const int*)d_cscptr, (const int*)d_cscidx, total, n_loci, n_haps, d_hs, keys, vals);
+    size_t tb = 0;
+    rocprim::radix_sort_pairs(nullptr, tb, keys, keys2, vals, vals2, total, 0, 64, st);
+    char* tmp = sc.get<char>(tb);
+    if (!tmp) return fail(nullptr, ECB_ERR_HIP, "out of device memory");
+    if (rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, total, 0, 64, st) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "sort");
+    k_ms_heads<<<nblk(total, TPB), TPB, 0, st>>>(keys2, total, flag);
+    u32 nnz = 0;
+    if (cv_scan(st, flag, total, pos, &nnz, sc) != ECB_OK) return fail(nullptr, ECB_ERR_HIP, "scan");
+    k_cv_back_emit<<<nblk(total, TPB), TPB, 0, st>>>(keys2, vals2, flag, pos, total, n_loci, (int*)d_indices, (int*)d_data);
+    k_cv_back_rowptr<<<nblk((u64)n_ecs + 1, TPB), TPB, 0, st>>>(keys2, pos, total, nnz, n_ecs, n_loci, (int*)d_indptr);
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "csc -> csr");
+    *nnz_out = nnz;
+    return ECB_OK;
+}

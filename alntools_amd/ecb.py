@@ -27,7 +27,7 @@ SYMBOLS = ("ecb_abi_version", "ecb_device_count", "ecb_create", "ecb_destroy", "
            "ecb_push", "ecb_push_device", "ecb_push_cells", "ecb_verify_device", "ecb_finalize", "ecb_export",
            "ecb_export_device", "ecb_export_ranges", "ecb_export_range_minmax", "ecb_export_pairs", "ecb_export_read_ec", "ecb_table_sizes",
            "ecb_table_export_device", "ecb_table_merge_device", "ecb_counters", "ecb_add_counters", "ecb_profile",
-           "ecb_profile_read")
+           "ecb_profile_read", "ecb_csr_to_hapcsc_device", "ecb_hapcsc_to_csr_device")
 
 
 class EcbError(RuntimeError):
@@ -95,6 +95,8 @@ def load():
     lib.ecb_add_counters.argtypes = [vp, u64, u64, u64]
     lib.ecb_profile.argtypes = [vp, C.c_int]
     lib.ecb_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]
+    lib.ecb_csr_to_hapcsc_device.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, C.POINTER(u64)]
+    lib.ecb_hapcsc_to_csr_device.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, u64, vp, vp, vp, C.POINTER(u64)]
     _lib = lib
     return lib
 
@@ -105,6 +107,45 @@ def _ptr(a):
 
 def _dev_ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def csr_to_hapcsc(indptr, indices, data, n_loci, n_haps):
+    """f-2 on device tensors (int32, CUDA): CSR(bitmask) -> (csc_indptr [H, T+1], csc_indices [total], nnz per haplotype).
+    Haplotype h's row indices are ``csc_indices[starts[h]:starts[h+1]]`` (``bin_utils.ec2emase``'s per-haplotype CSC)."""
+    import torch
+    lib = load()
+    dev = indptr.device
+    E = indptr.numel() - 1
+    tot = C.c_uint64()
+    rc = lib.ecb_csr_to_hapcsc_device(dev.index or 0, E, n_loci, n_haps, _dev_ptr(indptr), _dev_ptr(indices), _dev_ptr(data),
+                                      None, None, C.byref(tot))
+    if rc != 0:
+        raise EcbError(rc, (lib.ecb_last_error(None) or b"").decode())
+    cptr = torch.empty((n_haps, n_loci + 1), dtype=torch.int32, device=dev)
+    cidx = torch.empty(max(tot.value, 1), dtype=torch.int32, device=dev)
+    rc = lib.ecb_csr_to_hapcsc_device(dev.index or 0, E, n_loci, n_haps, _dev_ptr(indptr), _dev_ptr(indices), _dev_ptr(data),
+                                      _dev_ptr(cptr), _dev_ptr(cidx), C.byref(tot))
+    if rc != 0:
+        raise EcbError(rc, (lib.ecb_last_error(None) or b"").decode())
+    return cptr, cidx[:tot.value]
+
+
+def hapcsc_to_csr(csc_indptr, csc_indices, n_ecs):
+    """f-2 inverse on device tensors: per-haplotype CSC -> CSR(bitmask) (``bin_utils.emase2ec``: A = sum 2^h M_h)."""
+    import torch
+    lib = load()
+    dev = csc_indptr.device
+    H, T1 = csc_indptr.shape
+    total = csc_indices.numel()
+    ip = torch.empty(n_ecs + 1, dtype=torch.int32, device=dev)
+    ix = torch.empty(total, dtype=torch.int32, device=dev)
+    da = torch.empty(total, dtype=torch.int32, device=dev)
+    nnz = C.c_uint64()
+    rc = lib.ecb_hapcsc_to_csr_device(dev.index or 0, n_ecs, T1 - 1, H, _dev_ptr(csc_indptr), _dev_ptr(csc_indices), total,
+                                      _dev_ptr(ip), _dev_ptr(ix), _dev_ptr(da), C.byref(nnz))
+    if rc != 0:
+        raise EcbError(rc, (lib.ecb_last_error(None) or b"").decode())
+    return ip, ix[:nnz.value], da[:nnz.value]
 
 
 class EcBuilder(object):

@@ -157,6 +157,21 @@ int ecb_table_merge_device(ecb_handle* h, const void* d_entries, uint64_t n_entr
 int ecb_counters(ecb_handle* h, uint64_t* all_alignments, uint64_t* valid_alignments, uint64_t* n_reads);
 int ecb_add_counters(ecb_handle* h, uint64_t all_alignments, uint64_t valid_alignments, uint64_t n_reads);
 
+/* f-2: the sparse-format conversions behind ec2emase / emase2ec (bin_utils.py:979-1028), on device arrays.
+ * .bin holds A as one CSR over (EC, locus) whose value is the haplotype bitmask (bin_utils.py:208-211); EMASE holds one
+ * CSC matrix (E x T, row indices ascending) per haplotype (Sparse3DMatrix.py:189-193, 325-342).
+ * ecb_csr_to_hapcsc_device: call with d_csc_indices = NULL to learn *total (= sum of popcounts), then again to fill
+ *   d_csc_indptr (int32, H x (T+1), each haplotype's pointers starting at 0) and d_csc_indices (int32 rows; haplotype h's
+ *   block starts at the sum of the earlier haplotypes' nnz).
+ * ecb_hapcsc_to_csr_device: the inverse (A = sum_h 2^h M_h, columns ascending); d_indices/d_data hold at most `total`
+ *   entries, *nnz receives the count. */
+int ecb_csr_to_hapcsc_device(int device, uint32_t n_ecs, uint32_t n_loci, uint32_t n_haps, const void* d_indptr_a,
+                             const void* d_indices_a, const void* d_data_a, void* d_csc_indptr, void* d_csc_indices,
+                             uint64_t* total);
+int ecb_hapcsc_to_csr_device(int device, uint32_t n_ecs, uint32_t n_loci, uint32_t n_haps, const void* d_csc_indptr,
+                             const void* d_csc_indices, uint64_t total, void* d_indptr_a, void* d_indices_a,
+                             void* d_data_a, uint64_t* nnz);
+
 /* Measurement: HIP-event time of the record-stream kernel on the handle's own stream. */
 int ecb_profile(ecb_handle* h, int enable);
 int ecb_profile_read(ecb_handle* h, double* kernel_ms, uint64_t* launches, uint64_t* records);

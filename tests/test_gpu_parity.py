@@ -309,3 +309,50 @@ def test_full_size_config3_properties():
         assert np.array_equal(whole[k], merged[k]), k
     for e in engines + [root]:
         e.b.close()
+
+
+def test_sparse_format_round_trip_on_device(golden_dir):
+    """f-2 / BASELINE config 5: CSR(bitmask) -> per-haplotype CSC -> CSR on the device; per-haplotype CSC equals scipy's
+    (what ec2emase stores), and the round trip reproduces the .bin arrays exactly."""
+    import torch
+    from alntools_amd import bin_utils
+    dev = torch.device("cuda:0")
+    for name in ("g2_c1.bin", "g1_edge.bin", "g4_multi_min0.bin"):
+        m = bin_utils.ecload(os.path.join(golden_dir, name))
+        ip, ix, da = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (m.indptrA, m.indicesA, m.dataA))
+        cptr, cidx = ecb.csr_to_hapcsc(ip, ix, da, m.num_loci, m.num_haplotypes)
+        cptr_h, cidx_h = cptr.cpu().numpy(), cidx.cpu().numpy()
+        start = 0
+        for h in range(m.num_haplotypes):
+            ref = m.haplotype_csc(h)
+            assert np.array_equal(cptr_h[h], ref.indptr), (name, h)
+            assert np.array_equal(cidx_h[start:start + ref.nnz], ref.indices), (name, h)
+            start += ref.nnz
+        ip2, ix2, da2 = ecb.hapcsc_to_csr(cptr, cidx, m.num_reads)
+        assert np.array_equal(ip2.cpu().numpy(), m.indptrA) and np.array_equal(ix2.cpu().numpy(), m.indicesA)
+        assert np.array_equal(da2.cpu().numpy(), m.dataA)
+
+
+def test_sparse_format_round_trip_at_scale():
+    import torch
+    spec = synth.SynthSpec(3_000_000, 40_000, 8, paired=True)
+    dev = torch.device("cuda:0")
+    t = synth.generate(spec, 0, spec.n_reads, device=dev)
+    with ecb.EcBuilder(spec.n_loci, spec.n_haps) as b:
+        b.push_device(t["read_id"], t["locus"], t["hapflag"])
+        s = b.finalize()
+        out = b.export()
+    ip, ix, da = (torch.from_numpy(out[k]).to(dev) for k in ("indptrA", "indicesA", "dataA"))
+    cptr, cidx = ecb.csr_to_hapcsc(ip, ix, da, spec.n_loci, spec.n_haps)
+    assert cidx.numel() == int(np.unpackbits(out["dataA"].astype(np.uint8)).sum())      # one entry per set haplotype bit
+    rows = cidx.cpu().numpy()
+    ptr = cptr.cpu().numpy().astype(np.int64)
+    starts = np.concatenate([[0], np.cumsum(ptr[:, -1])])
+    for h in (0, spec.n_haps - 1):                                                       # rows ascending within every column
+        seg = rows[starts[h]:starts[h + 1]]
+        brk = np.zeros(len(seg), dtype=bool)
+        brk[ptr[h][1:-1][ptr[h][1:-1] < len(seg)]] = True
+        d = np.diff(seg)
+        assert np.all((d > 0) | brk[1:])
+    ip2, ix2, da2 = ecb.hapcsc_to_csr(cptr, cidx, s["n_ecs"])
+    assert torch.equal(ip2, ip) and torch.equal(ix2, ix) and torch.equal(da2, da)
