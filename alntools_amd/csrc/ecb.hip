@@ -1,28 +1,26 @@
 // libecb -- equivalence-class builder for alntools' bam2ec / bam2emase hot path on MI355X (gfx950).
 //
-// What the reference does per alignment in Python (alntools/bam_utils.py:258-344), per merge
-// (:680-724) and per EC (:788-847) is done here by three groups of kernels:
+// What the reference does per alignment in Python (alntools/bam_utils.py:258-344), per merge (:680-724) and per EC
+// (:788-847) is done here by these groups of kernels (DESIGN.md section 4 has the measurements behind the shapes):
 //
-//   k_stream   one pass over the record tuples (12 B/record, coalesced 16-B loads).  A workgroup
-//              walks a contiguous slice of the stream tile by tile (2048 records).  Per tile it
-//              (a) applies the record filter (bam_utils.py:264-270) and finds read heads from the
-//                  host's run counter (bam_utils.py:289-320);
-//              (b) inserts every valid record into an LDS open-addressing table that is cut into one
-//                  private range per read (2 slots per record of the read): key = locus, value = OR of
-//                  haplotype bits -- this is the duplicate collapse of bam_utils.py:322-325 and the
-//                  per-(EC,target,haplotype) bit test of bam_utils.py:800-819 in one LDS atomic;
-//              (c) one lane per read walks its range, sums a 2x64-bit mix over the distinct
-//                  (locus, mask) pairs -- an order-independent 126-bit set hash, the stand-in for the
-//                  sorted string key of bam_utils.py:307 -- and upserts the global EC table
-//                  (count += 1, first = min(read index): bam_utils.py:309-312, 688-698).  The lane that
-//                  creates an EC copies its pairs into the key arena.
-//   k_slow     the same for single reads that do not fit a tile or hit a full table (one workgroup per
-//              read, global scratch table).
-//   finalize   rank ECs by first appearance (bitmap + scan: bam_utils.py:682-698), exclusive scan of
-//              row lengths, sort each row by locus and emit CSR A / N (bam_utils.py:835-847,
-//              bin_utils.py:208-211).
+//   k_stream   one pass over the record tuples (12 B/record, 16-byte loads).  Wave-autonomous: each wave owns a
+//              contiguous slice of the stream and walks it in tiles of 512 records with wave-private LDS and no
+//              workgroup barriers.  Per tile: (a) record filter (bam_utils.py:264-270) and read heads from the host's run
+//              counter (:289-320); (b) one {locus -> haplotype mask} open-addressing table per read in LDS -- ds_cmpst on the
+//              locus, ds_or of the haplotype bit: the duplicate collapse of :322-325 and the per-(EC, target, haplotype) bit
+//              test of :800-819 in two LDS atomics; each table entry is hashed once and summed per read (a commutative set
+//              hash, the stand-in for the sorted string key of :307); (c) one lane per read looks the 126-bit key up in the
+//              global EC table or inserts it, and records the slot of the read.  The lane that creates an EC copies its
+//              (locus, mask) pairs from LDS to the key arena.
+//   k_slow     the same for single reads that do not fit a tile or hit a full table (one workgroup per read).
+//   k_count    reads per EC and first read per EC (:309-312, 688-698) from the per-read slots, without global atomics:
+//              partition by slot range, count in LDS.
+//   finalize   rank ECs by first appearance (bitmap + scan: :682-698), scan of row lengths, sort each row by locus and
+//              emit CSR A / N (:835-847, bin_utils.py:208-211).
+//   k_merge    multi-GPU: re-insert another rank's serialised table (the ordered merge of :680-724).
+//   k_ms_*, k_cv_*   multisample (EC, cell, file) triples; CSR(bitmask) <-> per-haplotype CSC (bin_utils.py:979-1028).
 //
-// Integer / indexing work only: no MFMA.  The bound is HBM bandwidth.
+// Integer / indexing work only: no MFMA.  The bound is HBM bandwidth; today the stream kernel is VALU-issue bound.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -44,9 +42,6 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 
 constexpr int TPB = 256;             // threads per workgroup (4 waves of 64)
-constexpr int RPL = 8;               // records per lane per tile (2 x 16-byte loads per stream)
-constexpr int TILE = TPB * RPL;      // records per tile
-constexpr int MAXR = 512;            // reads finished per tile (more heads than this: the next tile starts there)
 constexpr u32 MAX_PROBE = 256;       // EC-table probes before a read is deferred to k_slow
 constexpr u32 PENDING = 0xFFFFFFFFu;
 constexpr u32 ARENA_CHUNK = 512;     // pairs a wave reserves from the key arena per global atomic
@@ -149,13 +144,6 @@ __device__ __forceinline__ u64 table_find_or_insert(Slot* table, u64 cap_mask, u
 // tiles of WT records with wave-private LDS and no workgroup barriers, so the 16 waves of a CU overlap
 // each other's HBM and EC-table latency.  Per tile and lane: 8 records (2 x 16-byte loads per stream).
 // ---------------------------------------------------------------------------------------------
-// tuning switches (A/B-tested on MI355X)
-#ifndef V_BALLOT_SUMS
-#define V_BALLOT_SUMS 1
-#endif
-#ifndef V_MERGE
-#define V_MERGE 0
-#endif
 constexpr int WT = 512;              // records per wave tile
 constexpr int WMAXR = 64;            // reads finished per wave tile (one lane each in phase (c))
 constexpr int NWAVE = TPB / 64;
@@ -329,6 +317,15 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
         const bool last_complete = (te == A.n);                  // batches end on a read boundary
         const u32 nrc = last_complete ? nr : (nr ? nr - 1u : 0u);
         const u32 nproc = min(min(nrc, nown), (u32)WMAXR);
+        // Reads finished in this tile get their table geometry packed once: first slot (10 bits) | end slot (10) | mask of
+        // the largest power of two within the range (10).  Probing starts at first + (locus & mask): the loci of a read are
+        // mostly consecutive target ids, which low bits never collide on -- cheaper than a multiplicative hash and the
+        // collision path below becomes rare.
+        if (lane < nproc) {
+            const u32 sg = L.seg[lane + 1], s2 = sg & 0xFFFFu, e2 = sg >> 16;
+            L.seg[lane + 1] = s2 | (e2 << 10) | (((1u << (31 - __clz((int)(e2 - s2)))) - 1u) << 20);
+        }
+        wave_sync();
         const bool done = (te >= c1 && nown <= nproc);           // every read that starts in our slice
         u64 p_next = te;
         u32 base_next = base + nr;
@@ -363,8 +360,7 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
                 const u32 on = (m_ok >> k) & (u32)(r_rl[k] < nproc) & 1u;
                 act |= on << k;
                 const u32 sg = L.seg[on ? r_rl[k] + 1u : 0u];
-                const u32 s2 = sg & 0xFFFFu, len = (sg >> 16) - s2;
-                q[k] = s2 + (__umul24(__umul24(r_key[k] & 0xFFFFFFu, 0x9E3779u) >> 8 & 0xFFFFu, len) >> 16);
+                q[k] = (sg & 0x3FFu) + (r_key[k] & (sg >> 20));
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k)
@@ -387,7 +383,7 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
                     bool made = false;
                     if (coll >> k & 1u) {
                         const u32 sg = L.seg[r_rl[k] + 1u];
-                        const u32 s2 = sg & 0xFFFFu, e2 = sg >> 16;
+                        const u32 s2 = sg & 0x3FFu, e2 = (sg >> 10) & 0x3FFu;
                         u32 o;
                         do {
                             if (++q[k] == e2) q[k] = s2;
@@ -423,7 +419,7 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
             if (on && A.verify) {                                   // exactness pass: set of this read == key of its EC ?
                 const Slot s = A.table[A.read_slot[rd]];
                 bool same = s.n == L.npair[lane];
-                const u32 b2 = L.seg[lane + 1] & 0xFFFFu, f2 = L.seg[lane + 1] >> 16;
+                const u32 b2 = L.seg[lane + 1] & 0x3FFu, f2 = (L.seg[lane + 1] >> 10) & 0x3FFu;
                 for (u32 t = b2; t < f2 && same; ++t) {
                     const u32 kk = L.tkey[t];
                     if (!kk) continue;
@@ -445,7 +441,7 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
                     if (slot == ~0ull) {                            // table too full here: defer the read, park
                         atomicExch(&A.ctr->full, 1u);
                         const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
-                        if (qi < A.queue_cap) A.queue[qi] = tb + unslot(L.seg[lane + 1] & 0xFFFFu); else atomicOr(&A.ctr->err, ERR_QUEUE);
+                        if (qi < A.queue_cap) A.queue[qi] = tb + unslot(L.seg[lane + 1] & 0x3FFu); else atomicOr(&A.ctr->err, ERR_QUEUE);
                     } else {
                         A.read_slot[rd] = (u32)slot;
                     }
@@ -467,7 +463,7 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
                 if (created && !(bad & ERR_ARENA)) {
                     u64 off = chunk_at + (incl - want);
                     A.table[slot].off = (u32)off; A.table[slot].n = np;
-                    const u32 b2 = L.seg[lane + 1] & 0xFFFFu, f2 = L.seg[lane + 1] >> 16;
+                    const u32 b2 = L.seg[lane + 1] & 0x3FFu, f2 = (L.seg[lane + 1] >> 10) & 0x3FFu;
                     for (u32 t = b2; t < f2; ++t) {
                         const u32 kk = L.tkey[t];
                         if (kk) A.arena[off++] = make_uint2(kk - 1u, L.tmask[t]);

@@ -2,7 +2,7 @@
 # GPU box: PMC counters for k_stream (separate passes, no tracing domains besides kernel-trace).  usage: tools_pmc.sh <workload> <outdir>
 W=${1:-c2}; OUT=${2:-gpurun_out/pmc}
 R=$GRAFT_REPO_ROOT; mkdir -p $R/$OUT
-cd /tmp && export TMPDIR=/tmp
+cd /tmp && export TMPDIR=/tmp ECB_NO_VERIFY=1
 run() { # name counters...
   name=$1; shift
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex k_stream --output-format csv -d $R/$OUT/$name -- python $R/bench.py --workload $W --steps 1 --warmup 0 --no-cpu-baseline > $R/$OUT/$name.log 2>&1
