@@ -144,21 +144,28 @@ __device__ __forceinline__ u64 table_find_or_insert(Slot* table, u64 cap_mask, u
 // tiles of WT records with wave-private LDS and no workgroup barriers, so the 16 waves of a CU overlap
 // each other's HBM and EC-table latency.  Per tile and lane: 8 records (2 x 16-byte loads per stream).
 // ---------------------------------------------------------------------------------------------
-constexpr int WT = 512;              // records per wave tile
+#ifndef ECB_RPL
+#define ECB_RPL 8
+#endif
+constexpr int RPL = ECB_RPL;         // records per lane per tile: groups of 4 consecutive records (one 16-byte load per stream)
+static_assert(RPL == 8, "only 8 records per lane is validated (16 was measured: 233 VGPRs, 2 waves/SIMD, 11-25 % slower)");
+constexpr int NG = RPL / 4;          // groups; group g of lane l holds records 256 g + 4 l .. + 3 of the tile
+constexpr int WT = 64 * RPL;         // records per wave tile
 constexpr int WMAXR = 64;            // reads finished per wave tile (one lane each in phase (c))
 constexpr int NWAVE = TPB / 64;
-
 constexpr int TSLOTS = WT + WT / 2;  // LDS table slots per wave tile: 1.5 per record
+constexpr u32 SBITS = (TSLOTS <= 1024) ? 10 : 11;   // bits of a table-slot index
+constexpr u32 SMASK = (1u << SBITS) - 1u;
 struct alignas(16) WaveLds {
     u32 tkey[TSLOTS];                // per-read {locus -> mask} tables, 1.5 slots per record of the read; key = locus + 1
     u32 tmask[TSLOTS];               // (contiguous with tkey: cleared together with 16-byte stores)
     u64 acc[WMAXR][2];               // per read: set-hash sums (2 x 64 bits)
-    unsigned short ent[WT];          // table entries created in this tile: slot | read << 10
+    u32 ent[WT];                     // table entries created in this tile: slot | read << SBITS
     unsigned short npair[WMAXR];     // per read: number of (locus, mask) pairs
-    u32 seg[WMAXR + 3];              // seg[rl + 1] = first table slot of read rl | end slot << 16 (seg[0] absorbs a store)
+    u32 seg[WMAXR + 3];              // seg[rl + 1]: first table slot of read rl | end slot << 16; repacked for finished reads
 };
 __device__ __forceinline__ u32 tslot(u32 rec) { return rec + (rec >> 1); }   // first table slot of a read starting at `rec`
-__device__ __forceinline__ u32 unslot(u32 t) { const u32 m = (t * 683u) >> 11; return 2u * m + (t - 3u * m); }   // inverse, t < 1024
+__device__ __forceinline__ u32 unslot(u32 t) { const u32 m = (t * 683u) >> 11; return 2u * m + (t - 3u * m); }   // inverse, t < 4096
 
 struct StreamArgs {
     const u32* rid; const u32* loc; const u32* hf;
@@ -193,12 +200,12 @@ __device__ __forceinline__ u32 group_mask(int lo, int hi) {
     return hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
 }
 
-struct TileRegs { u32 rr[8], ll[8], hh[8]; };
+struct TileRegs { u32 rr[RPL], ll[RPL], hh[RPL]; };
 
 __device__ __forceinline__ void load_tile(const StreamArgs& A, u64 tb, u64 te, u32 lane, TileRegs& R) {
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const u64 i0 = tb + (u64)g * (WT / 2) + 4u * lane;
+    for (int g = 0; g < NG; ++g) {
+        const u64 i0 = tb + (u64)g * 256 + 4u * lane;
         if (i0 + 4 <= te) {
             uint4 v = *reinterpret_cast<const uint4*>(A.rid + i0);
             R.rr[4 * g] = v.x; R.rr[4 * g + 1] = v.y; R.rr[4 * g + 2] = v.z; R.rr[4 * g + 3] = v.w;
@@ -257,19 +264,22 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
         // ---- (a) filter, heads -------------------------------------------------------------------
         // Written with integer bit arithmetic throughout: every instruction costs a 4-cycle issue slot, and
         // compare -> mask -> select chains were a third of this kernel's instruction count.
-        u32 r_key[8], r_bit[8], r_rl[8];          // locus + 1, haplotype bit, read index within the tile
+        u32 r_key[RPL], r_bit[RPL], r_rl[RPL];    // locus + 1, haplotype bit, read index within the tile
         u32 m_ok = 0, m_head = 0, m_own = 0;       // bit k: valid & in range / head / head of a read we own
         {
-            const u32 up0 = __shfl_up(R.rr[3], 1), up1 = __shfl_up(R.rr[7], 1), last0 = __shfl(R.rr[3], 63);
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const int i0 = g * (WT / 2) + 4 * (int)lane;
+            for (int g = 0; g < NG; ++g) {
+                const int i0 = g * 256 + 4 * (int)lane;
+                // the record before this group's first: the previous lane's last record of the group, or (lane 0) the
+                // previous group's very last record
+                const u32 up = __shfl_up(R.rr[4 * g + 3], 1);
+                const u32 wrap = g == 0 ? base - 1u : (u32)__shfl(R.rr[4 * (g > 0 ? g - 1 : 0) + 3], 63);
                 const u32 lo_in = (1u << clamp04(p_rel - i0, 0, 4)) - 1u;        // records before p
                 const u32 in4 = ((1u << clamp04(te_rel - i0, 0, 4)) - 1u) & ~lo_in;
                 const u32 own4 = ((1u << clamp04(c1_rel - i0, 0, 4)) - 1u) & ~lo_in;
                 const u32 cnt4 = ((1u << clamp04(cnt_hi - i0, 0, 4)) - 1u) &
                                  ~((1u << clamp04(cnt_lo - i0, 0, 4)) - 1u);
-                u32 prev = g == 0 ? (lane == 0 ? base - 1u : up0) : (lane == 0 ? last0 : up1);
+                u32 prev = lane == 0 ? wrap : up;
                 u32 ok4 = 0, head4 = 0, big4 = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -300,10 +310,10 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
         {   // a head at record x starts its read and ends the one before it; stored as table-slot offsets
             unsigned short* sh = reinterpret_cast<unsigned short*>(L.seg);
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
+            for (int k = 0; k < RPL; ++k)
                 if ((m_head >> k & 1u) && r_rl[k] <= (u32)WMAXR) {
-                    // tslot(4*lane + c) = 6*lane + tslot(c): one add per record
-                    const unsigned short x = (unsigned short)(6u * lane + tslot((k & 3) + (k >> 2) * (WT / 2)));
+                    // tslot(4*lane + c) = 6*lane + tslot(c) for even-multiple-of-4 offsets: one add per record
+                    const unsigned short x = (unsigned short)(6u * lane + tslot((k & 3) + (k >> 2) * 256));
                     sh[2 * r_rl[k] + 2] = x;                           // start of read rl   (seg is indexed rl + 1)
                     sh[2 * r_rl[k] + 1] = x;                           // end of read rl - 1 (lands in the unused seg[0] for rl = 0)
                 }
@@ -317,13 +327,13 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
         const bool last_complete = (te == A.n);                  // batches end on a read boundary
         const u32 nrc = last_complete ? nr : (nr ? nr - 1u : 0u);
         const u32 nproc = min(min(nrc, nown), (u32)WMAXR);
-        // Reads finished in this tile get their table geometry packed once: first slot (10 bits) | end slot (10) | mask of
-        // the largest power of two within the range (10).  Probing starts at first + (locus & mask): the loci of a read are
+        // Reads finished in this tile get their table geometry packed once: first slot (SBITS bits) | end slot (SBITS) | mask of
+        // the largest power of two within the range (10 bits).  Probing starts at first + (locus & mask): the loci of a read are
         // mostly consecutive target ids, which low bits never collide on -- cheaper than a multiplicative hash and the
         // collision path below becomes rare.
         if (lane < nproc) {
             const u32 sg = L.seg[lane + 1], s2 = sg & 0xFFFFu, e2 = sg >> 16;
-            L.seg[lane + 1] = s2 | (e2 << 10) | (((1u << (31 - __clz((int)(e2 - s2)))) - 1u) << 20);
+            L.seg[lane + 1] = s2 | (e2 << SBITS) | (min((1u << (31 - __clz((int)(e2 - s2)))) - 1u, 0x3FFu) << (2 * SBITS));
         }
         wave_sync();
         const bool done = (te >= c1 && nown <= nproc);           // every read that starts in our slice
@@ -354,19 +364,19 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
         // A lane whose CAS created an entry queues it; every entry is hashed once when all masks are final.
         u32 n_ent = 0;
         if (!(A.ablate & 1u)) {
-            u32 q[8], old[8], act = 0, coll = 0;
+            u32 q[RPL], old[RPL], act = 0, coll = 0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < RPL; ++k) {
                 const u32 on = (m_ok >> k) & (u32)(r_rl[k] < nproc) & 1u;
                 act |= on << k;
                 const u32 sg = L.seg[on ? r_rl[k] + 1u : 0u];
-                q[k] = (sg & 0x3FFu) + (r_key[k] & (sg >> 20));
+                q[k] = (sg & SMASK) + (r_key[k] & (sg >> (2 * SBITS)));
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
+            for (int k = 0; k < RPL; ++k)
                 if (act >> k & 1u) old[k] = atomicCAS(&L.tkey[q[k]], 0u, r_key[k]);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < RPL; ++k) {
                 const bool on = act >> k & 1u;
                 const bool made = on && old[k] == 0u;                // this lane created the (read, locus) entry
                 const bool hit = made || (on && old[k] == r_key[k]);
@@ -374,16 +384,16 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
                 if (hit) atomicOr(&L.tmask[q[k]], r_bit[k]);         // duplicate (read, target) records vanish here: bam_utils.py:322-325
                 const u64 mm = __ballot(made);
                 if (made) L.ent[n_ent + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u))] =
-                    (unsigned short)(q[k] | (r_rl[k] << 10));
+                    q[k] | (r_rl[k] << SBITS);
                 n_ent += (u32)__popcll(mm);
             }
             if (__ballot(coll != 0u)) {                              // slot taken by another locus of the read: probe on (rare)
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < RPL; ++k) {
                     bool made = false;
                     if (coll >> k & 1u) {
                         const u32 sg = L.seg[r_rl[k] + 1u];
-                        const u32 s2 = sg & 0x3FFu, e2 = (sg >> 10) & 0x3FFu;
+                        const u32 s2 = sg & SMASK, e2 = (sg >> SBITS) & SMASK;
                         u32 o;
                         do {
                             if (++q[k] == e2) q[k] = s2;
@@ -394,14 +404,14 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
                     }
                     const u64 mm = __ballot(made);
                     if (made) L.ent[n_ent + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u))] =
-                        (unsigned short)(q[k] | (r_rl[k] << 10));
+                        q[k] | (r_rl[k] << SBITS);
                     n_ent += (u32)__popcll(mm);
                 }
             }
         }
         wave_sync();
         for (u32 e = lane; e < n_ent; e += 64) {
-            const u32 en = L.ent[e], qq = en & 0x3FFu, rl = en >> 10;
+            const u32 en = L.ent[e], qq = en & SMASK, rl = en >> SBITS;
             u64 a, b;
             pair_hash64(L.tkey[qq] - 1u, L.tmask[qq], a, b);
             atomicAdd(&L.acc[rl][0], a); atomicAdd(&L.acc[rl][1], b);
@@ -419,7 +429,7 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
             if (on && A.verify) {                                   // exactness pass: set of this read == key of its EC ?
                 const Slot s = A.table[A.read_slot[rd]];
                 bool same = s.n == L.npair[lane];
-                const u32 b2 = L.seg[lane + 1] & 0x3FFu, f2 = (L.seg[lane + 1] >> 10) & 0x3FFu;
+                const u32 b2 = L.seg[lane + 1] & SMASK, f2 = (L.seg[lane + 1] >> SBITS) & SMASK;
                 for (u32 t = b2; t < f2 && same; ++t) {
                     const u32 kk = L.tkey[t];
                     if (!kk) continue;
@@ -441,7 +451,7 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
                     if (slot == ~0ull) {                            // table too full here: defer the read, park
                         atomicExch(&A.ctr->full, 1u);
                         const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
-                        if (qi < A.queue_cap) A.queue[qi] = tb + unslot(L.seg[lane + 1] & 0x3FFu); else atomicOr(&A.ctr->err, ERR_QUEUE);
+                        if (qi < A.queue_cap) A.queue[qi] = tb + unslot(L.seg[lane + 1] & SMASK); else atomicOr(&A.ctr->err, ERR_QUEUE);
                     } else {
                         A.read_slot[rd] = (u32)slot;
                     }
@@ -463,7 +473,7 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
                 if (created && !(bad & ERR_ARENA)) {
                     u64 off = chunk_at + (incl - want);
                     A.table[slot].off = (u32)off; A.table[slot].n = np;
-                    const u32 b2 = L.seg[lane + 1] & 0x3FFu, f2 = (L.seg[lane + 1] >> 10) & 0x3FFu;
+                    const u32 b2 = L.seg[lane + 1] & SMASK, f2 = (L.seg[lane + 1] >> SBITS) & SMASK;
                     for (u32 t = b2; t < f2; ++t) {
                         const u32 kk = L.tkey[t];
                         if (kk) A.arena[off++] = make_uint2(kk - 1u, L.tmask[t]);
