@@ -4,8 +4,8 @@
 
 One "step" = one whole pass of the hot path over the workload's record tuples, already
 resident in HBM: reset the EC table, stream every record through libecb's k_stream kernel
-(filter, read segmentation, per-read target sets, EC hash-reduce), exchange + merge the
-per-GPU EC tables when N > 1 (RCCL all-gather), rank ECs by first appearance and emit CSR A / N.
+(filter, read segmentation, per-read target sets, EC lookup/insert), count reads per EC (k_count), exchange + merge
+the per-GPU EC tables when N > 1 (RCCL point-to-point to rank 0), rank ECs by first appearance and emit CSR A / N.
 
 Workload (default): BASELINE config 3 -- 100 M paired-end reads, 8 haplotypes x 80 k
 transcripts (~3.3 G BAM records, ~40 GB of tuples), synthetic (alntools_amd/synth.py, seed
@@ -109,9 +109,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X: libecb has no CPU path")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("ECB_FORCE_DIST"))   # ECB_FORCE_DIST: exercise the RCCL path at N = 1
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     R, T, H, paired, desc = WORKLOADS[args.workload]
     spec = synth.SynthSpec(R, T, H, paired=paired)
@@ -126,7 +129,7 @@ def main():
     b = ecb.EcBuilder(T, H, device=local, ec_capacity=ec_cap, arena_capacity=1 << 26)
     eng = ecdist.GpuEngine(b, device)
     root_eng = None
-    if world > 1 and rank == 0:
+    if use_dist and rank == 0:
         root_eng = ecdist.GpuEngine(ecb.EcBuilder(T, H, device=local, ec_capacity=ec_cap, arena_capacity=1 << 26), device)
 
     def make_root():
@@ -138,7 +141,7 @@ def main():
     def step():
         b.reset()
         b.push_device(rid, loc, hf)
-        if world > 1:
+        if use_dist:
             m = ecdist.exchange_and_merge(eng, make_root, root=0)
             if m is not None:
                 sizes.update(m.b.finalize())
@@ -152,7 +155,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -168,13 +171,13 @@ def main():
     k_ms, k_launches, _ = b.profile_read()
     b.profile(False)
     exact = None
-    if world == 1 and not os.environ.get("ECB_ABLATE") and not os.environ.get("ECB_NO_VERIFY"):
+    if not use_dist and not os.environ.get("ECB_ABLATE") and not os.environ.get("ECB_NO_VERIFY"):
         # outside the timed region: re-derive every read's target set and compare it with its EC's stored key
         b.reset()
         b.push_device(rid, loc, hf)
         bad, skipped = b.verify_device(rid, loc, hf)
         exact = {"reads_differing_from_their_ec_key": bad, "reads_not_rechecked": skipped}
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt[0])
@@ -213,7 +216,7 @@ def main():
             "config": {"workload": desc, "reads": R, "loci": T, "haplotypes": H, "paired_end": paired,
                        "records": total_records, "valid_alignments": total_valid, "reads_with_alignments": total_reads,
                        "ecs": sizes.get("n_ecs"), "nnz_a": sizes.get("nnz_a"),
-                       "sharding": "contiguous reads over %d GPU(s)%s" % (world, ", RCCL all-gather EC-table merge on rank 0" if world > 1 else ""),
+                       "sharding": "contiguous reads over %d GPU(s)%s" % (world, ", per-rank EC tables sent point-to-point over RCCL and merged in rank order on rank 0" if world > 1 else ""),
                        "generate_s": round(t_gen, 2), "exactness_pass": exact},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -221,10 +224,10 @@ def main():
                          "launches_per_step": launches_per_step,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not use_dist and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rid, loc, hf, H, min(args.cpu_sample_reads, st["reads"]))
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
