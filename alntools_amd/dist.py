@@ -70,7 +70,7 @@ def exchange_and_merge(engine, make_root_engine, group=None, root=0):
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
         return None
-    bufs, ops = {}, []
+    bufs, ops, owner = {}, [], []
     for r in range(world):
         e_r, p_r = sizes[r][0], sizes[r][1]
         if r == root or not e_r:
@@ -78,21 +78,28 @@ def exchange_and_merge(engine, make_root_engine, group=None, root=0):
         bufs[r] = (torch.empty(e_r * ENTRY_WORDS, dtype=torch.int64, device=dev),
                    torch.empty(max(p_r, 1) * PAIR_WORDS, dtype=torch.int64, device=dev))
         ops.append(dist.P2POp(dist.irecv, bufs[r][0], r, group))
+        owner.append(r)
         if p_r:
             ops.append(dist.P2POp(dist.irecv, bufs[r][1][:p_r * PAIR_WORDS], r, group))
+            owner.append(r)
     reqs = dist.batch_isend_irecv(ops) if ops else []
+    if len(reqs) != len(owner):                  # some backends hand back one request for the whole batch
+        for req in reqs:
+            req.wait()
+        reqs, owner = [], []
     merged = make_root_engine()
-    for req in reqs:
-        req.wait()
-    if dev.type == "cuda":
-        torch.cuda.synchronize(dev)
-    for r in range(world):                      # rank order = stream order
+    for r in range(world):                      # rank order = stream order; later tables keep arriving while we merge
         e_r, p_r = sizes[r][0], sizes[r][1]
         if not e_r:
             continue
         if r == root:
             merged.table_merge(ent, e_r, prs, p_r)
-        else:
-            merged.table_merge(bufs[r][0], e_r, bufs[r][1], p_r)
+            continue
+        for req, o in zip(reqs, owner):
+            if o == r:
+                req.wait()
+        if dev.type == "cuda":
+            torch.cuda.current_stream(dev).synchronize()
+        merged.table_merge(bufs[r][0], e_r, bufs[r][1], p_r)
     merged.add_counters(sum(s[3] for s in sizes), sum(s[4] for s in sizes), sum(s[2] for s in sizes))
     return merged
