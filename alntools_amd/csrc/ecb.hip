@@ -148,7 +148,7 @@ __device__ __forceinline__ u64 table_find_or_insert(Slot* table, u64 cap_mask, u
 #define ECB_RPL 8
 #endif
 constexpr int RPL = ECB_RPL;         // records per lane per tile: groups of 4 consecutive records (one 16-byte load per stream)
-static_assert(RPL == 8, "only 8 records per lane is validated (16 was measured: 233 VGPRs, 2 waves/SIMD, 11-25 % slower)");
+static_assert(RPL == 8, "only 8 records per lane is validated (16 was measured: 233 VGPRs, 2 waves/SIMD, 11-25 % slower; it also needs a 32-bit ent[])");
 constexpr int NG = RPL / 4;          // groups; group g of lane l holds records 256 g + 4 l .. + 3 of the tile
 constexpr int WT = 64 * RPL;         // records per wave tile
 constexpr int WMAXR = 64;            // reads finished per wave tile (one lane each in phase (c))
@@ -160,7 +160,7 @@ struct alignas(16) WaveLds {
     u32 tkey[TSLOTS];                // per-read {locus -> mask} tables, 1.5 slots per record of the read; key = locus + 1
     u32 tmask[TSLOTS];               // (contiguous with tkey: cleared together with 16-byte stores)
     u64 acc[WMAXR][2];               // per read: set-hash sums (2 x 64 bits)
-    u32 ent[WT];                     // table entries created in this tile: slot | read << SBITS
+    unsigned short ent[WT];          // table entries created in this tile: slot | read << 10 (SBITS = 10 at 8 records per lane)
     unsigned short npair[WMAXR];     // per read: number of (locus, mask) pairs
     u32 seg[WMAXR + 3];              // seg[rl + 1]: first table slot of read rl | end slot << 16; repacked for finished reads
 };
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
                 if (hit) atomicOr(&L.tmask[q[k]], r_bit[k]);         // duplicate (read, target) records vanish here: bam_utils.py:322-325
                 const u64 mm = __ballot(made);
                 if (made) L.ent[n_ent + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u))] =
-                    q[k] | (r_rl[k] << SBITS);
+                    (unsigned short)(q[k] | (r_rl[k] << SBITS));
                 n_ent += (u32)__popcll(mm);
             }
             if (__ballot(coll != 0u)) {                              // slot taken by another locus of the read: probe on (rare)
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
                     }
                     const u64 mm = __ballot(made);
                     if (made) L.ent[n_ent + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u))] =
-                        q[k] | (r_rl[k] << SBITS);
+                        (unsigned short)(q[k] | (r_rl[k] << SBITS));
                     n_ent += (u32)__popcll(mm);
                 }
             }

@@ -126,11 +126,11 @@ def _worker(rank, world, port, spec_args, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("paired", [False, True])
-def test_two_rank_merge_equals_single_process(tmp_path, paired):
+@pytest.mark.parametrize("world,paired", [(2, False), (2, True), (3, True)])
+def test_multi_rank_merge_equals_single_process(tmp_path, world, paired):
     spec_args = dict(n_reads=3000, n_loci=300, n_haps=4, paired=paired)
     out = str(tmp_path / "merged.npz")
-    mp.spawn(_worker, args=(2, _free_port(), spec_args, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), spec_args, out), nprocs=world, join=True)
     got = np.load(out)
     spec = synth.SynthSpec(**spec_args)
     t = synth.generate(spec, 0, spec.n_reads)
