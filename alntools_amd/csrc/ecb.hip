@@ -153,7 +153,14 @@ constexpr int NG = RPL / 4;          // groups; group g of lane l holds records 
 constexpr int WT = 64 * RPL;         // records per wave tile
 constexpr int WMAXR = 64;            // reads finished per wave tile (one lane each in phase (c))
 constexpr int NWAVE = TPB / 64;
-constexpr int TSLOTS = WT + WT / 2;  // LDS table slots per wave tile: 1.5 per record
+#ifndef ECB_SLOT_SHIFT
+#define ECB_SLOT_SHIFT 1
+#endif
+#ifndef ECB_WAVES_PER_SIMD
+#define ECB_WAVES_PER_SIMD 4
+#endif
+constexpr int SLOT_SHIFT = ECB_SLOT_SHIFT;           // table slots per record = 1 + 2^-SLOT_SHIFT (1: 1.5, 2: 1.25)
+constexpr int TSLOTS = WT + (WT >> SLOT_SHIFT);      // LDS table slots per wave tile
 constexpr u32 SBITS = (TSLOTS <= 1024) ? 10 : 11;   // bits of a table-slot index
 constexpr u32 SMASK = (1u << SBITS) - 1u;
 struct alignas(16) WaveLds {
@@ -164,8 +171,11 @@ struct alignas(16) WaveLds {
     unsigned short npair[WMAXR];     // per read: number of (locus, mask) pairs
     u32 seg[WMAXR + 3];              // seg[rl + 1]: first table slot of read rl | end slot << 16; repacked for finished reads
 };
-__device__ __forceinline__ u32 tslot(u32 rec) { return rec + (rec >> 1); }   // first table slot of a read starting at `rec`
-__device__ __forceinline__ u32 unslot(u32 t) { const u32 m = (t * 683u) >> 11; return 2u * m + (t - 3u * m); }   // inverse, t < 4096
+__device__ __forceinline__ u32 tslot(u32 rec) { return rec + (rec >> SLOT_SHIFT); }   // first table slot of a read starting at `rec`
+__device__ __forceinline__ u32 unslot(u32 t) {                                          // inverse, t < 1024
+    if (SLOT_SHIFT == 1) { const u32 m = (t * 683u) >> 11; return 2u * m + (t - 3u * m); }
+    const u32 m = (t * 205u) >> 10; return 4u * m + (t - 5u * m);
+}
 
 struct StreamArgs {
     const u32* rid; const u32* loc; const u32* hf;
@@ -180,7 +190,6 @@ struct StreamArgs {
     u64* queue; u64 queue_cap;       // head record index of deferred reads
     u64* resume;                     // per wave {next record to process, records counted up to}
     u32* wave_counts;                // per wave {records offered, records valid, ECs created}: summed by k_sum_counts
-    u32 verify;                      // 1: do not insert; compare every read's set with the key of its recorded EC
     u32 ablate;                      // profiling only (env ECB_ABLATE): 1 = stop after (a), 2 = after (b), 4 = no EC table
 };
 
@@ -225,7 +234,9 @@ __device__ __forceinline__ void load_tile(const StreamArgs& A, u64 tb, u64 te, u
     }
 }
 
-__global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
+// VERIFY = false: the hot kernel.  VERIFY = true: the exactness pass (same tiling, compares instead of inserting).
+template <bool VERIFY>
+__global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A) {
     __shared__ WaveLds wl[NWAVE];
     const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     WaveLds& L = wl[w];
@@ -313,7 +324,7 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
             for (int k = 0; k < RPL; ++k)
                 if ((m_head >> k & 1u) && r_rl[k] <= (u32)WMAXR) {
                     // tslot(4*lane + c) = 6*lane + tslot(c) for even-multiple-of-4 offsets: one add per record
-                    const unsigned short x = (unsigned short)(6u * lane + tslot((k & 3) + (k >> 2) * 256));
+                    const unsigned short x = (unsigned short)((4u + (4u >> SLOT_SHIFT)) * lane + tslot((k & 3) + (k >> 2) * 256));
                     sh[2 * r_rl[k] + 2] = x;                           // start of read rl   (seg is indexed rl + 1)
                     sh[2 * r_rl[k] + 1] = x;                           // end of read rl - 1 (lands in the unused seg[0] for rl = 0)
                 }
@@ -426,7 +437,7 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
             bool created = false;
             u32 np = 0;
             const u32 rd = base + lane;
-            if (on && A.verify) {                                   // exactness pass: set of this read == key of its EC ?
+            if (on && VERIFY) {                                     // exactness pass: set of this read == key of its EC ?
                 const Slot s = A.table[A.read_slot[rd]];
                 bool same = s.n == L.npair[lane];
                 const u32 b2 = L.seg[lane + 1] & SMASK, f2 = (L.seg[lane + 1] >> SBITS) & SMASK;
@@ -481,7 +492,7 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
                 }
                 if (!(bad & ERR_ARENA)) { chunk_at += total; chunk_left -= total; }
             }
-            if (!A.verify) my_new += (u32)__popcll(__ballot(created));
+            if (!VERIFY) my_new += (u32)__popcll(__ballot(created));
         }
         wave_sync();
 
@@ -493,7 +504,7 @@ __global__ __launch_bounds__(TPB, 4) void k_stream(StreamArgs A) {
     // records offered / valid: one atomic pair per wave
     const u32 wa = wave_sum(my_all), wv = wave_sum(my_valid);
     // per-wave totals go to their own words: thousands of waves adding to three shared counters serialise (~50 ns each)
-    const u32 wn = A.verify ? wave_sum(my_new) : my_new;
+    const u32 wn = VERIFY ? wave_sum(my_new) : my_new;
     if (lane == 0) { A.wave_counts[3 * wid] = wa; A.wave_counts[3 * wid + 1] = wv; A.wave_counts[3 * wid + 2] = wn; }
 }
 
@@ -1234,7 +1245,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
     // One contiguous slice per wave; ECB_ROUNDS x as many waves as are resident at once (a launch of 1.25 rounds costs 2).
     int bpc = 4;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_stream, TPB, 0);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_stream<false>, TPB, 0);
     const u64 rounds = getenv("ECB_ROUNDS") ? std::max(1, atoi(getenv("ECB_ROUNDS"))) : 4;
     u64 waves = (u64)cus * std::max(bpc, 1) * NWAVE * rounds;
     waves = std::min<u64>(waves, (n + 2 * WT - 1) / (2 * WT));
@@ -1264,7 +1275,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     u32* d_wcounts = nullptr;
     POOL(h, P_WCOUNTS, d_wcounts, 3 * waves);
     StreamArgs a{d_rid, d_loc, d_hf, n, chunk, h->prev_rid, h->cfg.n_loci, h->cfg.n_haplotypes,
-                 h->table, h->cap - 1, h->arena, h->arena_cap, 0, h->ctr, h->read_slot, h->queue, h->queue_cap, d_resume, d_wcounts, 0u,
+                 h->table, h->cap - 1, h->arena, h->arena_cap, 0, h->ctr, h->read_slot, h->queue, h->queue_cap, d_resume, d_wcounts,
                  getenv("ECB_ABLATE") ? (u32)atoi(getenv("ECB_ABLATE")) : 0u};
     for (;;) {
         HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));   // per launch
@@ -1279,7 +1290,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
         }
         HIPCHK(h, hipMemsetAsync(d_wcounts, 0, 3 * waves * sizeof(u32), h->stream));
         if (h->prof) hipEventRecord(h->ev0, h->stream);
-        k_stream<<<(unsigned)blocks, TPB, 0, h->stream>>>(a);
+        k_stream<false><<<(unsigned)blocks, TPB, 0, h->stream>>>(a);
         if (h->prof) hipEventRecord(h->ev1, h->stream);
         k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, waves, h->ctr);
         HIPCHK(h, hipGetLastError());
@@ -1479,7 +1490,7 @@ int ecb_verify_device(ecb_handle* h, const void* d_read_id, const void* d_locus,
     const Counters before = h->hctr;
     int cus = 256, bpc = 4;
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_stream, TPB, 0);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_stream<false>, TPB, 0);
     u64 waves = std::min<u64>((u64)cus * std::max(bpc, 1) * NWAVE * 4, (n + 2 * WT - 1) / (2 * WT));
     waves = std::max<u64>(waves, 1);
     u64 chunk = ((n + waves - 1) / waves + 3) & ~(u64)3;
@@ -1500,8 +1511,8 @@ int ecb_verify_device(ecb_handle* h, const void* d_read_id, const void* d_locus,
     }
     StreamArgs a{(const u32*)d_read_id, (const u32*)d_locus, (const u32*)d_hapflag, n, chunk, 0xFFFFFFFFu,
                  h->cfg.n_loci, h->cfg.n_haplotypes, h->table, h->cap - 1, h->arena, h->arena_cap, h->arena_cap, h->ctr,
-                 h->read_slot, h->queue, h->queue_cap, d_resume, d_wcounts, 1u, 0u};
-    k_stream<<<(unsigned)blocks, TPB, 0, h->stream>>>(a);
+                 h->read_slot, h->queue, h->queue_cap, d_resume, d_wcounts, 0u};
+    k_stream<true><<<(unsigned)blocks, TPB, 0, h->stream>>>(a);
     k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, waves, h->ctr);
     rc = sync_counters(h);
     if (rc != ECB_OK) return rc;
