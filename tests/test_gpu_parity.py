@@ -356,3 +356,51 @@ def test_sparse_format_round_trip_at_scale():
         assert np.all((d > 0) | brk[1:])
     ip2, ix2, da2 = ecb.hapcsc_to_csr(cptr, cidx, s["n_ecs"])
     assert torch.equal(ip2, ip) and torch.equal(ix2, ix) and torch.equal(da2, da)
+
+
+def _random_stream(seed, n_reads, n_loci, n_haps, max_len, p_invalid, loci_mode):
+    """Unstructured tuples: random read lengths, loci drawn to collide in the LDS tables, duplicate records,
+    invalid records anywhere (also first and last), every haplotype index up to n_haps - 1."""
+    rng = np.random.RandomState(seed)
+    rid, loc, hf = [], [], []
+    cur = -1
+    for _ in range(n_reads):
+        L = int(rng.randint(1, max_len + 1))
+        if loci_mode == "strided":            # congruent low bits: worst case for the low-bit probe start
+            pool = (rng.randint(0, max(n_loci // 64, 1)) * 64 + 64 * np.arange(8)) % n_loci
+        elif loci_mode == "wide":
+            pool = rng.randint(0, n_loci, size=max(L, 1))
+        else:
+            base = rng.randint(0, n_loci)
+            pool = (base + np.arange(4)) % n_loci
+        started = False
+        for _ in range(L):
+            valid = rng.rand() >= p_invalid
+            if valid and not started:
+                cur += 1
+                started = True
+            flag = 0x10 if rng.rand() < 0.5 else 0
+            if not valid:
+                flag = 0x4 if rng.rand() < 0.5 else (0x1 | 0x40)          # unmapped, or paired but not proper
+            rid.append(cur if cur >= 0 else 0xFFFFFFFF)
+            loc.append(int(pool[rng.randint(len(pool))]))
+            hf.append(flag | (int(rng.randint(n_haps)) << 16))
+    return dict(read_id=np.array(rid, dtype=np.uint64).astype(np.uint32), locus=np.array(loc, dtype=np.uint32),
+                hapflag=np.array(hf, dtype=np.uint32), pos=np.zeros(len(rid), np.int32))
+
+
+@pytest.mark.parametrize("seed,n_loci,n_haps,max_len,p_inv,mode", [
+    (1, 50, 1, 60, 0.1, "wide"),                 # one haplotype: every record a new locus, tables at their fullest
+    (2, 1 << 20, 31, 40, 0.2, "strided"),        # 31 haplotypes (bit 30 set), loci congruent mod 64
+    (3, (1 << 27) - 1, 8, 200, 0.05, "wide"),    # the largest locus index the key packing allows; long reads
+    (4, 300, 4, 12, 0.5, "near"),                # half the records invalid
+    (5, 7, 2, 3, 0.0, "near"),                   # tiny reads: more than 64 reads per tile
+])
+def test_random_streams_match_the_c_oracle(seed, n_loci, n_haps, max_len, p_inv, mode):
+    from oracle import c_oracle
+    t = _random_stream(seed, 6000, n_loci, n_haps, max_len, p_inv, mode)
+    exp = c_oracle.ec_from_tuples(t["read_id"], t["locus"], t["hapflag"], n_haps, threads=2)
+    for batch in (None, 777):
+        out, sizes = _run_host(t, n_loci, n_haps, batch=batch)
+        _check(out, sizes, exp)
+        assert sizes["n_reads"] == exp["n_reads"]
