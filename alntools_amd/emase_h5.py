@@ -7,9 +7,10 @@ Logical layout: root attrs ``incidence_only``, ``mtype='csc_matrix'``, ``shape=(
 ``/lengths`` (T x H); ``/count`` (vector, or group indptr/indices/data when 2-D); attr ``hname``;
 arrays ``/lname``, ``/rname``, ``/sname``.
 
-PyTables (the reference's writer) and h5py are both absent from this image, so this module can only
-run where one of them is installed; the byte/attribute-level structure PyTables produces is NOT
-pinned by any fixture ("parity unpinned: .h5").
+PyTables (the reference's writer) and h5py are both absent from this image; the fallback is a ctypes binding of
+libhdf5 itself (``h5lite.py``), which writes the same groups, datasets (chunked, shuffle + deflate 1) and attributes
+(tuples/lists pickled, as PyTables stores them).  The byte/attribute-level structure PyTables produces is NOT pinned by
+any fixture ("parity unpinned: .h5"): what is tested is the logical round trip .bin -> .h5 -> .bin.
 """
 from __future__ import annotations
 
@@ -26,8 +27,10 @@ def _backend():
         import h5py  # noqa: F401
         return "h5py"
     except ImportError:
-        raise RuntimeError("EMASE .h5 I/O needs PyTables or h5py; neither is installed. "
-                           "Use the .bin (EC format 2) output, which is complete and byte-exact.")
+        pass
+    from . import h5lite
+    h5lite.lib()                       # raises with a clear message if libhdf5 is missing too
+    return "libhdf5"
 
 
 def save(h5file, m, title=None, incidence_only=True):
@@ -60,6 +63,32 @@ def save(h5file, m, title=None, incidence_only=True):
             f.create_carray(f.root, 'lname', obj=np.array(m.lname), title='Locus Names', filters=fil)
             f.create_carray(f.root, 'rname', obj=np.arange(E).astype(str), title='Read Names', filters=fil)
             f.create_carray(f.root, 'sname', obj=np.array(m.sname), title='Sample Names', filters=fil)
+        return
+    if be == "libhdf5":
+        from . import h5lite
+        with h5lite.File(h5file, 'w') as f:
+            f.set_attr('/', 'TITLE', (title or '').encode())
+            f.set_attr('/', 'incidence_only', np.bool_(incidence_only))
+            f.set_attr('/', 'mtype', b'csc_matrix')                  # bytes: the reference's loader calls .decode() on it
+            f.set_attr('/', 'shape', (T, H, E))
+            for h, sp in enumerate(mats):
+                f.create_group('/h%d' % h)
+                f.create_array('/h%d/indptr' % h, sp.indptr.astype('uint32'))
+                f.create_array('/h%d/indices' % h, sp.indices.astype('uint32'))
+                if not incidence_only:
+                    f.create_array('/h%d/data' % h, sp.data.astype(np.float64))
+            f.create_array('/lengths', np.asarray(m.lengths))
+            if m.num_samples == 1:
+                f.create_array('/count', m.dataN.astype(np.float64))
+            else:
+                f.create_group('/count')
+                f.create_array('/count/indptr', m.indptrN.astype('uint32'))
+                f.create_array('/count/indices', m.indicesN.astype('uint32'))
+                f.create_array('/count/data', m.dataN.astype('uint32'))
+            f.set_attr('/', 'hname', list(m.hname))
+            f.create_array('/lname', np.array(m.lname, dtype='S'))
+            f.create_array('/rname', np.arange(E).astype('S'))
+            f.create_array('/sname', np.array(m.sname, dtype='S'))
         return
     import h5py
     with h5py.File(h5file, 'w') as f:
@@ -106,6 +135,19 @@ def load(h5file):
             else:
                 c = cnode.read()
                 N = (np.array([0, E]), np.arange(E), c)
+    elif be == "libhdf5":
+        from . import h5lite
+        with h5lite.File(h5file, 'r') as f:
+            T, H, E = (int(x) for x in f.get_attr('/', 'shape'))
+            parts = [(f.read_array('/h%d/indptr' % h), f.read_array('/h%d/indices' % h)) for h in range(H)]
+            lengths = f.read_array('/lengths')
+            hname = [x.decode() if isinstance(x, bytes) else str(x) for x in f.get_attr('/', 'hname')]
+            lname = [x.decode() for x in f.read_array('/lname')]
+            sname = [x.decode() for x in f.read_array('/sname')]
+            if f.exists('/count/indptr'):
+                N = (f.read_array('/count/indptr'), f.read_array('/count/indices'), f.read_array('/count/data'))
+            else:
+                N = (np.array([0, E]), np.arange(E), f.read_array('/count'))
     else:
         import h5py
         with h5py.File(h5file, 'r') as f:

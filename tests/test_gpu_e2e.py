@@ -108,3 +108,20 @@ def test_plain_c_program_runs_the_hot_path(tmp_path):
                            "-o", exe, "-L", libdir, "-l:libecb.so", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "abi ok (device)" in out.stdout, (out.returncode, out.stdout, out.stderr)
+
+
+def test_bam2emase_then_emase2ec_gives_the_reference_bin(golden_dir, tmp_path):
+    """bam2emase writes the EMASE .h5 (through libhdf5); converting it back with emase2ec must give the very bytes the
+    reference's bam2ec wrote for the same BAM.  (The .h5 container itself is not pinned: PyTables is not installed.)"""
+    from alntools_amd import emase_h5
+    try:
+        emase_h5._backend()
+    except RuntimeError:
+        pytest.skip("no HDF5 library on this box")
+    g = json.load(open(os.path.join(golden_dir, "g1_edge.json")))
+    bam = str(tmp_path / g["sample"])
+    bamio.write_bam(bam, [tuple(r) for r in g["references"]], [tuple(r) for r in g["records"]])
+    h5, back = str(tmp_path / "o.h5"), str(tmp_path / "back.bin")
+    methods.bam2emase(bam, h5)
+    methods.emase2ec(h5, back)
+    assert _bytes(back) == _bytes(os.path.join(golden_dir, "g1_edge.bin"))
