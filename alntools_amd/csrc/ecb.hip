@@ -468,7 +468,8 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                     }
                 }
             }
-            if (__ballot(created)) {                                // rare after the first tiles of a slice
+            const u64 cmask = __ballot(created);
+            if (cmask) {                                            // some read of this tile founded an EC
                 const u32 want = created ? np : 0u;
                 u32 incl = want;
 #pragma unroll
@@ -481,16 +482,24 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                     chunk_at = __shfl(at, 0); chunk_left = take;
                     if (chunk_at + take > A.arena_cap) { bad |= ERR_ARENA; chunk_left = 0; }
                 }
-                if (created && !(bad & ERR_ARENA)) {
-                    u64 off = chunk_at + (incl - want);
-                    A.table[slot].off = (u32)off; A.table[slot].n = np;
-                    const u32 b2 = L.seg[lane + 1] & SMASK, f2 = (L.seg[lane + 1] >> SBITS) & SMASK;
-                    for (u32 t = b2; t < f2; ++t) {
-                        const u32 kk = L.tkey[t];
-                        if (kk) A.arena[off++] = make_uint2(kk - 1u, L.tmask[t]);
+                if (!(bad & ERR_ARENA)) {
+                    const u32 off = (u32)(chunk_at + (incl - want));   // the arena holds < 2^32 pairs (Slot::off)
+                    if (created) { A.table[slot].off = off; A.table[slot].n = np; }
+                    // The key is copied by the whole wave from the tile's entry queue (every (read, locus) entry once, any
+                    // order: rows are sorted when they are emitted), not by the founding lane walking its read's table:
+                    // that serial walk with 1-3 lanes alive was ~400 issue slots per tile, a quarter of the kernel.
+                    for (u32 e0 = 0; e0 < n_ent; e0 += 64) {
+                        const u32 e = e0 + lane;
+                        const u32 en = e < n_ent ? L.ent[e] : 0u, qq = en & SMASK, rl = en >> SBITS;
+                        const u32 o = __shfl(off, rl);                                  // (all lanes: the loop bound is uniform)
+                        if (e < n_ent && (cmask >> rl & 1ull)) {
+                            const u32 was = atomicSub(reinterpret_cast<u32*>(&L.npair[rl & ~1u]), (rl & 1u) ? 0x10000u : 1u);
+                            const u32 pos = ((rl & 1u) ? was >> 16 : was & 0xFFFFu) - 1u;   // a place of its own among the read's pairs
+                            A.arena[(u64)o + pos] = make_uint2(L.tkey[qq] - 1u, L.tmask[qq]);
+                        }
                     }
+                    chunk_at += total; chunk_left -= total;
                 }
-                if (!(bad & ERR_ARENA)) { chunk_at += total; chunk_left -= total; }
             }
             if (!VERIFY) my_new += (u32)__popcll(__ballot(created));
         }
@@ -1531,7 +1540,7 @@ int ecb_reset(ecb_handle* h) {
     if (!h) return ECB_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
     free_results(h);
-    HIPCHK(h, hipMemsetAsync(h->table, 0, h->cap * sizeof(Slot), h->stream));
+    if (!getenv("ECB_KEEP_TABLE")) HIPCHK(h, hipMemsetAsync(h->table, 0, h->cap * sizeof(Slot), h->stream));
     HIPCHK(h, hipMemsetAsync(h->ctr, 0, sizeof(Counters), h->stream));
     if (h->read_slot && h->reads_hi) HIPCHK(h, hipMemsetAsync(h->read_slot, 0xFF, h->reads_hi * sizeof(u32), h->stream));
     if (h->rng_min) {

@@ -173,7 +173,7 @@ class EcBuilder(object):
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             self._lib.ecb_destroy(self._h)
-            self._h = C.c_void_p()
+            self._h = None          # (not C.c_void_p(): at interpreter shutdown the ctypes module may already be gone)
 
     __del__ = close
 
