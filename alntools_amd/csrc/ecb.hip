@@ -191,6 +191,7 @@ struct StreamArgs {
     u64* resume;                     // per wave {next record to process, records counted up to}
     u32* wave_counts;                // per wave {records offered, records valid, ECs created}: summed by k_sum_counts
     u32 ablate;                      // profiling only (env ECB_ABLATE): 1 = stop after (a), 2 = after (b), 4 = no EC table
+    u64* timing;                     // profiling only (-DECB_TIMING): clocks per phase, summed over waves
 };
 
 __device__ __forceinline__ void wave_sync() {   // orders this wave's LDS traffic (lanes run in lockstep)
@@ -210,6 +211,14 @@ __device__ __forceinline__ u32 group_mask(int lo, int hi) {
 }
 
 struct TileRegs { u32 rr[RPL], ll[RPL], hh[RPL]; };
+
+// -DECB_TIMING: profiling build.  Every wave adds up the shader clocks it spends in each phase of a tile (stalls are
+// charged to the phase whose s_waitcnt sits them out); k_stream adds them into StreamArgs::timing[8].
+#ifdef ECB_TIMING
+#define TICK(i) do { const u64 t_ = __builtin_readcyclecounter(); tacc[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define TICK(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ void load_tile(const StreamArgs& A, u64 tb, u64 te, u32 lane, TileRegs& R) {
 #pragma unroll
@@ -253,9 +262,13 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
     load_tile(A, p & ~(u64)3, min((p & ~(u64)3) + (u64)WT, A.n), lane, R);
     u32 parked = __hip_atomic_load(&A.ctr->full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     u32 bad = 0;
+    asm volatile("" : "+v"(parked));          // (settled before the loop: otherwise the loop header carries an s_waitcnt vmcnt(0) that every tile pays)
     u64 chunk_at = A.arena_first + wid * ARENA_FIRST;   // this wave's reservation in the key arena (first one pre-assigned)
     u32 chunk_left = A.arena_first + (wid + 1) * ARENA_FIRST <= A.arena_cap ? ARENA_FIRST : 0u, my_new = 0;
 
+#ifdef ECB_TIMING
+    u64 tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
     while (p < c1) {
         if (parked) break;            // the EC table filled up somewhere: the host grows it and relaunches
         p = ((u64)(u32)__builtin_amdgcn_readfirstlane((u32)(p >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((u32)p);   // (the builtin returns int: no sign extension)
@@ -315,6 +328,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                 m_ok |= ok4 << (4 * g); m_head |= head4 << (4 * g); m_own |= (head4 & own4) << (4 * g);
             }
         }
+        TICK(0);
         if (__ballot(bad != 0u)) break;            // never index LDS with a broken run counter
         const u32 sums = wave_sum(__popc(m_head) | (__popc(m_own) << 16));
         const u32 nr = sums & 0xFFFFu, nown = sums >> 16;         // heads in [p, te) / in [p, c1): ours
@@ -358,6 +372,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
             else { p_next = h; base_next = base + nproc; }
         }
         if (done) p_next = c1;
+        TICK(1);
         // ---- prefetch the next tile while this one is hashed and looked up --------------------------
         TileRegs N;
         u32 parked_next = 0;
@@ -373,6 +388,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
         // ---- (b) per-read {locus -> haplotype mask} tables in LDS ------------------------------------
         // Staged so that the 8 records' LDS round trips overlap: segment reads, CAS on the locus, OR of the bit.
         // A lane whose CAS created an entry queues it; every entry is hashed once when all masks are final.
+        TICK(2);
         u32 n_ent = 0;
         if (!(A.ablate & 1u)) {
             u32 q[RPL], old[RPL], act = 0, coll = 0;
@@ -421,6 +437,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
             }
         }
         wave_sync();
+        TICK(3);
         for (u32 e = lane; e < n_ent; e += 64) {
             const u32 en = L.ent[e], qq = en & SMASK, rl = en >> SBITS;
             u64 a, b;
@@ -430,44 +447,56 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
         }
         wave_sync();
 
+        TICK(4);
         // ---- (c) one lane per read: EC lookup; a new EC gets its key from the read's LDS table ---------
-        if (!(A.ablate & 3u)) {
-            const bool on = lane < nproc;
-            u64 slot = ~0ull;
-            bool created = false;
-            u32 np = 0;
-            const u32 rd = base + lane;
-            if (on && VERIFY) {                                     // exactness pass: set of this read == key of its EC ?
-                const Slot s = A.table[A.read_slot[rd]];
-                bool same = s.n == L.npair[lane];
-                const u32 b2 = L.seg[lane + 1] & SMASK, f2 = (L.seg[lane + 1] >> SBITS) & SMASK;
-                for (u32 t = b2; t < f2 && same; ++t) {
-                    const u32 kk = L.tkey[t];
-                    if (!kk) continue;
-                    bool found = false;
-                    for (u32 i = 0; i < s.n; ++i) {
-                        const uint2 pr = A.arena[s.off + i];
-                        found |= (pr.x == kk - 1u) && (pr.y == L.tmask[t]);
-                    }
-                    same = found;
+        u64 slot = ~0ull;
+        bool created = false;
+        u32 np = 0;
+        const bool on = lane < nproc && !(A.ablate & 3u);
+        const u32 rd = base + lane;
+        if (on && VERIFY) {                                         // exactness pass: set of this read == key of its EC ?
+            const Slot s = A.table[A.read_slot[rd]];
+            bool same = s.n == L.npair[lane];
+            const u32 b2 = L.seg[lane + 1] & SMASK, f2 = (L.seg[lane + 1] >> SBITS) & SMASK;
+            for (u32 t = b2; t < f2 && same; ++t) {
+                const u32 kk = L.tkey[t];
+                if (!kk) continue;
+                bool found = false;
+                for (u32 i = 0; i < s.n; ++i) {
+                    const uint2 pr = A.arena[s.off + i];
+                    found |= (pr.x == kk - 1u) && (pr.y == L.tmask[t]);
                 }
-                if (!same) my_new += 1;                             // (counted as "mismatches" in verify mode)
-            } else if (on) {
-                u64 lo, hi;
-                np = L.npair[lane];
-                finish_hash(L.acc[lane][0], L.acc[lane][1], np, lo, hi);
-                if (A.ablate & 4u) { slot = lo & A.cap_mask; A.read_slot[rd] = (u32)slot; }
-                else {
-                    slot = table_find_or_insert(A.table, A.cap_mask, lo, hi, &created);
-                    if (slot == ~0ull) {                            // table too full here: defer the read, park
-                        atomicExch(&A.ctr->full, 1u);
-                        const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
-                        if (qi < A.queue_cap) A.queue[qi] = tb + unslot(L.seg[lane + 1] & SMASK); else atomicOr(&A.ctr->err, ERR_QUEUE);
-                    } else {
-                        A.read_slot[rd] = (u32)slot;
-                    }
-                }
+                same = found;
             }
+            if (!same) my_new += 1;                                 // (counted as "mismatches" in verify mode)
+        } else if (on) {
+            u64 lo, hi;
+            np = L.npair[lane];
+            finish_hash(L.acc[lane][0], L.acc[lane][1], np, lo, hi);
+            if (A.ablate & 4u) slot = lo & A.cap_mask;
+            else slot = table_find_or_insert(A.table, A.cap_mask, lo, hi, &created);
+        }
+        TICK(5);
+        // Take over the prefetched tile HERE, right behind the lookup's own wait and before this tile issues any store.
+        // vmcnt counts in order: wherever the compiler first touches these registers it waits for everything issued before
+        // that point, and at the end of the tile (where the moves sink to if left alone) or at the top of the next one
+        // (the parked flag) that meant sitting out the round trips of the founders' stores -- ~3000 clocks per tile on C3.
+        R = N; parked = parked_next;
+#pragma unroll
+        for (int k = 0; k < RPL; ++k) {
+            asm volatile("" : "+v"(R.rr[k])); asm volatile("" : "+v"(R.ll[k])); asm volatile("" : "+v"(R.hh[k]));
+        }
+        asm volatile("" : "+v"(parked));
+        if (on && !VERIFY) {
+            if (slot == ~0ull) {                                    // table too full here: defer the read, park
+                atomicExch(&A.ctr->full, 1u);
+                const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
+                if (qi < A.queue_cap) A.queue[qi] = tb + unslot(L.seg[lane + 1] & SMASK); else atomicOr(&A.ctr->err, ERR_QUEUE);
+            } else {
+                A.read_slot[rd] = (u32)slot;
+            }
+        }
+        {
             const u64 cmask = __ballot(created);
             if (cmask) {                                            // some read of this tile founded an EC
                 const u32 want = created ? np : 0u;
@@ -505,8 +534,9 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
         }
         wave_sync();
 
+        TICK(6);
         counted = max(counted, tb + (u64)cnt_hi);
-        p = p_next; base = base_next; R = N; parked = parked_next;
+        p = p_next; base = base_next;
     }
     if (__ballot(bad != 0u)) { if (bad) atomicOr(&A.ctr->err, bad); p = c1; }
     if (lane == 0) { A.resume[2 * wid] = p; A.resume[2 * wid + 1] = counted; }
@@ -514,6 +544,9 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
     const u32 wa = wave_sum(my_all), wv = wave_sum(my_valid);
     // per-wave totals go to their own words: thousands of waves adding to three shared counters serialise (~50 ns each)
     const u32 wn = VERIFY ? wave_sum(my_new) : my_new;
+#ifdef ECB_TIMING
+    if (lane == 0 && A.timing) for (int i = 0; i < 8; ++i) atomicAdd(A.timing + i, tacc[i]);
+#endif
     if (lane == 0) { A.wave_counts[3 * wid] = wa; A.wave_counts[3 * wid + 1] = wv; A.wave_counts[3 * wid + 2] = wn; }
 }
 
@@ -1285,7 +1318,11 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     POOL(h, P_WCOUNTS, d_wcounts, 3 * waves);
     StreamArgs a{d_rid, d_loc, d_hf, n, chunk, h->prev_rid, h->cfg.n_loci, h->cfg.n_haplotypes,
                  h->table, h->cap - 1, h->arena, h->arena_cap, 0, h->ctr, h->read_slot, h->queue, h->queue_cap, d_resume, d_wcounts,
-                 getenv("ECB_ABLATE") ? (u32)atoi(getenv("ECB_ABLATE")) : 0u};
+                 getenv("ECB_ABLATE") ? (u32)atoi(getenv("ECB_ABLATE")) : 0u, nullptr};
+#ifdef ECB_TIMING
+    HIPCHK(h, hipMalloc(&a.timing, 8 * sizeof(u64)));
+    HIPCHK(h, hipMemset(a.timing, 0, 8 * sizeof(u64)));
+#endif
     for (;;) {
         HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));   // per launch
         HIPCHK(h, hipMemsetAsync(&h->ctr->full, 0, sizeof(u32), h->stream));
@@ -1318,6 +1355,17 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
         rc = grow_table(h, h->cap * 4);                 // some workgroups stopped early: more room, then resume
         if (rc != ECB_OK) break;
     }
+#ifdef ECB_TIMING
+    {
+        u64 t[8];
+        hipMemcpy(t, a.timing, sizeof(t), hipMemcpyDeviceToHost); hipFree(a.timing);
+        static const char* nm[8] = {"clear+filter+heads", "seg/geometry", "prefetch issue", "(b) LDS tables", "hash entries", "(c) lookup", "claim", "-"};
+        u64 tot = 0; for (int i = 0; i < 7; ++i) tot += t[i];
+        fprintf(stderr, "[ecb timing] %llu waves, clocks per wave:", (unsigned long long)waves);
+        for (int i = 0; i < 7; ++i) fprintf(stderr, "  %s %.0f (%.1f%%)", nm[i], (double)t[i] / waves, 100.0 * t[i] / std::max<u64>(tot, 1));
+        fprintf(stderr, "\n");
+    }
+#endif
     if (rc != ECB_OK) return rc;
     if (h->prof) h->prof_records += n;
     h->prev_rid = last_rid;
