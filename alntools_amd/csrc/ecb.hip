@@ -198,11 +198,19 @@ __device__ __forceinline__ void wave_sync() {   // orders this wave's LDS traffi
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-__device__ __forceinline__ u32 wave_sum(u32 v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+// Wave-wide sums and scans on the DPP cross-lane paths of the VALU (row_shr within rows of 16 lanes, then row_bcast:15 / :31
+// across rows): six dependent VALU ops instead of six dependent trips through the LDS crossbar (ds_bpermute, which is
+// what __shfl* compile to) -- the latter were ~700 clocks of latency per use.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u32 dpp_add(u32 v) { return v + (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false); }
+__device__ __forceinline__ u32 wave_incl_scan(u32 v) {
+    v = dpp_add<0x111, 0xf>(v); v = dpp_add<0x112, 0xf>(v); v = dpp_add<0x114, 0xf>(v); v = dpp_add<0x118, 0xf>(v);   // row_shr:1,2,4,8
+    v = dpp_add<0x142, 0xa>(v);            // row_bcast:15 -> rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);            // row_bcast:31 -> rows 2 and 3
     return v;
 }
+__device__ __forceinline__ u32 wave_sum(u32 v) { return (u32)__builtin_amdgcn_readlane((int)wave_incl_scan(v), 63); }
+__device__ __forceinline__ u32 lane_above(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }   // wave_shr:1 (lane 0 gets 0)
 __device__ __forceinline__ int clamp04(int x, int, int) { return min(max(x, 0), 4); }   // v_med3_i32
 // bits [lo, hi) of a 4-record group, lo/hi given relative to the group's first record
 __device__ __forceinline__ u32 group_mask(int lo, int hi) {
@@ -296,8 +304,8 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                 const int i0 = g * 256 + 4 * (int)lane;
                 // the record before this group's first: the previous lane's last record of the group, or (lane 0) the
                 // previous group's very last record
-                const u32 up = __shfl_up(R.rr[4 * g + 3], 1);
-                const u32 wrap = g == 0 ? base - 1u : (u32)__shfl(R.rr[4 * (g > 0 ? g - 1 : 0) + 3], 63);
+                const u32 up = lane_above(R.rr[4 * g + 3]);
+                const u32 wrap = g == 0 ? base - 1u : (u32)__builtin_amdgcn_readlane((int)R.rr[4 * (g > 0 ? g - 1 : 0) + 3], 63);
                 const u32 lo_in = (1u << clamp04(p_rel - i0, 0, 4)) - 1u;        // records before p
                 const u32 in4 = ((1u << clamp04(te_rel - i0, 0, 4)) - 1u) & ~lo_in;
                 const u32 own4 = ((1u << clamp04(c1_rel - i0, 0, 4)) - 1u) & ~lo_in;
@@ -500,10 +508,8 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
             const u64 cmask = __ballot(created);
             if (cmask) {                                            // some read of this tile founded an EC
                 const u32 want = created ? np : 0u;
-                u32 incl = want;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(incl, d); if (lane >= (u32)d) incl += t; }
-                const u32 total = __shfl(incl, 63);
+                const u32 incl = wave_incl_scan(want);
+                const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
                 if (total > chunk_left) {                           // reserve another stretch of the key arena
                     const u32 take = max(total, ARENA_CHUNK);
                     u64 at = 0;
