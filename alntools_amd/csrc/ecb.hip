@@ -477,7 +477,8 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                 same = found;
             }
             if (!same) my_new += 1;                                 // (counted as "mismatches" in verify mode)
-        } else if (on) {
+        }
+        else if (on) {
             u64 lo, hi;
             np = L.npair[lane];
             finish_hash(L.acc[lane][0], L.acc[lane][1], np, lo, hi);
