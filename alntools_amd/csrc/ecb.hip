@@ -863,6 +863,87 @@ __global__ void k_export_entries(const Slot* table, const u32* list, u64 n, Slot
     out[e] = s;
 }
 
+// Partitioned export (multi-GPU merge by key range): part of an EC = a few high bits of its key, so every rank sends
+// part p of its table to rank p, rank p merges what it gets, and no EC is ever merged on two ranks.
+constexpr u32 MAX_PARTS = 64;
+__device__ __forceinline__ u32 part_of(u64 lo, u32 n_parts) { return (u32)((lo >> 40) % n_parts); }   // (the low bits pick the table slot)
+
+constexpr u32 PARTS_PER_BLOCK = 16 * TPB;     // entries per workgroup: same-address global atomics cost ~50 ns each, so few of them
+__global__ __launch_bounds__(TPB) void k_parts_count(const Slot* table, const u32* list, u64 n, u32 n_parts, u64* cnt) {
+    __shared__ u32 ce[MAX_PARTS], cp[MAX_PARTS];
+    if (threadIdx.x < MAX_PARTS) { ce[threadIdx.x] = 0; cp[threadIdx.x] = 0; }
+    __syncthreads();
+    const u64 e0 = blockIdx.x * (u64)PARTS_PER_BLOCK, e1 = min(e0 + PARTS_PER_BLOCK, n);
+    for (u64 eb = e0; eb < e1; eb += TPB) {
+        const u64 e = eb + threadIdx.x;
+        u32 q = MAX_PARTS, np = 0;
+        if (e < e1) { const Slot& s = table[list[e]]; q = part_of(s.lo, n_parts); np = s.n; }
+        for (u32 t = 0; t < n_parts; ++t) {          // one LDS atomic per wave and part (few parts = few, hot counters)
+            const u64 m = __ballot(q == t);
+            if (!m) continue;
+            const u32 tot = wave_sum(q == t ? np : 0u);
+            if ((threadIdx.x & 63u) == 0) { atomicAdd(&ce[t], (u32)__popcll(m)); atomicAdd(&cp[t], tot); }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < n_parts) {
+        if (ce[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], (u64)ce[threadIdx.x]);
+        if (cp[threadIdx.x]) atomicAdd(&cnt[n_parts + threadIdx.x], (u64)cp[threadIdx.x]);
+    }
+}
+// cur[0..n_parts) / cur[n_parts..2 n_parts): next free entry / pair of every part (start = the part's offset);
+// pair_base[q] = first pair of part q: Slot::off is written relative to it.  Two walks over the workgroup's entries:
+// count per part, reserve (one global atomic per part), then place.
+__global__ __launch_bounds__(TPB) void k_parts_export(const Slot* table, const u32* list, u64 n, const uint2* arena, u32 n_parts,
+                                                      u64* cur, const u64* pair_base, Slot* out_e, uint2* out_p, u32 read_base) {
+    __shared__ u32 ce[MAX_PARTS], cp[MAX_PARTS];
+    __shared__ u64 be[MAX_PARTS], bp[MAX_PARTS];
+    const u32 lane = threadIdx.x & 63u;
+    const u64 e0 = blockIdx.x * (u64)PARTS_PER_BLOCK, e1 = min(e0 + PARTS_PER_BLOCK, n);
+    for (int pass = 0; pass < 2; ++pass) {
+        if (threadIdx.x < MAX_PARTS) { ce[threadIdx.x] = 0; cp[threadIdx.x] = 0; }
+        __syncthreads();
+        for (u64 eb = e0; eb < e1; eb += TPB) {
+            const u64 e = eb + threadIdx.x;
+            Slot s{};
+            u32 q = MAX_PARTS, re = 0, rp = 0;
+            if (e < e1) { s = table[list[e]]; q = part_of(s.lo, n_parts); }
+            for (u32 t = 0; t < n_parts; ++t) {      // rank within the workgroup: wave prefix + one LDS atomic per wave and part
+                const bool mine = q == t;
+                const u64 m = __ballot(mine);
+                if (!m) continue;
+                const u32 v = mine ? s.n : 0u, incl = wave_incl_scan(v);
+                const u32 tot = (u32)__builtin_amdgcn_readlane((int)incl, 63);   // (read here, with every lane alive: inside the branch below
+                u32 b_e = 0, b_p = 0;                                            //  the compiler sinks the scan's last add under exec = lane 0)
+                if (lane == 0) { b_e = atomicAdd(&ce[t], (u32)__popcll(m)); b_p = atomicAdd(&cp[t], tot); }
+                b_e = (u32)__builtin_amdgcn_readfirstlane((int)b_e); b_p = (u32)__builtin_amdgcn_readfirstlane((int)b_p);
+                if (mine) { re = b_e + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); rp = b_p + incl - v; }
+            }
+            if (pass == 1 && e < e1) {
+                const u64 po = bp[q] + rp;
+                for (u32 t = 0; t < s.n; ++t) out_p[po + t] = arena[s.off + t];
+                s.first_inv = ~(~s.first_inv + read_base);
+                s.off = (u32)(po - pair_base[q]);
+                out_e[be[q] + re] = s;
+            }
+        }
+        __syncthreads();
+        if (pass == 0 && threadIdx.x < n_parts) {
+            be[threadIdx.x] = ce[threadIdx.x] ? atomicAdd(&cur[threadIdx.x], (u64)ce[threadIdx.x]) : 0ull;
+            bp[threadIdx.x] = cp[threadIdx.x] ? atomicAdd(&cur[n_parts + threadIdx.x], (u64)cp[threadIdx.x]) : 0ull;
+        }
+        __syncthreads();
+    }
+}
+// adopt: entries known to be distinct ECs go to consecutive slots of an empty table, keys to the arena, no hashing
+__global__ void k_adopt(const Slot* ent, u64 n, Slot* table, u64 slot_base, u32 arena_base) {
+    const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    Slot s = ent[e];
+    s.off += arena_base;
+    table[slot_base + e] = s;
+}
+
 __global__ __launch_bounds__(TPB) void k_merge(const Slot* ent, u64 n, const uint2* pairs, u64 n_pairs, Slot* table, u64 cap_mask,
                                                uint2* arena, u64 arena_cap, Counters* ctr) {
     const u64 e = blockIdx.x * (u64)TPB + threadIdx.x;
@@ -1127,6 +1208,7 @@ struct ecb_handle {
     std::string err;
     bool finalized = false;
     bool counted = false;             // Slot::count / first_inv hold the reads pushed so far (k_count ran)
+    bool adopted = false;             // the table holds adopted entries in consecutive slots (no hashing): finalize / export only
 
     Slot* table = nullptr; u64 cap = 0;
     uint2* arena = nullptr; u64 arena_cap = 0;
@@ -1155,7 +1237,7 @@ struct ecb_handle {
     ecb_sizes sizes{};
 
     // device scratch reused across calls (grown on demand, freed at destroy)
-    enum { P_RESUME, P_SUMS, P_HIST, P_OFFS, P_PAIRS, P_CNT, P_LIST, P_BITMAP, P_WPOP, P_WPREFIX, P_ROWLEN, P_ORDER,
+    enum { P_RESUME, P_SUMS, P_HIST, P_OFFS, P_PAIRS, P_CNT, P_PARTS, P_LIST, P_BITMAP, P_WPOP, P_WPREFIX, P_ROWLEN, P_ORDER,
            P_WCOUNTS, P_RANK, P_INDPTR, P_COUNTS, P_INDICES, P_DATA, P_MS_KEYS, P_MS_KEYS2, P_MS_VALS, P_MS_VALS2, P_MS_TMP,
            P_MS_FLAG, P_MS_POS, P_MS_OKEY, P_MS_OFIRST, P_MS_OSTART, P_MS_X, P_N };
     void* pool[P_N] = {}; u64 pool_bytes[P_N] = {};
@@ -1608,7 +1690,7 @@ int ecb_reset(ecb_handle* h) {
     h->prev_rid = 0xFFFFFFFFu; h->n_reads = 0; h->reads_hi = 0; h->meta_hi = 0; h->n_triples = 0;
     h->extra_all = h->extra_valid = h->extra_reads = 0;
     h->c_rid.clear(); h->c_loc.clear(); h->c_hf.clear(); h->c_pos.clear();
-    h->finalized = false; h->counted = false; h->sizes = ecb_sizes{}; h->n_list = 0;
+    h->finalized = false; h->counted = false; h->adopted = false; h->sizes = ecb_sizes{}; h->n_list = 0;
     return ECB_OK;
 }
 
@@ -1904,6 +1986,7 @@ int ecb_table_export_device(ecb_handle* h, void* d_entries, void* d_pairs, uint6
 int ecb_table_merge_device(ecb_handle* h, const void* d_entries, uint64_t n_entries, const void* d_pairs, uint64_t n_pairs) {
     if (!h) return ECB_ERR_ARG;
     if (h->finalized) return fail(h, ECB_ERR_STATE, "merge after finalize");
+    if (h->adopted) return fail(h, ECB_ERR_STATE, "merge into a table that adopted entries");
     if (!n_entries) return ECB_OK;
     if (!d_entries || (n_pairs && !d_pairs)) return fail(h, ECB_ERR_ARG, "null table buffers");
     HIPCHK(h, hipSetDevice(h->device));
@@ -1918,6 +2001,74 @@ int ecb_table_merge_device(ecb_handle* h, const void* d_entries, uint64_t n_entr
     rc = sync_counters(h);
     if (rc != ECB_OK) return rc;
     if (h->hctr.n_queue) return fail(h, ECB_ERR_TABLE_FULL, "internal: merge found no slot in a half-empty table");
+    return ECB_OK;
+}
+
+int ecb_table_export_parts_device(ecb_handle* h, void* d_entries, void* d_pairs, uint64_t read_base, uint32_t n_parts,
+                                  uint64_t* entry_offsets, uint64_t* pair_offsets) {
+    if (!h || !d_entries || !d_pairs || !entry_offsets || !pair_offsets) return ECB_ERR_ARG;
+    if (n_parts == 0 || n_parts > MAX_PARTS) return fail(h, ECB_ERR_LIMIT, "1 .. %u parts", MAX_PARTS);
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = sync_counters(h);
+    if (rc != ECB_OK) return rc;
+    if (read_base + h->n_reads >= (1ull << 32) - 1) return fail(h, ECB_ERR_LIMIT, "more than 2^32-2 reads in total");
+    rc = ensure_counts(h);
+    if (rc != ECB_OK) return rc;
+    rc = compact_table(h);
+    if (rc != ECB_OK) return rc;
+    const u64 E = h->n_ecs();
+    u64* d_cnt = nullptr;                              // [0, 2P): counts, then cursors; [2P, 3P): first pair of every part
+    POOL(h, P_PARTS, d_cnt, 3 * (u64)n_parts);
+    HIPCHK(h, hipMemsetAsync(d_cnt, 0, 2 * n_parts * sizeof(u64), h->stream));
+    if (E) k_parts_count<<<nblk(E, PARTS_PER_BLOCK), TPB, 0, h->stream>>>(h->table, h->list, E, n_parts, d_cnt);
+    std::vector<u64> cnt(2 * n_parts), cur(3 * n_parts);
+    HIPCHK(h, hipMemcpyAsync(cnt.data(), d_cnt, 2 * n_parts * sizeof(u64), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    entry_offsets[0] = pair_offsets[0] = 0;
+    for (u32 q = 0; q < n_parts; ++q) {
+        entry_offsets[q + 1] = entry_offsets[q] + cnt[q];
+        pair_offsets[q + 1] = pair_offsets[q] + cnt[n_parts + q];
+        cur[q] = entry_offsets[q]; cur[n_parts + q] = pair_offsets[q]; cur[2 * n_parts + q] = pair_offsets[q];
+    }
+    HIPCHK(h, hipMemcpyAsync(d_cnt, cur.data(), 3 * n_parts * sizeof(u64), hipMemcpyHostToDevice, h->stream));
+    if (E) k_parts_export<<<nblk(E, PARTS_PER_BLOCK), TPB, 0, h->stream>>>(h->table, h->list, E, h->arena, n_parts, d_cnt, d_cnt + 2 * n_parts,
+                                                               (Slot*)d_entries, (uint2*)d_pairs, (u32)read_base);
+    HIPCHK(h, hipStreamSynchronize(h->stream));      // (cur lives on this stack frame)
+    return ECB_OK;
+}
+
+int ecb_table_adopt_device(ecb_handle* h, const void* d_entries, uint64_t n_entries, const void* d_pairs, uint64_t n_pairs) {
+    if (!h) return ECB_ERR_ARG;
+    if (h->finalized) return fail(h, ECB_ERR_STATE, "adopt after finalize");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = sync_counters(h);
+    if (rc != ECB_OK) return rc;
+    if (!h->adopted && (h->n_ecs() || h->n_reads || !h->c_rid.empty()))
+        return fail(h, ECB_ERR_STATE, "adopt needs an empty handle (use ecb_table_merge_device to add to a built table)");
+    if (h->cfg.flags & ECB_F_MULTISAMPLE) return fail(h, ECB_ERR_STATE, "multisample is single-GPU in this build");
+    h->adopted = true; h->counted = true;
+    if (!n_entries) return ECB_OK;
+    if (!d_entries || (n_pairs && !d_pairs)) return fail(h, ECB_ERR_ARG, "null table buffers");
+    const u64 have = h->n_ecs(), top = h->hctr.arena_top;
+    if (top + n_pairs > h->arena_cap || top + n_pairs >= (1ull << 32))
+        return fail(h, ECB_ERR_TABLE_FULL, "EC key arena exhausted (%llu pairs): raise arena_capacity", (unsigned long long)h->arena_cap);
+    if (have + n_entries > h->cap) {                    // consecutive slots: a bigger array and a copy, no rehash
+        u64 nc = h->cap;
+        while (nc < have + n_entries) nc *= 2;
+        Slot* nt = nullptr;
+        HIPCHK(h, hipMalloc(&nt, nc * sizeof(Slot)));
+        HIPCHK(h, hipMemsetAsync(nt, 0, nc * sizeof(Slot), h->stream));
+        HIPCHK(h, hipMemcpyAsync(nt, h->table, have * sizeof(Slot), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipFree(h->table));
+        h->table = nt; h->cap = nc;
+    }
+    k_adopt<<<nblk(n_entries, TPB), TPB, 0, h->stream>>>((const Slot*)d_entries, n_entries, h->table, have, (u32)top);
+    if (n_pairs) HIPCHK(h, hipMemcpyAsync(h->arena + top, d_pairs, n_pairs * sizeof(uint2), hipMemcpyDeviceToDevice, h->stream));
+    h->hctr.n_ecs = have + n_entries; h->hctr.arena_top = top + n_pairs;
+    HIPCHK(h, hipMemcpyAsync(&h->ctr->n_ecs, &h->hctr.n_ecs, sizeof(u64), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&h->ctr->arena_top, &h->hctr.arena_top, sizeof(u64), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return ECB_OK;
 }
 

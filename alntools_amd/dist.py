@@ -1,15 +1,22 @@
 # -*- coding: utf-8 -*-
-"""Multi-GPU EC build: contiguous read shards, one table exchange, ordered merge.
+"""Multi-GPU EC build: contiguous read shards, EC tables merged by key range, one gather.
 
-The reference parallelises over contiguous chunk ranges per process and merges the
-workers' ordered dicts in process order (``alntools/bam_utils.py:646-658, 680-724``), which
-makes EC rank = global first appearance.  Here every rank builds the table of its own
-contiguous read shard, the tables (tens of MB) are sent to the root over RCCL/xGMI (point to point),
-and the root re-inserts them in rank order with ``first = read_base(rank) + local first``.
+The reference parallelises over contiguous chunk ranges per process and merges the workers' ordered dicts in
+process order (``alntools/bam_utils.py:646-658, 680-724``), which makes EC rank = global first appearance.  Here
+every rank builds the table of its own contiguous read shard (``first`` is rebased to the global read numbering on
+export), then
 
-The functions only need an *engine* with ``table_sizes/counters/table_export/table_merge/
-add_counters`` -- :class:`GpuEngine` wraps an :class:`alntools_amd.ecb.EcBuilder`; the CPU
-``gloo`` tests plug in an oracle-backed engine.
+1. every rank cuts its table into ``world`` key ranges (``ecb_table_export_parts_device``) and sends range q to
+   rank q -- point to point over RCCL/xGMI, every pair of GPUs on its own link, ``world - 1`` messages of
+   ``1/world`` of a table each;
+2. rank q merges the ``world`` pieces of range q in rank order (``ecb_table_merge_device``): the hashing and key
+   comparison of the merge is spread over the GPUs instead of queueing on the root;
+3. the merged ranges hold disjoint ECs: they are sent to the root, which loads them without hashing
+   (``ecb_table_adopt_device``) and finalizes (rank by first appearance, CSR emit).
+
+The functions only need an *engine* with ``table_sizes/counters/table_export/table_export_parts/table_merge/
+table_adopt/add_counters`` -- :class:`GpuEngine` wraps an :class:`alntools_amd.ecb.EcBuilder`; the CPU ``gloo`` tests
+plug in an oracle-backed engine.
 """
 from __future__ import annotations
 
@@ -39,6 +46,16 @@ class GpuEngine(object):
         self.b.table_export_device(ent, prs, read_base)
         return ent, prs
 
+    def table_export_parts(self, read_base, n_parts):
+        ne, npairs, _ = self.b.table_sizes()
+        ent = torch.empty(max(ne, 1) * ENTRY_WORDS, dtype=torch.int64, device=self.device)
+        prs = torch.empty(max(npairs, 1) * PAIR_WORDS, dtype=torch.int64, device=self.device)
+        eoff, poff = self.b.table_export_parts_device(ent, prs, read_base, n_parts)
+        return ent, prs, eoff, poff
+
+    def table_adopt(self, ent, n_entries, prs, n_pairs):
+        self.b.table_adopt_device(ent, n_entries, prs, n_pairs)
+
     def table_merge(self, ent, n_entries, prs, n_pairs):
         self.b.table_merge_device(ent, n_entries, prs, n_pairs)
 
@@ -46,11 +63,111 @@ class GpuEngine(object):
         self.b.add_counters(a, v, r)
 
 
-def exchange_and_merge(engine, make_root_engine, group=None, root=0):
+def _p2p(ops):
+    if not ops:
+        return
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+
+
+def exchange_and_merge(engine, make_part_engine, make_root_engine, group=None, root=0):
     """All ranks call this after pushing their shard.  Returns the merged engine on ``root`` (ready to finalize),
-    ``None`` elsewhere.  One small all-gather (sizes), then every rank sends its table straight to the root
-    (point-to-point over xGMI: the 7 peers of an 8-GPU node use 7 different links at once; a ring all-gather would
-    push everything through every link)."""
+    ``None`` elsewhere.  Two small all-gathers (sizes) and two rounds of point-to-point messages; see the module text."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = engine.device
+    ne, npairs, nreads = engine.table_sizes()
+    n_all, n_valid, _ = engine.counters()
+    mine = torch.tensor([ne, npairs, nreads, n_all, n_valid], dtype=torch.int64, device=dev)
+    sizes = torch.empty(world * 5, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes, mine, group=group)
+    sizes = sizes.view(world, 5).cpu().tolist()
+    read_base = sum(s[2] for s in sizes[:rank])
+
+    # 1. cut by key range, range q -> rank q
+    ent, prs, eoff, poff = engine.table_export_parts(read_base, world)
+    cuts = torch.tensor([eoff[q + 1] - eoff[q] for q in range(world)] + [poff[q + 1] - poff[q] for q in range(world)],
+                        dtype=torch.int64, device=dev)
+    allcuts = torch.empty(world * 2 * world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(allcuts, cuts, group=group)
+    allcuts = allcuts.view(world, 2 * world).cpu().tolist()
+    in_e = [allcuts[r][rank] for r in range(world)]
+    in_p = [allcuts[r][world + rank] for r in range(world)]
+    piece_e = [None] * world
+    piece_p = [None] * world
+    ops = []
+    for r in range(world):
+        if r == rank:
+            piece_e[r] = ent[eoff[r] * ENTRY_WORDS:eoff[r + 1] * ENTRY_WORDS]
+            piece_p[r] = prs[poff[r] * PAIR_WORDS:poff[r + 1] * PAIR_WORDS]
+            continue
+        if eoff[r + 1] > eoff[r]:
+            ops.append(dist.P2POp(dist.isend, ent[eoff[r] * ENTRY_WORDS:eoff[r + 1] * ENTRY_WORDS], r, group))
+            if poff[r + 1] > poff[r]:
+                ops.append(dist.P2POp(dist.isend, prs[poff[r] * PAIR_WORDS:poff[r + 1] * PAIR_WORDS], r, group))
+        if in_e[r]:
+            piece_e[r] = torch.empty(in_e[r] * ENTRY_WORDS, dtype=torch.int64, device=dev)
+            piece_p[r] = torch.empty(max(in_p[r], 1) * PAIR_WORDS, dtype=torch.int64, device=dev)
+            ops.append(dist.P2POp(dist.irecv, piece_e[r], r, group))
+            if in_p[r]:
+                ops.append(dist.P2POp(dist.irecv, piece_p[r][:in_p[r] * PAIR_WORDS], r, group))
+    _p2p(ops)
+    if dev.type == "cuda":
+        torch.cuda.current_stream(dev).synchronize()
+
+    # 2. merge my key range, in rank order (= stream order)
+    part = make_part_engine()
+    for r in range(world):
+        if in_e[r]:
+            part.table_merge(piece_e[r], in_e[r], piece_p[r], in_p[r])
+    del piece_e, piece_p, ent, prs
+
+    # 3. the merged ranges are disjoint: gather them on the root, which adopts them as they are
+    pe_n, pp_n, _ = part.table_sizes()
+    pe, pp = part.table_export(0)
+    mine2 = torch.tensor([pe_n, pp_n], dtype=torch.int64, device=dev)
+    sz2 = torch.empty(world * 2, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sz2, mine2, group=group)
+    sz2 = sz2.view(world, 2).cpu().tolist()
+    if rank != root:
+        ops = []
+        if pe_n:
+            ops.append(dist.P2POp(dist.isend, pe[:pe_n * ENTRY_WORDS], root, group))
+            if pp_n:
+                ops.append(dist.P2POp(dist.isend, pp[:pp_n * PAIR_WORDS], root, group))
+        _p2p(ops)
+        if dev.type == "cuda":
+            torch.cuda.current_stream(dev).synchronize()     # keep pe / pp alive until they are on the wire
+        return None
+    bufs, ops = {}, []
+    for r in range(world):
+        e_r, p_r = sz2[r]
+        if r == root or not e_r:
+            continue
+        bufs[r] = (torch.empty(e_r * ENTRY_WORDS, dtype=torch.int64, device=dev),
+                   torch.empty(max(p_r, 1) * PAIR_WORDS, dtype=torch.int64, device=dev))
+        ops.append(dist.P2POp(dist.irecv, bufs[r][0], r, group))
+        if p_r:
+            ops.append(dist.P2POp(dist.irecv, bufs[r][1][:p_r * PAIR_WORDS], r, group))
+    _p2p(ops)
+    if dev.type == "cuda":
+        torch.cuda.current_stream(dev).synchronize()
+    merged = make_root_engine()
+    for r in range(world):
+        e_r, p_r = sz2[r]
+        if not e_r:
+            continue
+        if r == root:
+            merged.table_adopt(pe, e_r, pp, p_r)
+        else:
+            merged.table_adopt(bufs[r][0], e_r, bufs[r][1], p_r)
+    merged.add_counters(sum(s[3] for s in sizes), sum(s[4] for s in sizes), sum(s[2] for s in sizes))
+    return merged
+
+
+def exchange_and_merge_on_root(engine, make_root_engine, group=None, root=0):
+    """The simpler protocol (kept for comparison and as a fallback): every rank sends its whole table to the root, which
+    merges them one after the other.  The root's merges are serial: at 8 ranks they cost more than a rank's own shard."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     ne, npairs, nreads = engine.table_sizes()

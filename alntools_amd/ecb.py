@@ -26,7 +26,8 @@ FLAG_NEXT_POS_NEG = 0x2000
 SYMBOLS = ("ecb_abi_version", "ecb_device_count", "ecb_create", "ecb_destroy", "ecb_reset", "ecb_last_error",
            "ecb_push", "ecb_push_device", "ecb_push_cells", "ecb_verify_device", "ecb_finalize", "ecb_export",
            "ecb_export_device", "ecb_export_ranges", "ecb_export_range_minmax", "ecb_export_pairs", "ecb_export_read_ec", "ecb_table_sizes",
-           "ecb_table_export_device", "ecb_table_merge_device", "ecb_counters", "ecb_add_counters", "ecb_profile",
+           "ecb_table_export_device", "ecb_table_merge_device", "ecb_table_export_parts_device",
+           "ecb_table_adopt_device", "ecb_counters", "ecb_add_counters", "ecb_profile",
            "ecb_profile_read", "ecb_csr_to_hapcsc_device", "ecb_hapcsc_to_csr_device")
 
 
@@ -91,6 +92,8 @@ def load():
     lib.ecb_table_sizes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     lib.ecb_table_export_device.argtypes = [vp, vp, vp, u64]
     lib.ecb_table_merge_device.argtypes = [vp, vp, u64, vp, u64]
+    lib.ecb_table_export_parts_device.argtypes = [vp, vp, vp, u64, C.c_uint32, C.POINTER(u64), C.POINTER(u64)]
+    lib.ecb_table_adopt_device.argtypes = [vp, vp, u64, vp, u64]
     lib.ecb_counters.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     lib.ecb_add_counters.argtypes = [vp, u64, u64, u64]
     lib.ecb_profile.argtypes = [vp, C.c_int]
@@ -280,6 +283,15 @@ class EcBuilder(object):
 
     def table_merge_device(self, entries, n_entries, pairs, n_pairs):
         self._chk(self._lib.ecb_table_merge_device(self._h, _dev_ptr(entries), n_entries, _dev_ptr(pairs), n_pairs))
+
+    def table_export_parts_device(self, entries, pairs, read_base, n_parts):
+        """Export grouped into ``n_parts`` key ranges -> (entry_offsets, pair_offsets), lists of n_parts + 1."""
+        eo, po = (C.c_uint64 * (n_parts + 1))(), (C.c_uint64 * (n_parts + 1))()
+        self._chk(self._lib.ecb_table_export_parts_device(self._h, _dev_ptr(entries), _dev_ptr(pairs), read_base, n_parts, eo, po))
+        return list(eo), list(po)
+
+    def table_adopt_device(self, entries, n_entries, pairs, n_pairs):
+        self._chk(self._lib.ecb_table_adopt_device(self._h, _dev_ptr(entries), n_entries, _dev_ptr(pairs), n_pairs))
 
     def counters(self):
         """-> (all_alignments, valid_alignments, n_reads) so far."""

@@ -5,7 +5,7 @@
 One "step" = one whole pass of the hot path over the workload's record tuples, already
 resident in HBM: reset the EC table, stream every record through libecb's k_stream kernel
 (filter, read segmentation, per-read target sets, EC lookup/insert), count reads per EC (k_count), exchange + merge
-the per-GPU EC tables when N > 1 (RCCL point-to-point to rank 0), rank ECs by first appearance and emit CSR A / N.
+the per-GPU EC tables when N > 1 (by key range, RCCL point-to-point), rank ECs by first appearance and emit CSR A / N.
 
 Workload (default): BASELINE config 3 -- 100 M paired-end reads, 8 haplotypes x 80 k
 transcripts (~3.3 G BAM records, ~40 GB of tuples), synthetic (alntools_amd/synth.py, seed
@@ -128,13 +128,19 @@ def main():
     ec_cap = 1 << int(os.environ.get("ECB_EC_CAP_LOG2", "24" if args.workload in ("c3", "c3h") else "22"))
     b = ecb.EcBuilder(T, H, device=local, ec_capacity=ec_cap, arena_capacity=1 << 26)
     eng = ecdist.GpuEngine(b, device)
-    root_eng = None
-    if use_dist and rank == 0:
-        root_eng = ecdist.GpuEngine(ecb.EcBuilder(T, H, device=local, ec_capacity=ec_cap, arena_capacity=1 << 26), device)
+    root_eng = part_eng = None
+    if use_dist:        # the key range this rank merges (1/world of the ECs), and on rank 0 the table that adopts all ranges
+        part_eng = ecdist.GpuEngine(ecb.EcBuilder(T, H, device=local, ec_capacity=1 << 23, arena_capacity=1 << 26), device)
+        if rank == 0:
+            root_eng = ecdist.GpuEngine(ecb.EcBuilder(T, H, device=local, ec_capacity=1 << 23, arena_capacity=1 << 26), device)
 
     def make_root():
         root_eng.b.reset()
         return root_eng
+
+    def make_part():
+        part_eng.b.reset()
+        return part_eng
 
     sizes = {}
 
@@ -142,7 +148,7 @@ def main():
         b.reset()
         b.push_device(rid, loc, hf)
         if use_dist:
-            m = ecdist.exchange_and_merge(eng, make_root, root=0)
+            m = ecdist.exchange_and_merge(eng, make_part, make_root, root=0)
             if m is not None:
                 sizes.update(m.b.finalize())
         elif os.environ.get("ECB_ABLATE"):      # profiling-only builds of the kernel produce no ECs
@@ -216,7 +222,7 @@ def main():
             "config": {"workload": desc, "reads": R, "loci": T, "haplotypes": H, "paired_end": paired,
                        "records": total_records, "valid_alignments": total_valid, "reads_with_alignments": total_reads,
                        "ecs": sizes.get("n_ecs"), "nnz_a": sizes.get("nnz_a"),
-                       "sharding": "contiguous reads over %d GPU(s)%s" % (world, ", per-rank EC tables sent point-to-point over RCCL and merged in rank order on rank 0" if world > 1 else ""),
+                       "sharding": "contiguous reads over %d GPU(s)%s" % (world, ", per-rank EC tables cut into key ranges, exchanged point-to-point over RCCL, merged per range, gathered on rank 0" if world > 1 else ""),
                        "generate_s": round(t_gen, 2), "exactness_pass": exact},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -154,6 +154,16 @@ int ecb_table_sizes(ecb_handle* h, uint64_t* n_entries, uint64_t* n_pairs, uint6
 int ecb_table_export_device(ecb_handle* h, void* d_entries, void* d_pairs, uint64_t read_base);
 int ecb_table_merge_device(ecb_handle* h, const void* d_entries, uint64_t n_entries,
                            const void* d_pairs, uint64_t n_pairs);
+/* The same merge spread over the ranks (no serial root): ecb_table_export_parts_device writes the table grouped into
+ * n_parts (<= 64) key ranges -- part q = entries [entry_offsets[q], entry_offsets[q+1]) and pairs [pair_offsets[q],
+ * pair_offsets[q+1]), offsets returned in host arrays of n_parts + 1; buffers sized by ecb_table_sizes as above -- so
+ * that rank q receives part q of every rank and merges them (ecb_table_merge_device, in rank order).  The merged parts
+ * hold disjoint ECs: the root loads them with ecb_table_adopt_device (consecutive slots of an EMPTY handle, no hashing;
+ * afterwards that handle only takes more adopts, ecb_add_counters, ecb_finalize and the exports). */
+int ecb_table_export_parts_device(ecb_handle* h, void* d_entries, void* d_pairs, uint64_t read_base, uint32_t n_parts,
+                                  uint64_t* entry_offsets, uint64_t* pair_offsets);
+int ecb_table_adopt_device(ecb_handle* h, const void* d_entries, uint64_t n_entries,
+                           const void* d_pairs, uint64_t n_pairs);
 int ecb_counters(ecb_handle* h, uint64_t* all_alignments, uint64_t* valid_alignments, uint64_t* n_reads);
 int ecb_add_counters(ecb_handle* h, uint64_t all_alignments, uint64_t valid_alignments, uint64_t n_reads);
 

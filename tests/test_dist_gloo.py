@@ -1,6 +1,7 @@
-"""The multi-GPU exchange (alntools_amd/dist.py) at world size 2 on CPU / gloo, with an oracle-backed engine in
-place of libecb: contiguous read shards -> per-rank EC tables -> all-gather -> ordered merge on the root must
-equal the single-process oracle on the whole stream (EC order = global first appearance)."""
+"""The multi-GPU exchange (alntools_amd/dist.py) at world sizes 2 and 3 on CPU / gloo, with an oracle-backed engine in
+place of libecb: contiguous read shards -> per-rank EC tables -> cut by key range, exchanged, merged per range ->
+gathered and adopted on the root must equal the single-process oracle on the whole stream (EC order = global first
+appearance).  The simpler whole-table-to-root protocol is covered as well."""
 import hashlib
 import os
 import socket
@@ -73,10 +74,31 @@ class OracleEngine(object):
             prs += [l | (m << 32) for l, m in pairs]
         return (torch.tensor(ent or [0] * 4, dtype=torch.int64), torch.tensor(prs or [0], dtype=torch.int64))
 
+    def table_export_parts(self, read_base, n_parts):
+        ent, prs, eoff, poff = [], [], [0], [0]
+        for q in range(n_parts):
+            for (lo, hi), (count, first, pairs) in self.table.items():
+                if ((lo & 0xFFFFFFFFFFFFFFFF) >> 40) % n_parts != q:
+                    continue
+                first_inv = (~(first + read_base)) & 0xFFFFFFFF
+                w2 = count | (first_inv << 32)
+                w3 = (len(prs) - poff[q]) | (len(pairs) << 32)          # off relative to the part's pairs
+                ent += [lo, hi, w2 - (1 << 64) if w2 >= (1 << 63) else w2, w3]
+                prs += [l | (m << 32) for l, m in pairs]
+            eoff.append(len(ent) // 4)
+            poff.append(len(prs))
+        return (torch.tensor(ent or [0] * 4, dtype=torch.int64), torch.tensor(prs or [0], dtype=torch.int64), eoff, poff)
+
+    def table_adopt(self, ent, n_entries, prs, n_pairs):
+        before = len(self.table)
+        self.table_merge(ent, n_entries, prs, n_pairs)
+        assert len(self.table) == before + n_entries, "adopted parts must hold distinct ECs"
+
     def table_merge(self, ent, n_entries, prs, n_pairs):
         e = ent.numpy().astype(np.uint64).reshape(-1, 4)[:n_entries]
         p = prs.numpy().astype(np.uint64)
         for lo, hi, w2, w3 in e.tolist():
+            lo, hi = (x - (1 << 64) if x >= (1 << 63) else x for x in (lo, hi))      # keys stay signed 64-bit
             count, first = w2 & 0xFFFFFFFF, (~(w2 >> 32)) & 0xFFFFFFFF
             off, n = w3 & 0xFFFFFFFF, w3 >> 32
             pairs = tuple((int(x) & 0xFFFFFFFF, int(x) >> 32) for x in p[off:off + n])
@@ -107,7 +129,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, spec_args, out_path):
+def _worker(rank, world, port, spec_args, out_path, protocol):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -116,7 +138,11 @@ def _worker(rank, world, port, spec_args, out_path):
     t = synth.generate(spec, rank * R // world, (rank + 1) * R // world)      # local read ids from 0
     eng = OracleEngine(spec.n_haps)
     eng.build(t)
-    merged = ecdist.exchange_and_merge(eng, lambda: OracleEngine(spec.n_haps), root=0)
+    fresh = lambda: OracleEngine(spec.n_haps)
+    if protocol == "ranges":
+        merged = ecdist.exchange_and_merge(eng, fresh, fresh, root=0)
+    else:
+        merged = ecdist.exchange_and_merge_on_root(eng, fresh, root=0)
     if rank == 0:
         c = merged.csr()
         np.savez(out_path, n_all=merged.n_all, n_valid=merged.n_valid, n_reads=merged.n_reads, **c)
@@ -126,11 +152,11 @@ def _worker(rank, world, port, spec_args, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,paired", [(2, False), (2, True), (3, True)])
-def test_multi_rank_merge_equals_single_process(tmp_path, world, paired):
+@pytest.mark.parametrize("world,paired,protocol", [(2, False, "ranges"), (2, True, "ranges"), (3, True, "ranges"), (2, True, "root")])
+def test_multi_rank_merge_equals_single_process(tmp_path, world, paired, protocol):
     spec_args = dict(n_reads=3000, n_loci=300, n_haps=4, paired=paired)
     out = str(tmp_path / "merged.npz")
-    mp.spawn(_worker, args=(world, _free_port(), spec_args, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), spec_args, out, protocol), nprocs=world, join=True)
     got = np.load(out)
     spec = synth.SynthSpec(**spec_args)
     t = synth.generate(spec, 0, spec.n_reads)

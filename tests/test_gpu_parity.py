@@ -216,6 +216,70 @@ def test_mid_size_device_vs_c_oracle_properties(paired):
         assert np.array_equal(out[k], out2[k]), k
 
 
+def test_shard_tables_merged_by_key_range_and_adopted():
+    """The multi-GPU protocol of alntools_amd/dist.py without the collectives, on one GPU: three contiguous read shards,
+    every table cut into three key ranges, range q of all shards merged (in shard order) into its own handle, the three
+    merged ranges adopted by a root handle (tiny capacity: the adopt has to grow its table) == one handle over the
+    whole stream, including EC order.  Also: the ranges hold every entry exactly once, and the states that must refuse."""
+    import torch
+    from alntools_amd import dist as ecdist
+    spec = synth.SynthSpec(60000, 3000, 8, paired=True)
+    dev = torch.device("cuda:0")
+    whole = synth.generate(spec, 0, spec.n_reads)
+    exp = _expect(whole, spec.n_loci, spec.n_haps)
+    cuts = [0, 17000, 25000, spec.n_reads]
+    P = 3
+    pieces, sizes, base = [], [], 0
+    for a, b_ in zip(cuts[:-1], cuts[1:]):
+        t = synth.generate(spec, a, b_, device=dev)
+        b = ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=1 << 12)
+        b.push_device(t["read_id"], t["locus"], t["hapflag"])
+        eng = ecdist.GpuEngine(b, dev)
+        ne, npairs, nreads = b.table_sizes()
+        ent, prs, eoff, poff = eng.table_export_parts(base, P)
+        assert eoff[0] == 0 and eoff[-1] == ne and poff[0] == 0 and all(x <= y for x, y in zip(eoff, eoff[1:]))
+        e = ent[:ne * 4].view(-1, 4)
+        assert int((e[:, 3] >> 32).sum()) == poff[-1]                    # every key pair exported once
+        for q in range(P):                                               # offsets are relative to the part's pairs
+            seg = e[eoff[q]:eoff[q + 1]]
+            if len(seg):
+                assert int(((seg[:, 3] & 0xFFFFFFFF) + (seg[:, 3] >> 32)).max()) <= poff[q + 1] - poff[q]
+        pieces.append((ent, prs, eoff, poff))
+        sizes.append((nreads,) + b.counters()[:2])
+        base += nreads
+        b.close()
+    root = ecdist.GpuEngine(ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=1 << 10), dev)
+    total = 0
+    for q in range(P):
+        part = ecdist.GpuEngine(ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=1 << 12), dev)
+        for ent, prs, eoff, poff in pieces:
+            if eoff[q + 1] > eoff[q]:
+                part.table_merge(ent[eoff[q] * 4:eoff[q + 1] * 4], eoff[q + 1] - eoff[q], prs[poff[q]:poff[q + 1]], poff[q + 1] - poff[q])
+        pe_n, pp_n, _ = part.table_sizes()
+        pe, pp = part.table_export(0)
+        root.table_adopt(pe, pe_n, pp, pp_n)
+        total += pe_n
+        part.b.close()
+    with pytest.raises(ecb.EcbError):
+        root.table_merge(pe, pe_n, pp, pp_n)                             # no hashing into an adopted table
+    with pytest.raises(ecb.EcbError):
+        t = synth.generate(spec, 0, 10, device=dev)
+        root.b.push_device(t["read_id"], t["locus"], t["hapflag"])
+    root.add_counters(sum(s[1] for s in sizes), sum(s[2] for s in sizes), base)
+    s = root.b.finalize()
+    assert s["n_ecs"] == total
+    out = root.b.export()
+    _check(out, s, exp)
+    assert s["n_reads"] == whole["n_reads"]
+    root.b.close()
+    built = ecb.EcBuilder(spec.n_loci, spec.n_haps)
+    t = synth.generate(spec, 0, 100, device=dev)
+    built.push_device(t["read_id"], t["locus"], t["hapflag"])
+    with pytest.raises(ecb.EcbError):
+        built.table_adopt_device(pe, pe_n, pp, pp_n)                     # adopt needs an empty handle
+    built.close()
+
+
 def test_shard_tables_merge_to_the_single_handle_result():
     """Two handles over contiguous read shards, tables exported / merged on one GPU (the multi-GPU protocol
     without the collective) == one handle over the whole stream, including EC order."""

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """GPU box (one GPU): time the pieces of the N-GPU step on ONE card to see where a strong-scaling run spends its time.
 For N in 1, 2, 4, 8 the c3 stream is cut into N contiguous read shards; every shard's rank-side work (push, counts,
-table export) and the root-side work (N merges, finalize) are timed separately.  Transfers are not modelled.
+export by key range), the per-range merges (one rank's share) and the root-side work (adopt, finalize) are timed
+separately, next to the older whole-table-to-root protocol.  Transfers are not modelled.
 usage: python tools/scale_model.py [workload]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,6 +25,57 @@ def sync():
     torch.cuda.synchronize()
     return time.perf_counter()
 
+
+part = ecb.EcBuilder(T, H, device=0, ec_capacity=1 << 23, arena_capacity=1 << 26)
+peng = ecdist.GpuEngine(part, dev)
+for N in (1, 2, 4, 8):
+    for rep in range(2):
+        rank_ms, pieces, base, tot = [], [], 0, [0, 0, 0]
+        for r in range(N):
+            lo = int(torch.searchsorted(rid, torch.tensor([r * st["reads"] // N], dtype=torch.int32, device=dev))[0]) if r else 0
+            hi = int(torch.searchsorted(rid, torch.tensor([(r + 1) * st["reads"] // N], dtype=torch.int32, device=dev))[0]) if r < N - 1 else rid.numel()
+            s = [t[lo:hi].clone() for t in (rid, loc, hf)]
+            s[0] -= r * st["reads"] // N
+            t0 = sync()
+            b.reset()
+            b.push_device(*s)
+            t1 = sync()
+            ne, npairs, nreads = b.table_sizes()
+            t2 = sync()
+            pieces.append(eng.table_export_parts(base, N))
+            t3 = sync()
+            a, v, _ = b.counters()
+            rank_ms.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3))
+            base += nreads
+            tot = [tot[0] + a, tot[1] + v, tot[2] + nreads]
+            del s
+        root.reset()
+        part_ms, adopt_ms, moved = [], 0.0, []
+        for q in range(N):
+            t0 = sync()
+            part.reset()
+            for ent, prs, eoff, poff in pieces:
+                if eoff[q + 1] > eoff[q]:
+                    peng.table_merge(ent[eoff[q] * 4:eoff[q + 1] * 4], eoff[q + 1] - eoff[q], prs[poff[q]:poff[q + 1]], poff[q + 1] - poff[q])
+            pe_n, pp_n, _ = part.table_sizes()
+            pe, pp = peng.table_export(0)
+            t1 = sync()
+            reng.table_adopt(pe, pe_n, pp, pp_n)
+            t2 = sync()
+            part_ms.append((t1 - t0) * 1e3)
+            adopt_ms += (t2 - t1) * 1e3
+            moved.append((pe_n * 32 + pp_n * 8) / 1e6)
+        root.add_counters(*tot)
+        t5 = sync()
+        sz = root.finalize()
+        t6 = sync()
+        sent = [sum((p[2][q + 1] - p[2][q]) * 32 + (p[3][q + 1] - p[3][q]) * 8 for q in range(N) if q != r) / 1e6 for r, p in enumerate(pieces)]
+        del pieces
+    rk = max(sum(x) for x in rank_ms)
+    print("ranges N=%d: rank-side max %.2f ms (push %.2f, counts %.2f, cut+export %.2f) | my range: merge+export %.2f ms | root: adopt %.2f + "
+          "finalize %.2f ms | sent per rank %.0f MB, to root %.0f MB | model step %.2f ms  ECs %d" % (
+              N, rk, max(x[0] for x in rank_ms), max(x[1] for x in rank_ms), max(x[2] for x in rank_ms), max(part_ms), adopt_ms,
+              (t6 - t5) * 1e3, max(sent), sum(moved[1:]), rk + max(part_ms) + adopt_ms + (t6 - t5) * 1e3, sz["n_ecs"]), flush=True)
 
 for N in (1, 2, 4, 8):
     for rep in range(2):
