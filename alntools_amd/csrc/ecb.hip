@@ -45,7 +45,7 @@ constexpr int TPB = 256;             // threads per workgroup (4 waves of 64)
 constexpr u32 MAX_PROBE = 256;       // EC-table probes before a read is deferred to k_slow
 constexpr u32 PENDING = 0xFFFFFFFFu;
 constexpr u32 ARENA_CHUNK = 512;     // pairs a wave reserves from the key arena per global atomic
-constexpr u32 ARENA_FIRST = 128;     // pairs pre-assigned to every wave of a launch (no atomic at all for most waves)
+constexpr u32 ARENA_REGIONS = 64;    // the key arena has this many allocation cursors (see arena_alloc)
 constexpr u32 MAX_LOCI = 1u << 27;   // (locus << 5 | hap) + 1 must fit 32 bits
 
 constexpr u32 ERR_CONTRACT = 1u;     // device error bits (Counters::err)
@@ -62,12 +62,29 @@ struct Slot {                        // 32 bytes, one EC
 
 struct Counters {
     u64 all, valid;                  // records offered / passing the filter
-    u64 arena_top;                   // pairs used in the key arena
+    u64 arena_top;                   // pairs placed by ecb_table_adopt_device (dense from 0; an adopting handle allocates nothing else)
     u64 n_queue;                     // reads deferred to k_slow
     u64 n_ecs;                       // ECs created by k_slow / k_merge (k_stream's are counted by k_collect_new)
     u32 err;
     u32 full;                        // set when a read found no EC-table slot: workgroups park, host grows the table
+    u64 arena_reg[ARENA_REGIONS];    // next free pair of every arena region
 };
+
+// The key arena is cut into equal regions with a cursor each; a wave allocates from the region its index picks and moves
+// on when that one is full.  One cursor for the whole arena is one address for every reservation of every wave:
+// same-address atomics complete ~18 ns apart, and the 66 k chunk reservations of a C3 pass added 1.4 ms to k_stream.
+// (Regions of at least 64 k pairs; small arenas have fewer.)  Keys are found through Slot::off, nothing needs the arena dense.
+__host__ __device__ __forceinline__ u32 arena_regions(u64 arena_cap) { return (u32)(arena_cap >> 16 >= ARENA_REGIONS ? ARENA_REGIONS : (arena_cap >> 16 ? arena_cap >> 16 : 1)); }
+__device__ __forceinline__ u64 arena_alloc(Counters* ctr, u64 arena_cap, u32 n, u32 hint) {
+    const u32 R = arena_regions(arena_cap);
+    const u64 per = arena_cap / R;
+    for (u32 t = 0; t < R; ++t) {
+        const u32 r = (hint + t) % R;
+        const u64 at = atomicAdd(&ctr->arena_reg[r], (u64)n);     // (a failed try leaves the cursor past the end: that region is full)
+        if (at + n <= (u64)(r + 1) * per) return at;
+    }
+    return ~0ull;
+}
 
 // ---------------------------------------------------------------------------------------------
 // hashing: EC identity = the SET of (locus, haplotype) targets of a read (bam_utils.py:307 builds a
@@ -184,7 +201,6 @@ struct StreamArgs {
     u32 n_loci, n_haps;
     Slot* table; u64 cap_mask;
     uint2* arena; u64 arena_cap;
-    u64 arena_first;                 // wave w owns arena[arena_first + w * ARENA_FIRST, + ARENA_FIRST) without asking
     Counters* ctr;
     u32* read_slot;                  // slot of every read (indexed by read_id)
     u64* queue; u64 queue_cap;       // head record index of deferred reads
@@ -271,8 +287,8 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
     u32 parked = __hip_atomic_load(&A.ctr->full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     u32 bad = 0;
     asm volatile("" : "+v"(parked));          // (settled before the loop: otherwise the loop header carries an s_waitcnt vmcnt(0) that every tile pays)
-    u64 chunk_at = A.arena_first + wid * ARENA_FIRST;   // this wave's reservation in the key arena (first one pre-assigned)
-    u32 chunk_left = A.arena_first + (wid + 1) * ARENA_FIRST <= A.arena_cap ? ARENA_FIRST : 0u, my_new = 0;
+    u64 chunk_at = 0;                             // this wave's current reservation in the key arena
+    u32 chunk_left = 0, my_new = 0;
 
 #ifdef ECB_TIMING
     u64 tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
@@ -514,9 +530,10 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                 if (total > chunk_left) {                           // reserve another stretch of the key arena
                     const u32 take = max(total, ARENA_CHUNK);
                     u64 at = 0;
-                    if (lane == 0) at = atomicAdd(&A.ctr->arena_top, (u64)take);
-                    chunk_at = __shfl(at, 0); chunk_left = take;
-                    if (chunk_at + take > A.arena_cap) { bad |= ERR_ARENA; chunk_left = 0; }
+                    if (lane == 0) at = arena_alloc(A.ctr, A.arena_cap, take, (u32)wid);
+                    chunk_at = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(at >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)at);
+                    chunk_left = take;
+                    if (chunk_at == ~0ull) { bad |= ERR_ARENA; chunk_left = 0; }
                 }
                 if (!(bad & ERR_ARENA)) {
                     const u32 off = (u32)(chunk_at + (incl - want));   // the arena holds < 2^32 pairs (Slot::off)
@@ -771,9 +788,9 @@ __global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
         } else {
             A.read_slot[r0] = (u32)slot;
             if (created) {
-                const u64 off = atomicAdd(&A.ctr->arena_top, (u64)np);
+                const u64 off = arena_alloc(A.ctr, A.arena_cap, np, blockIdx.x);
                 atomicAdd(&A.ctr->n_ecs, 1ull);
-                s_created = 1; s_off = off; s_fits = (off + np <= A.arena_cap);
+                s_created = 1; s_off = off; s_fits = (off != ~0ull);
                 if (s_fits) { A.table[slot].off = (u32)off; A.table[slot].n = np; }
                 else atomicOr(&A.ctr->err, ERR_ARENA);
             }
@@ -852,15 +869,6 @@ __global__ __launch_bounds__(TPB_COMPACT) void k_compact(const Slot* table, u64 
             if ((occ >> k & 1u) && base + off[k] < max_list) list[base + off[k]] = (u32)(b + (u64)k * TPB_COMPACT + tid);
         __syncthreads();
     }
-}
-
-// serialise: entry e = slot list[e] with first rebased to the global read numbering
-__global__ void k_export_entries(const Slot* table, const u32* list, u64 n, Slot* out, u32 read_base) {
-    const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    Slot s = table[list[e]];
-    s.first_inv = ~(~s.first_inv + read_base);
-    out[e] = s;
 }
 
 // Partitioned export (multi-GPU merge by key range): part of an EC = a few high bits of its key, so every rank sends
@@ -971,11 +979,11 @@ __global__ __launch_bounds__(TPB) void k_merge(const Slot* ent, u64 n, const uin
     const u32 total = __shfl(incl, 63);
     const u32 n_new = (u32)__popcll(__ballot(created));
     u64 at = 0;
-    if (lane == 0 && n_new) { at = atomicAdd(&ctr->arena_top, (u64)total); atomicAdd(&ctr->n_ecs, (u64)n_new); }
+    if (lane == 0 && n_new) { at = arena_alloc(ctr, arena_cap, total, blockIdx.x * (TPB / 64) + (threadIdx.x >> 6)); atomicAdd(&ctr->n_ecs, (u64)n_new); }
     at = __shfl(at, 0);
     if (created) {
         const u64 off = at + (incl - want);
-        if (off + s.n > arena_cap) { atomicOr(&ctr->err, ERR_ARENA); return; }
+        if (at == ~0ull) { atomicOr(&ctr->err, ERR_ARENA); return; }
         for (u32 t = 0; t < s.n; ++t) arena[off + t] = pairs[s.off + t];
         table[j].off = (u32)off; table[j].n = s.n;
     }
@@ -1214,7 +1222,6 @@ struct ecb_handle {
     uint2* arena = nullptr; u64 arena_cap = 0;
     Counters* ctr = nullptr;
     Counters hctr{};                  // last read-back
-    u64 arena_top_host = 0;           // staging word for setting Counters::arena_top
     u32* read_slot = nullptr; u64 read_slot_cap = 0;
     u32* meta = nullptr; u64 meta_cap = 0, meta_hi = 0;   // multisample: cell | file << 22 per read
     u64 n_triples = 0; u64* ms_okey = nullptr; u32 *ms_ofirst = nullptr, *ms_ostart = nullptr;
@@ -1277,6 +1284,26 @@ int pool_get(ecb_handle* h, int id, u64 count, T** out) {
     return ECB_OK;
 }
 #define POOL(h, id, ptr, count) do { int rc_ = pool_get(h, ecb_handle::id, count, &(ptr)); if (rc_ != ECB_OK) return rc_; } while (0)
+
+// zero the device counters and point every arena region's cursor at its first pair
+int clear_counters(ecb_handle* h) {
+    Counters c{};
+    const u32 R = arena_regions(h->arena_cap);
+    const u64 per = h->arena_cap / R;
+    for (u32 r = 0; r < ARENA_REGIONS; ++r) c.arena_reg[r] = r < R ? r * per : h->arena_cap;
+    h->hctr = c;
+    HIPCHK(h, hipMemcpyAsync(h->ctr, &h->hctr, sizeof(Counters), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ECB_OK;
+}
+// pairs of the key arena handed out so far (an upper bound of the pairs in use: the tail of a wave's last chunk is idle)
+u64 arena_used(const ecb_handle* h) {
+    const u32 R = arena_regions(h->arena_cap);
+    const u64 per = h->arena_cap / R;
+    u64 used = h->hctr.arena_top;
+    for (u32 r = 0; r < R; ++r) used += std::min<u64>(h->hctr.arena_reg[r], (u64)(r + 1) * per) - r * per;
+    return used;
+}
 
 int sync_counters(ecb_handle* h) {
     HIPCHK(h, hipMemcpyAsync(&h->hctr, h->ctr, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
@@ -1406,7 +1433,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     u32* d_wcounts = nullptr;
     POOL(h, P_WCOUNTS, d_wcounts, 3 * waves);
     StreamArgs a{d_rid, d_loc, d_hf, n, chunk, h->prev_rid, h->cfg.n_loci, h->cfg.n_haplotypes,
-                 h->table, h->cap - 1, h->arena, h->arena_cap, 0, h->ctr, h->read_slot, h->queue, h->queue_cap, d_resume, d_wcounts,
+                 h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr, h->read_slot, h->queue, h->queue_cap, d_resume, d_wcounts,
                  getenv("ECB_ABLATE") ? (u32)atoi(getenv("ECB_ABLATE")) : 0u, nullptr};
 #ifdef ECB_TIMING
     HIPCHK(h, hipMalloc(&a.timing, 8 * sizeof(u64)));
@@ -1416,13 +1443,6 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
         HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));   // per launch
         HIPCHK(h, hipMemsetAsync(&h->ctr->full, 0, sizeof(u32), h->stream));
         a.table = h->table; a.cap_mask = h->cap - 1;
-        {   // every wave of this launch gets ARENA_FIRST pairs of the key arena up front
-            rc = sync_counters(h);
-            if (rc != ECB_OK) break;
-            a.arena_first = h->hctr.arena_top;
-            h->arena_top_host = std::min<u64>(a.arena_first + waves * ARENA_FIRST, h->arena_cap);   // (outlives the async copy)
-            hipMemcpyAsync(&h->ctr->arena_top, &h->arena_top_host, sizeof(u64), hipMemcpyHostToDevice, h->stream);
-        }
         HIPCHK(h, hipMemsetAsync(d_wcounts, 0, 3 * waves * sizeof(u32), h->stream));
         if (h->prof) hipEventRecord(h->ev0, h->stream);
         k_stream<false><<<(unsigned)blocks, TPB, 0, h->stream>>>(a);
@@ -1596,7 +1616,7 @@ int ecb_create(const ecb_config* cfg, ecb_handle** out) {
     if ((e = hipMalloc(&h->arena, h->arena_cap * sizeof(uint2))) != hipSuccess) return bail(ECB_ERR_HIP, "hipMalloc(arena)", e);
     if ((e = hipMalloc(&h->ctr, sizeof(Counters))) != hipSuccess) return bail(ECB_ERR_HIP, "hipMalloc(counters)", e);
     hipMemsetAsync(h->table, 0, h->cap * sizeof(Slot), h->stream);
-    hipMemsetAsync(h->ctr, 0, sizeof(Counters), h->stream);
+    clear_counters(h);
     if (cfg->flags & ECB_F_RANGES) {
         const u64 ns = (u64)cfg->n_loci * cfg->n_haplotypes;
         if ((e = hipMalloc(&h->rng_min, ns * sizeof(int))) != hipSuccess) return bail(ECB_ERR_HIP, "hipMalloc(ranges)", e);
@@ -1656,7 +1676,7 @@ int ecb_verify_device(ecb_handle* h, const void* d_read_id, const void* d_locus,
         HIPCHK(h, hipMalloc(&h->queue, h->queue_cap * sizeof(u64)));
     }
     StreamArgs a{(const u32*)d_read_id, (const u32*)d_locus, (const u32*)d_hapflag, n, chunk, 0xFFFFFFFFu,
-                 h->cfg.n_loci, h->cfg.n_haplotypes, h->table, h->cap - 1, h->arena, h->arena_cap, h->arena_cap, h->ctr,
+                 h->cfg.n_loci, h->cfg.n_haplotypes, h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr,
                  h->read_slot, h->queue, h->queue_cap, d_resume, d_wcounts, 0u};
     k_stream<true><<<(unsigned)blocks, TPB, 0, h->stream>>>(a);
     k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, waves, h->ctr);
@@ -1678,7 +1698,7 @@ int ecb_reset(ecb_handle* h) {
     HIPCHK(h, hipSetDevice(h->device));
     free_results(h);
     if (!getenv("ECB_KEEP_TABLE")) HIPCHK(h, hipMemsetAsync(h->table, 0, h->cap * sizeof(Slot), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->ctr, 0, sizeof(Counters), h->stream));
+    { int rc_ = clear_counters(h); if (rc_ != ECB_OK) return rc_; }
     if (h->read_slot && h->reads_hi) HIPCHK(h, hipMemsetAsync(h->read_slot, 0xFF, h->reads_hi * sizeof(u32), h->stream));
     if (h->rng_min) {
         const u64 ns = (u64)h->cfg.n_loci * h->cfg.n_haplotypes;
@@ -1686,7 +1706,6 @@ int ecb_reset(ecb_handle* h) {
         k_fill_i32<<<nblk(ns, TPB), TPB, 0, h->stream>>>(h->rng_max, ns, INT_MIN);
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->hctr = Counters{};
     h->prev_rid = 0xFFFFFFFFu; h->n_reads = 0; h->reads_hi = 0; h->meta_hi = 0; h->n_triples = 0;
     h->extra_all = h->extra_valid = h->extra_reads = 0;
     h->c_rid.clear(); h->c_loc.clear(); h->c_hf.clear(); h->c_pos.clear();
@@ -1806,7 +1825,7 @@ int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
     {   // 64-bit check of the row-length total before trusting a 32-bit scan
         rc = excl_scan(h, rowlen, E, h->indptr, &nnz);
         if (rc != ECB_OK) return rc;
-        if (h->hctr.arena_top >= (1ull << 31)) return fail(h, ECB_ERR_LIMIT, "A has more than 2^31-1 non-zeros");
+        if (arena_used(h) >= (1ull << 31)) return fail(h, ECB_ERR_LIMIT, "A has more than 2^31-1 non-zeros");
         HIPCHK(h, hipMemcpyAsync(h->indptr + E, &nnz, 4, hipMemcpyHostToDevice, h->stream));
     }
     POOL(h, P_INDICES, h->indices, nnz); POOL(h, P_DATA, h->data, nnz);
@@ -1961,26 +1980,14 @@ int ecb_table_sizes(ecb_handle* h, uint64_t* n_entries, uint64_t* n_pairs, uint6
     rc = ensure_counts(h);
     if (rc != ECB_OK) return rc;
     if (n_entries) *n_entries = h->n_ecs();
-    if (n_pairs) *n_pairs = h->hctr.arena_top;
+    if (n_pairs) *n_pairs = arena_used(h);
     if (n_reads) *n_reads = h->n_reads;
     return ECB_OK;
 }
 
 int ecb_table_export_device(ecb_handle* h, void* d_entries, void* d_pairs, uint64_t read_base) {
-    if (!h || !d_entries || !d_pairs) return ECB_ERR_ARG;
-    HIPCHK(h, hipSetDevice(h->device));
-    int rc = sync_counters(h);
-    if (rc != ECB_OK) return rc;
-    if (read_base + h->n_reads >= (1ull << 32) - 1) return fail(h, ECB_ERR_LIMIT, "more than 2^32-2 reads in total");
-    rc = ensure_counts(h);
-    if (rc != ECB_OK) return rc;
-    rc = compact_table(h);
-    if (rc != ECB_OK) return rc;
-    const u64 E = h->n_ecs();
-    if (E) k_export_entries<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->table, h->list, E, (Slot*)d_entries, (u32)read_base);
-    HIPCHK(h, hipMemcpyAsync(d_pairs, h->arena, h->hctr.arena_top * sizeof(uint2), hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return ECB_OK;
+    uint64_t eo[2], po[2];                             // one part: entries in table order, their keys packed behind each other
+    return ecb_table_export_parts_device(h, d_entries, d_pairs, read_base, 1, eo, po);
 }
 
 int ecb_table_merge_device(ecb_handle* h, const void* d_entries, uint64_t n_entries, const void* d_pairs, uint64_t n_pairs) {
