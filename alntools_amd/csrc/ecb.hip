@@ -952,41 +952,51 @@ __global__ void k_adopt(const Slot* ent, u64 n, Slot* table, u64 slot_base, u32 
     table[slot_base + e] = s;
 }
 
+constexpr u32 MERGE_PER_BLOCK = 16 * TPB;     // entries per workgroup (one EC-count atomic per workgroup, not per wave: ~18 ns each on one address)
 __global__ __launch_bounds__(TPB) void k_merge(const Slot* ent, u64 n, const uint2* pairs, u64 n_pairs, Slot* table, u64 cap_mask,
                                                uint2* arena, u64 arena_cap, Counters* ctr) {
-    const u64 e = blockIdx.x * (u64)TPB + threadIdx.x;
+    __shared__ u32 s_new;
+    if (threadIdx.x == 0) s_new = 0;
+    __syncthreads();
     const u32 lane = threadIdx.x & 63u;
-    const bool on = e < n;
-    Slot s{};
-    if (on) s = ent[e];
-    bool ok = on && (u64)s.off + s.n <= n_pairs;
-    if (on && !ok) atomicOr(&ctr->err, ERR_CONTRACT);
-    bool created = false;
-    u64 j = ~0ull;
-    if (ok) {
-        j = table_find_or_insert(table, cap_mask, s.lo, s.hi, &created);
-        if (j == ~0ull) atomicAdd(&ctr->n_queue, 1ull);            // host sizes the table so this cannot happen
-        else {
-            atomicAdd(&table[j].count, s.count);                     // one pair of atomics per merged EC, not per read
-            atomicMax(&table[j].first_inv, s.first_inv);
+    const u64 e0 = blockIdx.x * (u64)MERGE_PER_BLOCK, e1 = min(e0 + MERGE_PER_BLOCK, n);
+    u32 my_new = 0;                                // (wave-uniform)
+    for (u64 eb = e0; eb < e1; eb += TPB) {
+        const u64 e = eb + threadIdx.x;
+        const bool on = e < e1;
+        Slot s{};
+        if (on) s = ent[e];
+        const bool ok = on && (u64)s.off + s.n <= n_pairs;
+        if (on && !ok) atomicOr(&ctr->err, ERR_CONTRACT);
+        bool created = false;
+        u64 j = ~0ull;
+        if (ok) {
+            j = table_find_or_insert(table, cap_mask, s.lo, s.hi, &created);
+            if (j == ~0ull) atomicAdd(&ctr->n_queue, 1ull);        // host sizes the table so this cannot happen
+            else {
+                atomicAdd(&table[j].count, s.count);                 // one pair of atomics per merged EC, not per read
+                atomicMax(&table[j].first_inv, s.first_inv);
+            }
+        }
+        // key arena: one reservation per wave, not per created EC
+        const u64 cm = __ballot(created);
+        if (!cm) continue;
+        const u32 want = created ? s.n : 0u, incl = wave_incl_scan(want);
+        const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        my_new += (u32)__popcll(cm);
+        u64 at = 0;
+        if (lane == 0) at = arena_alloc(ctr, arena_cap, total, blockIdx.x * (TPB / 64) + (threadIdx.x >> 6));
+        at = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(at >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)at);
+        if (at == ~0ull) { if (lane == 0) atomicOr(&ctr->err, ERR_ARENA); continue; }
+        if (created) {
+            const u64 off = at + (incl - want);
+            for (u32 t = 0; t < s.n; ++t) arena[off + t] = pairs[s.off + t];
+            table[j].off = (u32)off; table[j].n = s.n;
         }
     }
-    // key arena and EC count: one atomic each per wave, not per created EC
-    const u32 want = created ? s.n : 0u;
-    u32 incl = want;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(incl, d); if (lane >= (u32)d) incl += t; }
-    const u32 total = __shfl(incl, 63);
-    const u32 n_new = (u32)__popcll(__ballot(created));
-    u64 at = 0;
-    if (lane == 0 && n_new) { at = arena_alloc(ctr, arena_cap, total, blockIdx.x * (TPB / 64) + (threadIdx.x >> 6)); atomicAdd(&ctr->n_ecs, (u64)n_new); }
-    at = __shfl(at, 0);
-    if (created) {
-        const u64 off = at + (incl - want);
-        if (at == ~0ull) { atomicOr(&ctr->err, ERR_ARENA); return; }
-        for (u32 t = 0; t < s.n; ++t) arena[off + t] = pairs[s.off + t];
-        table[j].off = (u32)off; table[j].n = s.n;
-    }
+    if (lane == 0 && my_new) atomicAdd(&s_new, my_new);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_new) atomicAdd(&ctr->n_ecs, (u64)s_new);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2003,7 +2013,7 @@ int ecb_table_merge_device(ecb_handle* h, const void* d_entries, uint64_t n_entr
     if (rc != ECB_OK) return rc;
     while ((h->n_ecs() + n_entries) * 2 > h->cap) { rc = grow_table(h, h->cap * 4); if (rc != ECB_OK) return rc; }
     HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));
-    k_merge<<<nblk(n_entries, TPB), TPB, 0, h->stream>>>((const Slot*)d_entries, n_entries, (const uint2*)d_pairs, n_pairs,
+    k_merge<<<nblk(n_entries, MERGE_PER_BLOCK), TPB, 0, h->stream>>>((const Slot*)d_entries, n_entries, (const uint2*)d_pairs, n_pairs,
                                                           h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr);
     rc = sync_counters(h);
     if (rc != ECB_OK) return rc;
