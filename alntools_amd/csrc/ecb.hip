@@ -2000,25 +2000,38 @@ int ecb_table_export_device(ecb_handle* h, void* d_entries, void* d_pairs, uint6
     return ecb_table_export_parts_device(h, d_entries, d_pairs, read_base, 1, eo, po);
 }
 
-int ecb_table_merge_device(ecb_handle* h, const void* d_entries, uint64_t n_entries, const void* d_pairs, uint64_t n_pairs) {
+int ecb_table_merge_batch_device(ecb_handle* h, uint32_t n_tables, const void* const* d_entries, const uint64_t* n_entries,
+                                const void* const* d_pairs, const uint64_t* n_pairs) {
     if (!h) return ECB_ERR_ARG;
     if (h->finalized) return fail(h, ECB_ERR_STATE, "merge after finalize");
     if (h->adopted) return fail(h, ECB_ERR_STATE, "merge into a table that adopted entries");
-    if (!n_entries) return ECB_OK;
-    if (!d_entries || (n_pairs && !d_pairs)) return fail(h, ECB_ERR_ARG, "null table buffers");
+    if (n_tables && (!d_entries || !n_entries || !d_pairs || !n_pairs)) return fail(h, ECB_ERR_ARG, "null table lists");
+    u64 total = 0;
+    for (u32 t = 0; t < n_tables; ++t) {
+        if (n_entries[t] && (!d_entries[t] || (n_pairs[t] && !d_pairs[t]))) return fail(h, ECB_ERR_ARG, "null table buffers");
+        total += n_entries[t];
+    }
+    if (!total) return ECB_OK;
     HIPCHK(h, hipSetDevice(h->device));
     int rc = sync_counters(h);
     if (rc != ECB_OK) return rc;
     rc = ensure_counts(h);                       // own reads first: merged counts are added on top
     if (rc != ECB_OK) return rc;
-    while ((h->n_ecs() + n_entries) * 2 > h->cap) { rc = grow_table(h, h->cap * 4); if (rc != ECB_OK) return rc; }
+    // room for every entry being new: one growth up front, then the merges queue up behind each other with one sync at the end
+    while ((h->n_ecs() + total) * 2 > h->cap) { rc = grow_table(h, h->cap * 4); if (rc != ECB_OK) return rc; }
     HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));
-    k_merge<<<nblk(n_entries, MERGE_PER_BLOCK), TPB, 0, h->stream>>>((const Slot*)d_entries, n_entries, (const uint2*)d_pairs, n_pairs,
-                                                          h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr);
+    for (u32 t = 0; t < n_tables; ++t)
+        if (n_entries[t])
+            k_merge<<<nblk(n_entries[t], MERGE_PER_BLOCK), TPB, 0, h->stream>>>((const Slot*)d_entries[t], n_entries[t], (const uint2*)d_pairs[t],
+                                                                              n_pairs[t], h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr);
     rc = sync_counters(h);
     if (rc != ECB_OK) return rc;
     if (h->hctr.n_queue) return fail(h, ECB_ERR_TABLE_FULL, "internal: merge found no slot in a half-empty table");
     return ECB_OK;
+}
+
+int ecb_table_merge_device(ecb_handle* h, const void* d_entries, uint64_t n_entries, const void* d_pairs, uint64_t n_pairs) {
+    return ecb_table_merge_batch_device(h, 1, &d_entries, &n_entries, &d_pairs, &n_pairs);
 }
 
 int ecb_table_export_parts_device(ecb_handle* h, void* d_entries, void* d_pairs, uint64_t read_base, uint32_t n_parts,
@@ -2054,24 +2067,30 @@ int ecb_table_export_parts_device(ecb_handle* h, void* d_entries, void* d_pairs,
     return ECB_OK;
 }
 
-int ecb_table_adopt_device(ecb_handle* h, const void* d_entries, uint64_t n_entries, const void* d_pairs, uint64_t n_pairs) {
+int ecb_table_adopt_batch_device(ecb_handle* h, uint32_t n_tables, const void* const* d_entries, const uint64_t* n_entries,
+                                const void* const* d_pairs, const uint64_t* n_pairs) {
     if (!h) return ECB_ERR_ARG;
     if (h->finalized) return fail(h, ECB_ERR_STATE, "adopt after finalize");
+    if (n_tables && (!d_entries || !n_entries || !d_pairs || !n_pairs)) return fail(h, ECB_ERR_ARG, "null table lists");
     HIPCHK(h, hipSetDevice(h->device));
     int rc = sync_counters(h);
     if (rc != ECB_OK) return rc;
     if (!h->adopted && (h->n_ecs() || h->n_reads || !h->c_rid.empty()))
         return fail(h, ECB_ERR_STATE, "adopt needs an empty handle (use ecb_table_merge_device to add to a built table)");
     if (h->cfg.flags & ECB_F_MULTISAMPLE) return fail(h, ECB_ERR_STATE, "multisample is single-GPU in this build");
+    u64 add_e = 0, add_p = 0;
+    for (u32 t = 0; t < n_tables; ++t) {
+        if (n_entries[t] && (!d_entries[t] || (n_pairs[t] && !d_pairs[t]))) return fail(h, ECB_ERR_ARG, "null table buffers");
+        if (n_entries[t]) { add_e += n_entries[t]; add_p += n_pairs[t]; }
+    }
     h->adopted = true; h->counted = true;
-    if (!n_entries) return ECB_OK;
-    if (!d_entries || (n_pairs && !d_pairs)) return fail(h, ECB_ERR_ARG, "null table buffers");
-    const u64 have = h->n_ecs(), top = h->hctr.arena_top;
-    if (top + n_pairs > h->arena_cap || top + n_pairs >= (1ull << 32))
+    if (!add_e) return ECB_OK;
+    u64 have = h->n_ecs(), top = h->hctr.arena_top;
+    if (top + add_p > h->arena_cap || top + add_p >= (1ull << 32))
         return fail(h, ECB_ERR_TABLE_FULL, "EC key arena exhausted (%llu pairs): raise arena_capacity", (unsigned long long)h->arena_cap);
-    if (have + n_entries > h->cap) {                    // consecutive slots: a bigger array and a copy, no rehash
+    if (have + add_e > h->cap) {                        // consecutive slots: a bigger array and a copy, no rehash
         u64 nc = h->cap;
-        while (nc < have + n_entries) nc *= 2;
+        while (nc < have + add_e) nc *= 2;
         Slot* nt = nullptr;
         HIPCHK(h, hipMalloc(&nt, nc * sizeof(Slot)));
         HIPCHK(h, hipMemsetAsync(nt, 0, nc * sizeof(Slot), h->stream));
@@ -2080,13 +2099,21 @@ int ecb_table_adopt_device(ecb_handle* h, const void* d_entries, uint64_t n_entr
         HIPCHK(h, hipFree(h->table));
         h->table = nt; h->cap = nc;
     }
-    k_adopt<<<nblk(n_entries, TPB), TPB, 0, h->stream>>>((const Slot*)d_entries, n_entries, h->table, have, (u32)top);
-    if (n_pairs) HIPCHK(h, hipMemcpyAsync(h->arena + top, d_pairs, n_pairs * sizeof(uint2), hipMemcpyDeviceToDevice, h->stream));
-    h->hctr.n_ecs = have + n_entries; h->hctr.arena_top = top + n_pairs;
+    for (u32 t = 0; t < n_tables; ++t) {
+        if (!n_entries[t]) continue;
+        k_adopt<<<nblk(n_entries[t], TPB), TPB, 0, h->stream>>>((const Slot*)d_entries[t], n_entries[t], h->table, have, (u32)top);
+        if (n_pairs[t]) HIPCHK(h, hipMemcpyAsync(h->arena + top, d_pairs[t], n_pairs[t] * sizeof(uint2), hipMemcpyDeviceToDevice, h->stream));
+        have += n_entries[t]; top += n_pairs[t];
+    }
+    h->hctr.n_ecs = have; h->hctr.arena_top = top;
     HIPCHK(h, hipMemcpyAsync(&h->ctr->n_ecs, &h->hctr.n_ecs, sizeof(u64), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(&h->ctr->arena_top, &h->hctr.arena_top, sizeof(u64), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return ECB_OK;
+}
+
+int ecb_table_adopt_device(ecb_handle* h, const void* d_entries, uint64_t n_entries, const void* d_pairs, uint64_t n_pairs) {
+    return ecb_table_adopt_batch_device(h, 1, &d_entries, &n_entries, &d_pairs, &n_pairs);
 }
 
 int ecb_counters(ecb_handle* h, uint64_t* all_alignments, uint64_t* valid_alignments, uint64_t* n_reads) {

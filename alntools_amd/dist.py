@@ -14,8 +14,8 @@ export), then
 3. the merged ranges hold disjoint ECs: they are sent to the root, which loads them without hashing
    (``ecb_table_adopt_device``) and finalizes (rank by first appearance, CSR emit).
 
-The functions only need an *engine* with ``table_sizes/counters/table_export/table_export_parts/table_merge/
-table_adopt/add_counters`` -- :class:`GpuEngine` wraps an :class:`alntools_amd.ecb.EcBuilder`; the CPU ``gloo`` tests
+The functions only need an *engine* with ``table_sizes/counters/table_export/table_export_parts/table_merge(_many)/
+table_adopt(_many)/add_counters`` -- :class:`GpuEngine` wraps an :class:`alntools_amd.ecb.EcBuilder`; the CPU ``gloo`` tests
 plug in an oracle-backed engine.
 """
 from __future__ import annotations
@@ -55,6 +55,13 @@ class GpuEngine(object):
 
     def table_adopt(self, ent, n_entries, prs, n_pairs):
         self.b.table_adopt_device(ent, n_entries, prs, n_pairs)
+
+    def table_merge_many(self, tables):
+        """``tables``: [(entries, n_entries, pairs, n_pairs), ...] merged in that order, one host wait for all."""
+        self.b.table_merge_batch_device(tables)
+
+    def table_adopt_many(self, tables):
+        self.b.table_adopt_batch_device(tables)
 
     def table_merge(self, ent, n_entries, prs, n_pairs):
         self.b.table_merge_device(ent, n_entries, prs, n_pairs)
@@ -117,9 +124,7 @@ def exchange_and_merge(engine, make_part_engine, make_root_engine, group=None, r
 
     # 2. merge my key range, in rank order (= stream order)
     part = make_part_engine()
-    for r in range(world):
-        if in_e[r]:
-            part.table_merge(piece_e[r], in_e[r], piece_p[r], in_p[r])
+    part.table_merge_many([(piece_e[r], in_e[r], piece_p[r], in_p[r]) for r in range(world) if in_e[r]])
     del piece_e, piece_p, ent, prs
 
     # 3. the merged ranges are disjoint: gather them on the root, which adopts them as they are
@@ -153,14 +158,8 @@ def exchange_and_merge(engine, make_part_engine, make_root_engine, group=None, r
     if dev.type == "cuda":
         torch.cuda.current_stream(dev).synchronize()
     merged = make_root_engine()
-    for r in range(world):
-        e_r, p_r = sz2[r]
-        if not e_r:
-            continue
-        if r == root:
-            merged.table_adopt(pe, e_r, pp, p_r)
-        else:
-            merged.table_adopt(bufs[r][0], e_r, bufs[r][1], p_r)
+    merged.table_adopt_many([(pe, sz2[r][0], pp, sz2[r][1]) if r == root else (bufs[r][0], sz2[r][0], bufs[r][1], sz2[r][1])
+                             for r in range(world) if sz2[r][0]])
     merged.add_counters(sum(s[3] for s in sizes), sum(s[4] for s in sizes), sum(s[2] for s in sizes))
     return merged
 

@@ -27,7 +27,7 @@ SYMBOLS = ("ecb_abi_version", "ecb_device_count", "ecb_create", "ecb_destroy", "
            "ecb_push", "ecb_push_device", "ecb_push_cells", "ecb_verify_device", "ecb_finalize", "ecb_export",
            "ecb_export_device", "ecb_export_ranges", "ecb_export_range_minmax", "ecb_export_pairs", "ecb_export_read_ec", "ecb_table_sizes",
            "ecb_table_export_device", "ecb_table_merge_device", "ecb_table_export_parts_device",
-           "ecb_table_adopt_device", "ecb_counters", "ecb_add_counters", "ecb_profile",
+           "ecb_table_adopt_device", "ecb_table_merge_batch_device", "ecb_table_adopt_batch_device", "ecb_counters", "ecb_add_counters", "ecb_profile",
            "ecb_profile_read", "ecb_csr_to_hapcsc_device", "ecb_hapcsc_to_csr_device")
 
 
@@ -94,6 +94,8 @@ def load():
     lib.ecb_table_merge_device.argtypes = [vp, vp, u64, vp, u64]
     lib.ecb_table_export_parts_device.argtypes = [vp, vp, vp, u64, C.c_uint32, C.POINTER(u64), C.POINTER(u64)]
     lib.ecb_table_adopt_device.argtypes = [vp, vp, u64, vp, u64]
+    for f in (lib.ecb_table_merge_batch_device, lib.ecb_table_adopt_batch_device):
+        f.argtypes = [vp, C.c_uint32, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64)]
     lib.ecb_counters.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     lib.ecb_add_counters.argtypes = [vp, u64, u64, u64]
     lib.ecb_profile.argtypes = [vp, C.c_int]
@@ -289,6 +291,19 @@ class EcBuilder(object):
         eo, po = (C.c_uint64 * (n_parts + 1))(), (C.c_uint64 * (n_parts + 1))()
         self._chk(self._lib.ecb_table_export_parts_device(self._h, _dev_ptr(entries), _dev_ptr(pairs), read_base, n_parts, eo, po))
         return list(eo), list(po)
+
+    def _batch(self, fn, tables):
+        """``tables``: list of (entries tensor, n_entries, pairs tensor, n_pairs)."""
+        n = len(tables)
+        pe, ne = (C.c_void_p * n)(*[t[0].data_ptr() for t in tables]), (C.c_uint64 * n)(*[t[1] for t in tables])
+        pp, npr = (C.c_void_p * n)(*[t[2].data_ptr() for t in tables]), (C.c_uint64 * n)(*[t[3] for t in tables])
+        self._chk(fn(self._h, n, pe, ne, pp, npr))
+
+    def table_merge_batch_device(self, tables):
+        self._batch(self._lib.ecb_table_merge_batch_device, tables)
+
+    def table_adopt_batch_device(self, tables):
+        self._batch(self._lib.ecb_table_adopt_batch_device, tables)
 
     def table_adopt_device(self, entries, n_entries, pairs, n_pairs):
         self._chk(self._lib.ecb_table_adopt_device(self._h, _dev_ptr(entries), n_entries, _dev_ptr(pairs), n_pairs))

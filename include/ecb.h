@@ -164,6 +164,12 @@ int ecb_table_export_parts_device(ecb_handle* h, void* d_entries, void* d_pairs,
                                   uint64_t* entry_offsets, uint64_t* pair_offsets);
 int ecb_table_adopt_device(ecb_handle* h, const void* d_entries, uint64_t n_entries,
                            const void* d_pairs, uint64_t n_pairs);
+/* Several tables in one call, in the order given (arrays of n_tables device pointers / sizes): the kernels queue up
+ * behind each other and the host waits once, not once per table. */
+int ecb_table_merge_batch_device(ecb_handle* h, uint32_t n_tables, const void* const* d_entries, const uint64_t* n_entries,
+                                 const void* const* d_pairs, const uint64_t* n_pairs);
+int ecb_table_adopt_batch_device(ecb_handle* h, uint32_t n_tables, const void* const* d_entries, const uint64_t* n_entries,
+                                 const void* const* d_pairs, const uint64_t* n_pairs);
 int ecb_counters(ecb_handle* h, uint64_t* all_alignments, uint64_t* valid_alignments, uint64_t* n_reads);
 int ecb_add_counters(ecb_handle* h, uint64_t all_alignments, uint64_t valid_alignments, uint64_t n_reads);
 

@@ -94,6 +94,14 @@ class OracleEngine(object):
         self.table_merge(ent, n_entries, prs, n_pairs)
         assert len(self.table) == before + n_entries, "adopted parts must hold distinct ECs"
 
+    def table_merge_many(self, tables):
+        for t in tables:
+            self.table_merge(*t)
+
+    def table_adopt_many(self, tables):
+        for t in tables:
+            self.table_adopt(*t)
+
     def table_merge(self, ent, n_entries, prs, n_pairs):
         e = ent.numpy().astype(np.uint64).reshape(-1, 4)[:n_entries]
         p = prs.numpy().astype(np.uint64)

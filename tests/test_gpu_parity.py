@@ -252,9 +252,13 @@ def test_shard_tables_merged_by_key_range_and_adopted():
     total = 0
     for q in range(P):
         part = ecdist.GpuEngine(ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=1 << 12), dev)
-        for ent, prs, eoff, poff in pieces:
-            if eoff[q + 1] > eoff[q]:
-                part.table_merge(ent[eoff[q] * 4:eoff[q + 1] * 4], eoff[q + 1] - eoff[q], prs[poff[q]:poff[q + 1]], poff[q + 1] - poff[q])
+        tabs = [(ent[eoff[q] * 4:eoff[q + 1] * 4], eoff[q + 1] - eoff[q], prs[poff[q]:poff[q + 1]], poff[q + 1] - poff[q])
+                for ent, prs, eoff, poff in pieces if eoff[q + 1] > eoff[q]]
+        if q == 0:
+            for t in tabs:                                               # one by one ...
+                part.table_merge(*t)
+        else:
+            part.table_merge_many(tabs)                                  # ... and as a batch (one host wait)
         pe_n, pp_n, _ = part.table_sizes()
         pe, pp = part.table_export(0)
         root.table_adopt(pe, pe_n, pp, pp_n)

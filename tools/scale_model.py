@@ -54,9 +54,8 @@ for N in (1, 2, 4, 8):
         for q in range(N):
             t0 = sync()
             part.reset()
-            for ent, prs, eoff, poff in pieces:
-                if eoff[q + 1] > eoff[q]:
-                    peng.table_merge(ent[eoff[q] * 4:eoff[q + 1] * 4], eoff[q + 1] - eoff[q], prs[poff[q]:poff[q + 1]], poff[q + 1] - poff[q])
+            peng.table_merge_many([(ent[eoff[q] * 4:eoff[q + 1] * 4], eoff[q + 1] - eoff[q], prs[poff[q]:poff[q + 1]], poff[q + 1] - poff[q])
+                                   for ent, prs, eoff, poff in pieces if eoff[q + 1] > eoff[q]])
             pe_n, pp_n, _ = part.table_sizes()
             pe, pp = peng.table_export(0)
             t1 = sync()
