@@ -68,6 +68,7 @@ struct Counters {
     u32 err;
     u32 full;                        // set when a read found no EC-table slot: workgroups park, host grows the table
     u64 arena_reg[ARENA_REGIONS];    // next free pair of every arena region
+    u64 next_slice;                  // k_stream: next unclaimed slice of the batch (zeroed per launch)
 };
 
 // The key arena is cut into equal regions with a cursor each; a wave allocates from the region its index picks and moves
@@ -273,26 +274,33 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
     __shared__ WaveLds wl[NWAVE];
     const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     WaveLds& L = wl[w];
-    const u64 wid = (u64)blockIdx.x * NWAVE + w;
+    // Persistent waves: the launch holds only as many waves as are resident at once, and every wave takes the next
+    // unclaimed slice of the stream when it has finished one.  (Slices bound to workgroups at launch left a SIMD slot
+    // idle until the slowest of a workgroup's four waves was done, and the last round ragged: a fifth of the kernel.)
+    const u64 pw = (u64)blockIdx.x * NWAVE + w;   // this wave
+    u32 my_all = 0, my_valid = 0, my_new = 0;     // per lane; a wave sees far fewer than 2^32 records
+    u32 bad = 0;
+    u64 chunk_at = 0;                             // this wave's current reservation in the key arena
+    u32 chunk_left = 0;
+#ifdef ECB_TIMING
+    u64 tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
+  for (;;) {
+    u64 wid = 0;                                  // the slice
+    if (lane == 0) wid = atomicAdd(&A.ctr->next_slice, 1ull);
+    wid = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(wid >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)wid);
     const u64 c0 = wid * A.chunk;
-    if (c0 >= A.n) return;
+    if (c0 >= A.n) break;
     const u64 c1 = min(c0 + A.chunk, A.n);
     u64 p = A.resume[2 * wid], counted = A.resume[2 * wid + 1];
-    if (p >= c1) return;
+    if (p >= c1) continue;                        // finished before a relaunch
 
-    u32 my_all = 0, my_valid = 0;                 // per lane; a slice is far below 2^32 records
     u32 base = (p == 0 ? A.prev_rid : A.rid[p - 1]) + 1u;     // read index of the first head >= p
     TileRegs R;
     load_tile(A, p & ~(u64)3, min((p & ~(u64)3) + (u64)WT, A.n), lane, R);
     u32 parked = __hip_atomic_load(&A.ctr->full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    u32 bad = 0;
     asm volatile("" : "+v"(parked));          // (settled before the loop: otherwise the loop header carries an s_waitcnt vmcnt(0) that every tile pays)
-    u64 chunk_at = 0;                             // this wave's current reservation in the key arena
-    u32 chunk_left = 0, my_new = 0;
 
-#ifdef ECB_TIMING
-    u64 tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
-#endif
     while (p < c1) {
         if (parked) break;            // the EC table filled up somewhere: the host grows it and relaunches
         p = ((u64)(u32)__builtin_amdgcn_readfirstlane((u32)(p >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((u32)p);   // (the builtin returns int: no sign extension)
@@ -530,7 +538,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                 if (total > chunk_left) {                           // reserve another stretch of the key arena
                     const u32 take = max(total, ARENA_CHUNK);
                     u64 at = 0;
-                    if (lane == 0) at = arena_alloc(A.ctr, A.arena_cap, take, (u32)wid);
+                    if (lane == 0) at = arena_alloc(A.ctr, A.arena_cap, take, (u32)pw);
                     chunk_at = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(at >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)at);
                     chunk_left = take;
                     if (chunk_at == ~0ull) { bad |= ERR_ARENA; chunk_left = 0; }
@@ -562,8 +570,11 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
         counted = max(counted, tb + (u64)cnt_hi);
         p = p_next; base = base_next;
     }
+    const bool stop = __ballot(bad != 0u) || parked;
     if (__ballot(bad != 0u)) { if (bad) atomicOr(&A.ctr->err, bad); p = c1; }
     if (lane == 0) { A.resume[2 * wid] = p; A.resume[2 * wid + 1] = counted; }
+    if (stop) break;
+  }
     // records offered / valid: one atomic pair per wave
     const u32 wa = wave_sum(my_all), wv = wave_sum(my_valid);
     // per-wave totals go to their own words: thousands of waves adding to three shared counters serialise (~50 ns each)
@@ -571,7 +582,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
 #ifdef ECB_TIMING
     if (lane == 0 && A.timing) for (int i = 0; i < 8; ++i) atomicAdd(A.timing + i, tacc[i]);
 #endif
-    if (lane == 0) { A.wave_counts[3 * wid] = wa; A.wave_counts[3 * wid + 1] = wv; A.wave_counts[3 * wid + 2] = wn; }
+    if (lane == 0) { A.wave_counts[3 * pw] = wa; A.wave_counts[3 * pw + 1] = wv; A.wave_counts[3 * pw + 2] = wn; }
 }
 
 __global__ __launch_bounds__(1024) void k_sum_counts(const u32* wave_counts, u64 waves, Counters* ctr) {
@@ -1411,17 +1422,20 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     while (h->n_ecs() * 2 > h->cap) { rc = grow_table(h, h->cap * 4); if (rc != ECB_OK) return rc; }
     int cus = 256;
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
-    // One contiguous slice per wave; ECB_ROUNDS x as many waves as are resident at once (a launch of 1.25 rounds costs 2).
+    // The stream is cut into ECB_ROUNDS x as many slices as waves are resident at once; the launch holds the resident
+    // waves only, which claim slice after slice (`waves` below counts slices).
     int bpc = 4;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_stream<false>, TPB, 0);
-    const u64 rounds = getenv("ECB_ROUNDS") ? std::max(1, atoi(getenv("ECB_ROUNDS"))) : 4;
-    u64 waves = (u64)cus * std::max(bpc, 1) * NWAVE * rounds;
+    const u64 rounds = getenv("ECB_ROUNDS") ? std::max(1, atoi(getenv("ECB_ROUNDS"))) : 32;
+    const u64 resident_blocks = (u64)cus * std::max(bpc, 1);
+    u64 waves = resident_blocks * NWAVE * rounds;
     waves = std::min<u64>(waves, (n + 2 * WT - 1) / (2 * WT));
     waves = std::max<u64>(waves, 1);
     u64 chunk = (n + waves - 1) / waves;
     chunk = (chunk + 3) & ~(u64)3;
     waves = (n + chunk - 1) / chunk;
-    const u64 blocks = (waves + NWAVE - 1) / NWAVE;
+    const u64 blocks = std::min<u64>((waves + NWAVE - 1) / NWAVE, resident_blocks);
+    const u64 pwaves = blocks * NWAVE;           // waves of the launch
     // a parked launch defers at most the reads of the tiles in flight
     const u64 need_q = waves * (u64)(WMAXR + 1) + 16;
     if (h->queue_cap < need_q) {
@@ -1441,7 +1455,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
         k_ranges<<<(unsigned)std::min<u64>(4096, (n + TPB - 1) / TPB), TPB, 0, h->stream>>>(
             d_loc, d_hf, d_pos, n, h->cfg.n_loci, h->cfg.n_haplotypes, h->rng_min, h->rng_max);
     u32* d_wcounts = nullptr;
-    POOL(h, P_WCOUNTS, d_wcounts, 3 * waves);
+    POOL(h, P_WCOUNTS, d_wcounts, 3 * pwaves);
     StreamArgs a{d_rid, d_loc, d_hf, n, chunk, h->prev_rid, h->cfg.n_loci, h->cfg.n_haplotypes,
                  h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr, h->read_slot, h->queue, h->queue_cap, d_resume, d_wcounts,
                  getenv("ECB_ABLATE") ? (u32)atoi(getenv("ECB_ABLATE")) : 0u, nullptr};
@@ -1452,12 +1466,13 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     for (;;) {
         HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));   // per launch
         HIPCHK(h, hipMemsetAsync(&h->ctr->full, 0, sizeof(u32), h->stream));
+        HIPCHK(h, hipMemsetAsync(&h->ctr->next_slice, 0, sizeof(u64), h->stream));
         a.table = h->table; a.cap_mask = h->cap - 1;
-        HIPCHK(h, hipMemsetAsync(d_wcounts, 0, 3 * waves * sizeof(u32), h->stream));
+        HIPCHK(h, hipMemsetAsync(d_wcounts, 0, 3 * pwaves * sizeof(u32), h->stream));
         if (h->prof) hipEventRecord(h->ev0, h->stream);
         k_stream<false><<<(unsigned)blocks, TPB, 0, h->stream>>>(a);
         if (h->prof) hipEventRecord(h->ev1, h->stream);
-        k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, waves, h->ctr);
+        k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, pwaves, h->ctr);
         HIPCHK(h, hipGetLastError());
         rc = sync_counters(h);
         if (h->prof) {
@@ -1673,11 +1688,11 @@ int ecb_verify_device(ecb_handle* h, const void* d_read_id, const void* d_locus,
     waves = (n + chunk - 1) / chunk;
     const u64 blocks = (waves + NWAVE - 1) / NWAVE;
     u64* d_resume = nullptr; u32* d_wcounts = nullptr;
-    POOL(h, P_RESUME, d_resume, 2 * waves); POOL(h, P_WCOUNTS, d_wcounts, 3 * waves);
+    POOL(h, P_RESUME, d_resume, 2 * waves); POOL(h, P_WCOUNTS, d_wcounts, 3 * blocks * NWAVE);
     std::vector<u64> r0(2 * waves);
     for (u64 b = 0; b < waves; ++b) r0[2 * b] = r0[2 * b + 1] = b * chunk;
     HIPCHK(h, hipMemcpyAsync(d_resume, r0.data(), 2 * waves * sizeof(u64), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemsetAsync(d_wcounts, 0, 3 * waves * sizeof(u32), h->stream));
+    HIPCHK(h, hipMemsetAsync(d_wcounts, 0, 3 * blocks * NWAVE * sizeof(u32), h->stream));
     HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));
     const u64 need_q = waves * (u64)(WMAXR + 1) + 16;
     if (h->queue_cap < need_q) {
@@ -1688,8 +1703,9 @@ int ecb_verify_device(ecb_handle* h, const void* d_read_id, const void* d_locus,
     StreamArgs a{(const u32*)d_read_id, (const u32*)d_locus, (const u32*)d_hapflag, n, chunk, 0xFFFFFFFFu,
                  h->cfg.n_loci, h->cfg.n_haplotypes, h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr,
                  h->read_slot, h->queue, h->queue_cap, d_resume, d_wcounts, 0u};
+    HIPCHK(h, hipMemsetAsync(&h->ctr->next_slice, 0, sizeof(u64), h->stream));
     k_stream<true><<<(unsigned)blocks, TPB, 0, h->stream>>>(a);
-    k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, waves, h->ctr);
+    k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, blocks * NWAVE, h->ctr);
     rc = sync_counters(h);
     if (rc != ECB_OK) return rc;
     *n_mismatch = h->hctr.n_ecs - before.n_ecs;
