@@ -585,6 +585,12 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
     if (lane == 0) { A.wave_counts[3 * pw] = wa; A.wave_counts[3 * pw + 1] = wv; A.wave_counts[3 * pw + 2] = wn; }
 }
 
+// resume points of a fresh batch: slice b starts (and has counted its records up to) record b * chunk
+__global__ void k_init_resume(u64* resume, u64 slices, u64 chunk) {
+    const u64 b = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (b < slices) { resume[2 * b] = b * chunk; resume[2 * b + 1] = b * chunk; }
+}
+
 __global__ __launch_bounds__(1024) void k_sum_counts(const u32* wave_counts, u64 waves, Counters* ctr) {
     __shared__ u64 s[3][16];
     u64 a = 0, v = 0, e = 0;
@@ -661,12 +667,21 @@ __global__ __launch_bounds__(TPB) void k_part_scatter(const u32* read_slot, u64 
     }
 }
 
-constexpr int TPB_COUNT = 1024;                // a hot EC makes its range's workgroup the tail: give it 16 waves
-__global__ __launch_bounds__(TPB_COUNT) void k_count_bins(const uint2* pairs, const u32* offs, u32 G, u32 n_buckets, u32 total,
-                                                          Slot* table) {
+constexpr int TPB_COUNT = 1024;
+// A hot EC makes its range the tail of the kernel (C2: one range of 512 held 4 % of the reads): the host cuts ranges
+// far above the average into pieces.  One piece = one workgroup; the pieces of a cut range add into the slots with
+// atomics, whole ranges are the only writer of their slots and just store.
+struct CountWork { u32 bucket, start, end, shared; };
+__global__ void k_bucket_starts(const u32* offs, u32 G, u32 n_buckets, u32 total, u32* starts) {
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n_buckets) starts[b] = offs[(u64)b * G];
+    if (b == n_buckets) starts[b] = total;
+}
+__global__ __launch_bounds__(TPB_COUNT) void k_count_bins(const uint2* pairs, const CountWork* work, Slot* table) {
     __shared__ u32 cnt[N_BINS], fst[N_BINS];
-    const u32 b = blockIdx.x, lane = threadIdx.x & 63u;
-    const u32 start = offs[(u64)b * G], end = (b + 1 < n_buckets) ? offs[(u64)(b + 1) * G] : total;
+    const CountWork wk = work[blockIdx.x];
+    const u32 b = wk.bucket, lane = threadIdx.x & 63u;
+    const u32 start = wk.start, end = wk.end;
     for (u32 q = threadIdx.x; q < N_BINS; q += TPB_COUNT) { cnt[q] = 0; fst[q] = 0xFFFFFFFFu; }
     __syncthreads();
     for (u32 i0 = start; i0 < end; i0 += 4 * TPB_COUNT) {
@@ -700,10 +715,10 @@ __global__ __launch_bounds__(TPB_COUNT) void k_count_bins(const uint2* pairs, co
     __syncthreads();
     for (u32 q = threadIdx.x; q < N_BINS; q += TPB_COUNT) {
         const u32 c = cnt[q];
-        if (c) {                                           // this workgroup is the only writer of its slots
+        if (c) {
             Slot* s = table + (((u64)b << BIN_BITS) | q);
-            s->count += c;
-            s->first_inv = max(s->first_inv, ~fst[q]);
+            if (wk.shared) { atomicAdd(&s->count, c); atomicMax(&s->first_inv, ~fst[q]); }
+            else { s->count += c; s->first_inv = max(s->first_inv, ~fst[q]); }      // the only writer of its slots
         }
     }
 }
@@ -1265,7 +1280,7 @@ struct ecb_handle {
     ecb_sizes sizes{};
 
     // device scratch reused across calls (grown on demand, freed at destroy)
-    enum { P_RESUME, P_SUMS, P_HIST, P_OFFS, P_PAIRS, P_CNT, P_PARTS, P_LIST, P_BITMAP, P_WPOP, P_WPREFIX, P_ROWLEN, P_ORDER,
+    enum { P_RESUME, P_SUMS, P_HIST, P_OFFS, P_PAIRS, P_CNT, P_PARTS, P_STARTS, P_WORK, P_LIST, P_BITMAP, P_WPOP, P_WPREFIX, P_ROWLEN, P_ORDER,
            P_WCOUNTS, P_RANK, P_INDPTR, P_COUNTS, P_INDICES, P_DATA, P_MS_KEYS, P_MS_KEYS2, P_MS_VALS, P_MS_VALS2, P_MS_TMP,
            P_MS_FLAG, P_MS_POS, P_MS_OKEY, P_MS_OFIRST, P_MS_OSTART, P_MS_X, P_N };
     void* pool[P_N] = {}; u64 pool_bytes[P_N] = {};
@@ -1445,12 +1460,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     }
     u64* d_resume = nullptr;
     POOL(h, P_RESUME, d_resume, 2 * waves);
-    {
-        std::vector<u64> r0(2 * waves);
-        for (u64 b = 0; b < waves; ++b) r0[2 * b] = r0[2 * b + 1] = b * chunk;
-        HIPCHK(h, hipMemcpyAsync(d_resume, r0.data(), 2 * waves * sizeof(u64), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-    }
+    k_init_resume<<<nblk(waves, TPB), TPB, 0, h->stream>>>(d_resume, waves, chunk);
     if (h->rng_min)
         k_ranges<<<(unsigned)std::min<u64>(4096, (n + TPB - 1) / TPB), TPB, 0, h->stream>>>(
             d_loc, d_hf, d_pos, n, h->cfg.n_loci, h->cfg.n_haplotypes, h->rng_min, h->rng_max);
@@ -1577,8 +1587,27 @@ int ensure_counts(ecb_handle* h) {
         int rc = excl_scan(h, hist, (u64)nb * G, offs, &total);
         if (rc == ECB_OK) {
             k_part_scatter<<<G, TPB, nb * 4, h->stream>>>(h->read_slot, R, nb, offs, pairs);
-            k_count_bins<<<nb, TPB_COUNT, 0, h->stream>>>(pairs, offs, G, nb, total, h->table);
-            hipError_t e = hipStreamSynchronize(h->stream);
+            // work list of k_count_bins: ranges far above the average are cut into pieces (see CountWork)
+            u32* d_starts = nullptr;
+            POOL(h, P_STARTS, d_starts, (u64)nb + 1);
+            k_bucket_starts<<<nblk((u64)nb + 1, TPB), TPB, 0, h->stream>>>(offs, G, nb, total, d_starts);
+            std::vector<u32> starts(nb + 1);
+            HIPCHK(h, hipMemcpyAsync(starts.data(), d_starts, ((u64)nb + 1) * sizeof(u32), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            const u32 piece = std::max<u32>(32768u, 2u * (u32)((total + nb - 1) / nb));
+            std::vector<CountWork> work;
+            work.reserve(nb + total / piece + 1);
+            for (u32 b = 0; b < nb; ++b) {
+                const u32 s0 = starts[b], s1 = starts[b + 1];
+                if (s1 == s0) continue;
+                if (s1 - s0 <= piece + piece / 2) { work.push_back(CountWork{b, s0, s1, 0u}); continue; }
+                for (u32 a = s0; a < s1; a += piece) work.push_back(CountWork{b, a, std::min(a + piece, s1), 1u});
+            }
+            CountWork* d_work = nullptr;
+            POOL(h, P_WORK, d_work, work.size());
+            HIPCHK(h, hipMemcpyAsync(d_work, work.data(), work.size() * sizeof(CountWork), hipMemcpyHostToDevice, h->stream));
+            if (!work.empty()) k_count_bins<<<(unsigned)work.size(), TPB_COUNT, 0, h->stream>>>(pairs, d_work, h->table);
+            hipError_t e = hipStreamSynchronize(h->stream);               // (also: `work` lives on this stack frame)
             if (e != hipSuccess) rc = fail(h, ECB_ERR_HIP, "k_count: %s", hipGetErrorString(e));
         }
         if (rc != ECB_OK) return rc;
@@ -1689,9 +1718,7 @@ int ecb_verify_device(ecb_handle* h, const void* d_read_id, const void* d_locus,
     const u64 blocks = (waves + NWAVE - 1) / NWAVE;
     u64* d_resume = nullptr; u32* d_wcounts = nullptr;
     POOL(h, P_RESUME, d_resume, 2 * waves); POOL(h, P_WCOUNTS, d_wcounts, 3 * blocks * NWAVE);
-    std::vector<u64> r0(2 * waves);
-    for (u64 b = 0; b < waves; ++b) r0[2 * b] = r0[2 * b + 1] = b * chunk;
-    HIPCHK(h, hipMemcpyAsync(d_resume, r0.data(), 2 * waves * sizeof(u64), hipMemcpyHostToDevice, h->stream));
+    k_init_resume<<<nblk(waves, TPB), TPB, 0, h->stream>>>(d_resume, waves, chunk);
     HIPCHK(h, hipMemsetAsync(d_wcounts, 0, 3 * blocks * NWAVE * sizeof(u32), h->stream));
     HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));
     const u64 need_q = waves * (u64)(WMAXR + 1) + 16;
