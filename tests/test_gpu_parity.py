@@ -319,7 +319,7 @@ def test_shard_tables_merge_to_the_single_handle_result():
 def test_full_size_config3_properties():
     """BASELINE config 3 at full size (100 M paired-end reads, 3.3 G records -- record indices pass 2^31): properties
     that need no slow oracle.  Totals match the generator's own counts; the stream cut into two contiguous shards
-    and merged gives the very same CSR (EC order included) as the whole."""
+    and merged by key range (the multi-GPU protocol on one card) gives the very same CSR (EC order included) as the whole."""
     import torch
     from alntools_amd import dist as ecdist
     sys_path_bench = os.path.join(os.path.dirname(__file__), "..")
@@ -363,20 +363,30 @@ def test_full_size_config3_properties():
         bb.push_device(r2, l2, h2)
         engines.append(ecdist.GpuEngine(bb, dev))
         meta.append(bb.table_sizes() + bb.counters()[:2])
-    root = ecdist.GpuEngine(ecb.EcBuilder(T, H, ec_capacity=1 << 24), dev)
-    base = 0
+    # ... by key range, as dist.py does across GPUs: cut both tables in two, merge range q of both, adopt the two results
+    root = ecdist.GpuEngine(ecb.EcBuilder(T, H, ec_capacity=1 << 20), dev)     # (small: the adopt has to grow it)
+    base, pieces = 0, []
     for eng, (ne, npairs, nreads, n_all, n_valid) in zip(engines, meta):
-        ent, prs = eng.table_export(base)
-        root.table_merge(ent, ne, prs, npairs)
+        pieces.append(eng.table_export_parts(base, 2))
         base += nreads
+        eng.b.close()
+    adopted = []
+    for q in range(2):
+        part = ecdist.GpuEngine(ecb.EcBuilder(T, H, ec_capacity=1 << 23), dev)
+        part.table_merge_many([(ent[eoff[q] * 4:eoff[q + 1] * 4], eoff[q + 1] - eoff[q], prs[poff[q]:poff[q + 1]], poff[q + 1] - poff[q])
+                               for ent, prs, eoff, poff in pieces])
+        pe_n, pp_n, _ = part.table_sizes()
+        adopted.append(part.table_export(0) + (pe_n, pp_n))
+        part.b.close()
+    del pieces
+    root.table_adopt_many([(pe, pe_n, pp, pp_n) for pe, pp, pe_n, pp_n in adopted])
     root.add_counters(sum(m[3] for m in meta), sum(m[4] for m in meta), base)
     s2 = root.b.finalize()
     merged = root.b.export()
     assert s2 == s
     for k in ("indptrA", "indicesA", "dataA", "dataN"):
         assert np.array_equal(whole[k], merged[k]), k
-    for e in engines + [root]:
-        e.b.close()
+    root.b.close()
 
 
 def test_sparse_format_round_trip_on_device(golden_dir):
