@@ -3,16 +3,16 @@
 W=${1:-c2}; OUT=${2:-gpurun_out/prof}
 R=$GRAFT_REPO_ROOT; mkdir -p $R/$OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT -- python $R/bench.py --workload $W --steps 3 --no-cpu-baseline > $R/$OUT/run.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT -- python $R/bench.py --workload $W --steps 5 --warmup 1 --no-cpu-baseline > $R/$OUT/run.log 2>&1
 cd $R
 f=$(find $OUT -name "*kernel_stats.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'anonymous namespace)::k_' in r['Name']]
-print("%-34s %6s %12s %12s" % ("kernel", "calls", "avg_ms", "total_ms"))
+print("%-34s %6s %10s %10s %10s %12s" % ("kernel", "calls", "avg_ms", "min_ms", "max_ms", "total_ms"))
 for r in rows:
     name = r['Name'].split('::')[1].split('(')[0] if '::' in r['Name'] else r['Name']
     name = r['Name'][r['Name'].index('k_'):].split('(')[0]
-    print("%-34s %6s %12.3f %12.3f" % (name[:34], r['Calls'], float(r['AverageNs']) / 1e6, float(r['TotalDurationNs']) / 1e6))
+    print("%-34s %6s %10.3f %10.3f %10.3f %12.3f" % (name[:34], r['Calls'], float(r['AverageNs']) / 1e6, float(r.get('MinNs', 0)) / 1e6, float(r.get('MaxNs', 0)) / 1e6, float(r['TotalDurationNs']) / 1e6))
 PY
 tail -1 $OUT/run.log | cut -c1-400
