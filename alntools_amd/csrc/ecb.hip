@@ -250,11 +250,13 @@ __device__ __forceinline__ void load_tile(const StreamArgs& A, u64 tb, u64 te, u
     for (int g = 0; g < NG; ++g) {
         const u64 i0 = tb + (u64)g * 256 + 4u * lane;
         if (i0 + 4 <= te) {
-            uint4 v = *reinterpret_cast<const uint4*>(A.rid + i0);
+            // (non-temporal: the stream is read once; without the hint it pushes the EC table's lines out of L2 -- measured 3 %)
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(A.rid + i0));
             R.rr[4 * g] = v.x; R.rr[4 * g + 1] = v.y; R.rr[4 * g + 2] = v.z; R.rr[4 * g + 3] = v.w;
-            v = *reinterpret_cast<const uint4*>(A.loc + i0);
+            v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(A.loc + i0));
             R.ll[4 * g] = v.x; R.ll[4 * g + 1] = v.y; R.ll[4 * g + 2] = v.z; R.ll[4 * g + 3] = v.w;
-            v = *reinterpret_cast<const uint4*>(A.hf + i0);
+            v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(A.hf + i0));
             R.hh[4 * g] = v.x; R.hh[4 * g + 1] = v.y; R.hh[4 * g + 2] = v.z; R.hh[4 * g + 3] = v.w;
         } else {
 #pragma unroll
