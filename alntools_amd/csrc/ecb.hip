@@ -207,6 +207,7 @@ struct StreamArgs {
     u64* queue; u64 queue_cap;       // head record index of deferred reads
     u64* resume;                     // per wave {next record to process, records counted up to}
     u32* wave_counts;                // per wave {records offered, records valid, ECs created}: summed by k_sum_counts
+    u64* wave_arena;                 // per wave {start, pairs left} of its arena reservation, kept from launch to launch
     u32 ablate;                      // profiling only (env ECB_ABLATE): 1 = stop after (a), 2 = after (b), 4 = no EC table
     u64* timing;                     // profiling only (-DECB_TIMING): clocks per phase, summed over waves
 };
@@ -282,8 +283,10 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
     const u64 pw = (u64)blockIdx.x * NWAVE + w;   // this wave
     u32 my_all = 0, my_valid = 0, my_new = 0;     // per lane; a wave sees far fewer than 2^32 records
     u32 bad = 0;
-    u64 chunk_at = 0;                             // this wave's current reservation in the key arena
-    u32 chunk_left = 0;
+    // this wave's current reservation in the key arena: what the last launch left of it is used first (a stream pushed in
+    // many small batches would otherwise leave the tail of a 512-pair chunk behind per wave and launch)
+    u64 chunk_at = VERIFY ? 0ull : A.wave_arena[2 * pw];
+    u32 chunk_left = VERIFY ? 0u : (u32)A.wave_arena[2 * pw + 1];
 #ifdef ECB_TIMING
     u64 tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
 #endif
@@ -585,6 +588,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
     if (lane == 0 && A.timing) for (int i = 0; i < 8; ++i) atomicAdd(A.timing + i, tacc[i]);
 #endif
     if (lane == 0) { A.wave_counts[3 * pw] = wa; A.wave_counts[3 * pw + 1] = wv; A.wave_counts[3 * pw + 2] = wn; }
+    if (!VERIFY && lane == 0) { A.wave_arena[2 * pw] = chunk_at; A.wave_arena[2 * pw + 1] = chunk_left; }
 }
 
 // resume points of a fresh batch: slice b starts (and has counted its records up to) record b * chunk
@@ -1254,6 +1258,7 @@ struct ecb_handle {
     std::string err;
     bool finalized = false;
     bool counted = false;             // Slot::count / first_inv hold the reads pushed so far (k_count ran)
+    u64* wave_arena = nullptr; u64 wave_arena_n = 0;   // see StreamArgs::wave_arena
     bool adopted = false;             // the table holds adopted entries in consecutive slots (no hashing): finalize / export only
 
     Slot* table = nullptr; u64 cap = 0;
@@ -1468,8 +1473,19 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
             d_loc, d_hf, d_pos, n, h->cfg.n_loci, h->cfg.n_haplotypes, h->rng_min, h->rng_max);
     u32* d_wcounts = nullptr;
     POOL(h, P_WCOUNTS, d_wcounts, 3 * pwaves);
+    if (h->wave_arena_n < pwaves) {                 // (only ever grows to the resident wave count; zero = nothing reserved)
+        u64* wa = nullptr;
+        HIPCHK(h, hipMalloc(&wa, 2 * pwaves * sizeof(u64)));
+        HIPCHK(h, hipMemsetAsync(wa, 0, 2 * pwaves * sizeof(u64), h->stream));
+        if (h->wave_arena) {
+            HIPCHK(h, hipMemcpyAsync(wa, h->wave_arena, 2 * h->wave_arena_n * sizeof(u64), hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            hipFree(h->wave_arena);
+        }
+        h->wave_arena = wa; h->wave_arena_n = pwaves;
+    }
     StreamArgs a{d_rid, d_loc, d_hf, n, chunk, h->prev_rid, h->cfg.n_loci, h->cfg.n_haplotypes,
-                 h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr, h->read_slot, h->queue, h->queue_cap, d_resume, d_wcounts,
+                 h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr, h->read_slot, h->queue, h->queue_cap, d_resume, d_wcounts, h->wave_arena,
                  getenv("ECB_ABLATE") ? (u32)atoi(getenv("ECB_ABLATE")) : 0u, nullptr};
 #ifdef ECB_TIMING
     HIPCHK(h, hipMalloc(&a.timing, 8 * sizeof(u64)));
@@ -1692,7 +1708,7 @@ void ecb_destroy(ecb_handle* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     free_results(h);
     hipFree(h->table); hipFree(h->arena); hipFree(h->ctr); hipFree(h->read_slot); hipFree(h->meta);
-    hipFree(h->rng_min); hipFree(h->rng_max); hipFree(h->queue);
+    hipFree(h->rng_min); hipFree(h->rng_max); hipFree(h->queue); hipFree(h->wave_arena);
     for (int i = 0; i < ecb_handle::P_N; ++i) hipFree(h->pool[i]);
     hipFree(h->st_rid); hipFree(h->st_loc); hipFree(h->st_hf); hipFree(h->st_pos);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -1731,7 +1747,7 @@ int ecb_verify_device(ecb_handle* h, const void* d_read_id, const void* d_locus,
     }
     StreamArgs a{(const u32*)d_read_id, (const u32*)d_locus, (const u32*)d_hapflag, n, chunk, 0xFFFFFFFFu,
                  h->cfg.n_loci, h->cfg.n_haplotypes, h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr,
-                 h->read_slot, h->queue, h->queue_cap, d_resume, d_wcounts, 0u};
+                 h->read_slot, h->queue, h->queue_cap, d_resume, d_wcounts, nullptr, 0u};
     HIPCHK(h, hipMemsetAsync(&h->ctr->next_slice, 0, sizeof(u64), h->stream));
     k_stream<true><<<(unsigned)blocks, TPB, 0, h->stream>>>(a);
     k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, blocks * NWAVE, h->ctr);
@@ -1757,6 +1773,7 @@ int ecb_reset(ecb_handle* h) {
 #endif
     HIPCHK(h, hipMemsetAsync(h->table, 0, h->cap * sizeof(Slot), h->stream));
     { int rc_ = clear_counters(h); if (rc_ != ECB_OK) return rc_; }
+    if (h->wave_arena) HIPCHK(h, hipMemsetAsync(h->wave_arena, 0, 2 * h->wave_arena_n * sizeof(u64), h->stream));
     if (h->read_slot && h->reads_hi) HIPCHK(h, hipMemsetAsync(h->read_slot, 0xFF, h->reads_hi * sizeof(u32), h->stream));
     if (h->rng_min) {
         const u64 ns = (u64)h->cfg.n_loci * h->cfg.n_haplotypes;

@@ -216,6 +216,22 @@ def test_mid_size_device_vs_c_oracle_properties(paired):
         assert np.array_equal(out[k], out2[k]), k
 
 
+def test_many_small_batches_do_not_leak_the_key_arena():
+    """A stream pushed in hundreds of small host batches into a handle whose key arena is only ~2.5 x the keys it has to
+    hold: a wave keeps the rest of its 512-pair reservation from launch to launch (leaving it behind per launch would
+    overrun this arena after a few dozen batches).  Result == one push."""
+    spec = synth.SynthSpec(40000, 3000, 8, paired=True)
+    t = synth.generate(spec, 0, spec.n_reads)
+    exp = _expect(t, spec.n_loci, spec.n_haps)
+    nnz = int(exp["indptr"][-1])
+    cap = 1 << 17
+    assert nnz * 2 < cap < nnz * 4
+    with ecb.EcBuilder(spec.n_loci, spec.n_haps, arena_capacity=cap, max_batch_records=4096) as b:
+        b.push(t["read_id"], t["locus"], t["hapflag"])           # > 300 launches of a few waves each
+        s = b.finalize()
+        _check(b.export(), s, exp)
+
+
 def test_shard_tables_merged_by_key_range_and_adopted():
     """The multi-GPU protocol of alntools_amd/dist.py without the collectives, on one GPU: three contiguous read shards,
     every table cut into three key ranges, range q of all shards merged (in shard order) into its own handle, the three
