@@ -5,12 +5,18 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np
 from alntools_amd import ecb, synth
 
-spec = synth.SynthSpec(4_000_000, 40_000, 8)
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
+PE = len(sys.argv) > 2 and sys.argv[2] == "pe"
+spec = synth.SynthSpec(R, 80_000 if PE else 40_000, 8, paired=PE)
 import torch
-g = synth.generate(spec, 0, spec.n_reads, device=torch.device("cuda:0"))
-h = {k: g[k].cpu().numpy().view(np.uint32) for k in ("read_id", "locus", "hapflag")}
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench
+rid, loc, hf, st = bench.generate_shard(spec, 0, spec.n_reads, torch.device("cuda:0"))
+h = {"read_id": rid.cpu().numpy().view(np.uint32), "locus": loc.cpu().numpy().view(np.uint32), "hapflag": hf.cpu().numpy().view(np.uint32)}
+del rid, loc, hf
+torch.cuda.empty_cache()
 n = len(h["read_id"])
-with ecb.EcBuilder(spec.n_loci, spec.n_haps, max_batch_records=1 << 24) as b:
+with ecb.EcBuilder(spec.n_loci, spec.n_haps, max_batch_records=1 << 24, ec_capacity=1 << 24) as b:
     for it in range(3):
         b.reset()
         t0 = time.perf_counter()
