@@ -164,6 +164,20 @@ def exchange_and_merge(engine, make_part_engine, make_root_engine, group=None, r
     return merged
 
 
+def reduce_ranges(range_min, range_max, group=None, device=None):
+    """`--rangefile` across ranks (the reference's merge of per-process extremes, ``bam_utils.py:713-721``): all-reduce the
+    per-(locus, haplotype) minima and maxima of ``reference_start`` (``EcBuilder.export_range_minmax`` of every rank) and
+    return ``max - min + 1``, 0 where no rank saw an alignment (``bam_utils.py:756-763``).  Every rank gets the result."""
+    import numpy as np
+    dev = device if device is not None else torch.device("cpu")
+    mn = torch.from_numpy(np.ascontiguousarray(range_min, dtype=np.int32)).to(dev)
+    mx = torch.from_numpy(np.ascontiguousarray(range_max, dtype=np.int32)).to(dev)
+    dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+    mn, mx = mn.cpu().numpy().astype(np.int64), mx.cpu().numpy().astype(np.int64)
+    return np.where(mx >= mn, mx - mn + 1, 0)
+
+
 def exchange_and_merge_on_root(engine, make_root_engine, group=None, root=0):
     """The simpler protocol (kept for comparison and as a fallback): every rank sends its whole table to the root, which
     merges them one after the other.  The root's merges are serial: at 8 ranks they cost more than a rank's own shard."""

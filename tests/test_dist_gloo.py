@@ -173,3 +173,35 @@ def test_multi_rank_merge_equals_single_process(tmp_path, world, paired, protoco
         assert np.array_equal(got[k], exp[k]), k
     assert int(got["n_all"]) == exp["n_all"] and int(got["n_valid"]) == exp["n_valid"]
     assert int(got["n_reads"]) == t["n_reads"]
+
+
+def _range_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rs = np.random.RandomState(7)
+    pos = rs.randint(0, 5000, size=(world, 40, 3))
+    seen = rs.rand(world, 40, 3) < 0.5
+    mn = np.where(seen[rank], pos[rank], np.iinfo(np.int32).max).astype(np.int32)
+    mx = np.where(seen[rank], pos[rank] + rs.randint(0, 100, size=(40, 3)), np.iinfo(np.int32).min).astype(np.int32)
+    got = ecdist.reduce_ranges(mn, mx)
+    np.save(out_path % rank, got)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_range_extremes_reduce_over_ranks(tmp_path):
+    """--rangefile with shards: min / max all-reduce, 0 where no rank saw an alignment."""
+    world = 2
+    out = str(tmp_path / "rng%d.npy")
+    mp.spawn(_range_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    rs = np.random.RandomState(7)
+    pos = rs.randint(0, 5000, size=(world, 40, 3))
+    seen = rs.rand(world, 40, 3) < 0.5
+    ext = rs.randint(0, 100, size=(40, 3))           # (rank 0 drew this; rank 1 draws the same numbers from the same seed)
+    big = np.iinfo(np.int64).max
+    mn = np.where(seen, pos, big).min(axis=0)
+    mx = np.where(seen, pos + ext, -1).max(axis=0)
+    exp = np.where(seen.any(axis=0), mx - mn + 1, 0)
+    for r in range(world):
+        assert np.array_equal(np.load(out % r), exp)
