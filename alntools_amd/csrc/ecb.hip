@@ -1161,9 +1161,42 @@ __global__ void k_ms_emit(const u64* keys, const u32* vals, const u32* flag, con
     if (i < n && flag[i]) { okey[pos[i]] = keys[i]; ofirst[pos[i]] = vals[i]; ostart[pos[i]] = (u32)i; }
     if (i == 0) ostart[n_out] = (u32)n;
 }
-__global__ void k_ms_split(const u64* okey, const u32* ostart, u64 n, u32* ec, u32* meta, u32* count) {
+__global__ void k_ms_split(const u64* okey, const u32* ostart, const u32* ocount, u64 n, u32* ec, u32* meta, u32* count) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (i < n) { ec[i] = (u32)(okey[i] >> 32); meta[i] = (u32)okey[i]; count[i] = ostart[i + 1] - ostart[i]; }
+    if (i < n) { ec[i] = (u32)(okey[i] >> 32); meta[i] = (u32)okey[i]; count[i] = ocount ? ocount[i] : ostart[i + 1] - ostart[i]; }
+}
+// multisample across GPUs: the keys of the final ECs in rank order; their ranks looked up in a shard's own table; the
+// shards' (EC, cell, file) triples combined on the root
+__global__ void k_export_keys(const Slot* table, const u32* order, u64 n, uint4* out) {
+    const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const Slot& s = table[order[e]];
+    out[e] = make_uint4((u32)s.lo, (u32)(s.lo >> 32), (u32)s.hi, (u32)(s.hi >> 32));
+}
+__global__ void k_set_global_rank(const uint4* keys, u64 n, const Slot* table, u64 cap_mask, u32* grank) {
+    const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const uint4 k = keys[e];
+    const u64 lo = ((u64)k.y << 32) | k.x, hi = ((u64)k.w << 32) | k.z;
+    u64 j = lo & cap_mask;
+    for (u64 probe = 0; probe <= cap_mask; ++probe, j = (j + 1) & cap_mask) {
+        const u64 clo = table[j].lo;
+        if (clo == 0ull) return;                                  // this shard never saw that EC
+        if (clo == lo && table[j].hi == hi) { grank[j] = (u32)e; return; }
+    }
+}
+__global__ void k_ms_out(const u64* okey, const u32* ofirst, const u32* ostart, u64 n, u32 read_base, u64* key, u32* count, u32* first) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n) { key[i] = okey[i]; count[i] = ostart[i + 1] - ostart[i]; first[i] = ofirst[i] + read_base; }
+}
+__global__ void k_ms_combine(const u64* keys, const u32* idx, const u32* flag, const u32* pos, u64 n, const u32* cnt_in, const u32* first_in,
+                             u64* okey, u32* ocount, u32* ofirst) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 o = pos[i] - (flag[i] ? 0u : 1u);                  // pos = exclusive scan of the head flags
+    if (flag[i]) okey[o] = keys[i];
+    atomicAdd(&ocount[o], cnt_in[idx[i]]);
+    atomicMin(&ofirst[o], first_in[idx[i]]);
 }
 
 
@@ -1267,7 +1300,8 @@ struct ecb_handle {
     Counters hctr{};                  // last read-back
     u32* read_slot = nullptr; u64 read_slot_cap = 0;
     u32* meta = nullptr; u64 meta_cap = 0, meta_hi = 0;   // multisample: cell | file << 22 per read
-    u64 n_triples = 0; u64* ms_okey = nullptr; u32 *ms_ofirst = nullptr, *ms_ostart = nullptr;
+    u64 n_triples = 0; u64* ms_okey = nullptr; u32 *ms_ofirst = nullptr, *ms_ostart = nullptr, *ms_ocount = nullptr;
+    bool ms_adopted = false;          // the triples came from ecb_ms_adopt_triples_device (multi-GPU)
     int *rng_min = nullptr, *rng_max = nullptr;
     u64* queue = nullptr; u64 queue_cap = 0;
     u64 n_ecs() const { return hctr.n_ecs; }
@@ -1289,7 +1323,7 @@ struct ecb_handle {
     // device scratch reused across calls (grown on demand, freed at destroy)
     enum { P_RESUME, P_SUMS, P_HIST, P_OFFS, P_PAIRS, P_CNT, P_PARTS, P_STARTS, P_WORK, P_LIST, P_BITMAP, P_WPOP, P_WPREFIX, P_ROWLEN, P_ORDER,
            P_WCOUNTS, P_RANK, P_INDPTR, P_COUNTS, P_INDICES, P_DATA, P_MS_KEYS, P_MS_KEYS2, P_MS_VALS, P_MS_VALS2, P_MS_TMP,
-           P_MS_FLAG, P_MS_POS, P_MS_OKEY, P_MS_OFIRST, P_MS_OSTART, P_MS_X, P_N };
+           P_MS_FLAG, P_MS_POS, P_MS_OKEY, P_MS_OFIRST, P_MS_OSTART, P_MS_X, P_MS_OCOUNT, P_MS_GRANK, P_MS_CIN, P_MS_FIN, P_N };
     void* pool[P_N] = {}; u64 pool_bytes[P_N] = {};
 
     // profiling
@@ -1647,6 +1681,34 @@ int compact_table(ecb_handle* h) {
     return ECB_OK;
 }
 
+// distinct (EC, cell, file) triples of this handle's reads: sort the per-read keys (EC id << 32 | meta), run-length encode.
+// ec_of_slot maps a table slot to the EC id to use (the handle's own ranks, or global ranks in a multi-GPU run).
+int ms_reduce(ecb_handle* h, const u32* ec_of_slot) {
+    const u64 R = h->n_reads;
+    if (h->meta_hi < R) return fail(h, ECB_ERR_STATE, "ecb_push_cells covered %llu of %llu reads",
+                                    (unsigned long long)h->meta_hi, (unsigned long long)R);
+    u64 *keys = nullptr, *keys2 = nullptr; u32 *vals = nullptr, *vals2 = nullptr, *flag = nullptr, *pos = nullptr;
+    POOL(h, P_MS_KEYS, keys, R); POOL(h, P_MS_KEYS2, keys2, R); POOL(h, P_MS_VALS, vals, R); POOL(h, P_MS_VALS2, vals2, R);
+    POOL(h, P_MS_FLAG, flag, R); POOL(h, P_MS_POS, pos, R);
+    k_ms_keys<<<nblk(R, TPB), TPB, 0, h->stream>>>(h->read_slot, ec_of_slot, h->meta, R, keys, vals);
+    size_t tmp_bytes = 0;
+    if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, R, 0, 64, h->stream) != hipSuccess)
+        return fail(h, ECB_ERR_HIP, "rocprim::radix_sort_pairs (size query)");
+    char* tmp = nullptr;
+    POOL(h, P_MS_TMP, tmp, tmp_bytes);
+    if (rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, R, 0, 64, h->stream) != hipSuccess)
+        return fail(h, ECB_ERR_HIP, "rocprim::radix_sort_pairs");
+    k_ms_heads<<<nblk(R, TPB), TPB, 0, h->stream>>>(keys2, R, flag);
+    u32 nt = 0;
+    int rc = excl_scan(h, flag, R, pos, &nt);
+    if (rc != ECB_OK) return rc;
+    POOL(h, P_MS_OKEY, h->ms_okey, nt); POOL(h, P_MS_OFIRST, h->ms_ofirst, nt); POOL(h, P_MS_OSTART, h->ms_ostart, (u64)nt + 1);
+    k_ms_emit<<<nblk(R, TPB), TPB, 0, h->stream>>>(keys2, vals2, flag, pos, R, nt, h->ms_okey, h->ms_ofirst, h->ms_ostart);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->n_triples = nt; h->ms_ocount = nullptr;
+    return ECB_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1781,7 +1843,7 @@ int ecb_reset(ecb_handle* h) {
         k_fill_i32<<<nblk(ns, TPB), TPB, 0, h->stream>>>(h->rng_max, ns, INT_MIN);
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->prev_rid = 0xFFFFFFFFu; h->n_reads = 0; h->reads_hi = 0; h->meta_hi = 0; h->n_triples = 0;
+    h->prev_rid = 0xFFFFFFFFu; h->n_reads = 0; h->reads_hi = 0; h->meta_hi = 0; h->n_triples = 0; h->ms_ocount = nullptr; h->ms_adopted = false;
     h->extra_all = h->extra_valid = h->extra_reads = 0;
     h->c_rid.clear(); h->c_loc.clear(); h->c_hf.clear(); h->c_pos.clear();
     h->finalized = false; h->counted = false; h->adopted = false; h->sizes = ecb_sizes{}; h->n_list = 0;
@@ -1922,31 +1984,14 @@ int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
     }
     h->sizes.n_ecs = E; h->sizes.nnz_a = nnz; h->sizes.n_samples = 1; h->sizes.nnz_n = E;
     if (h->cfg.flags & ECB_F_MULTISAMPLE) {
-        // distinct (EC, cell, file) triples: sort the per-read keys, run-length encode
-        const u64 R = h->n_reads;
-        if (h->extra_reads) return fail(h, ECB_ERR_STATE, "multisample is single-GPU in this build");
-        if (h->meta_hi < R) return fail(h, ECB_ERR_STATE, "ecb_push_cells covered %llu of %llu reads",
-                                        (unsigned long long)h->meta_hi, (unsigned long long)R);
-        u64 *keys = nullptr, *keys2 = nullptr; u32 *vals = nullptr, *vals2 = nullptr, *flag = nullptr, *pos = nullptr;
-        POOL(h, P_MS_KEYS, keys, R); POOL(h, P_MS_KEYS2, keys2, R); POOL(h, P_MS_VALS, vals, R); POOL(h, P_MS_VALS2, vals2, R);
-        POOL(h, P_MS_FLAG, flag, R); POOL(h, P_MS_POS, pos, R);
-        k_ms_keys<<<nblk(R, TPB), TPB, 0, h->stream>>>(h->read_slot, h->rank_of_slot, h->meta, R, keys, vals);
-        size_t tmp_bytes = 0;
-        if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, R, 0, 64, h->stream) != hipSuccess)
-            return fail(h, ECB_ERR_HIP, "rocprim::radix_sort_pairs (size query)");
-        char* tmp = nullptr;
-        POOL(h, P_MS_TMP, tmp, tmp_bytes);
-        if (rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, R, 0, 64, h->stream) != hipSuccess)
-            return fail(h, ECB_ERR_HIP, "rocprim::radix_sort_pairs");
-        k_ms_heads<<<nblk(R, TPB), TPB, 0, h->stream>>>(keys2, R, flag);
-        u32 nt = 0;
-        rc = excl_scan(h, flag, R, pos, &nt);
-        if (rc != ECB_OK) return rc;
-        POOL(h, P_MS_OKEY, h->ms_okey, nt); POOL(h, P_MS_OFIRST, h->ms_ofirst, nt); POOL(h, P_MS_OSTART, h->ms_ostart, (u64)nt + 1);
-        k_ms_emit<<<nblk(R, TPB), TPB, 0, h->stream>>>(keys2, vals2, flag, pos, R, nt, h->ms_okey, h->ms_ofirst, h->ms_ostart);
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        h->n_triples = nt;
-        h->sizes.n_samples = 0; h->sizes.nnz_n = nt;
+        if (h->adopted) {                            // multi-GPU: the triples arrive through ecb_ms_adopt_triples_device
+            h->n_triples = 0; h->sizes.n_samples = 0; h->sizes.nnz_n = 0;
+        } else {
+            if (h->extra_reads) return fail(h, ECB_ERR_STATE, "multisample across GPUs: adopt the merged ECs (ecb_table_adopt_device), then ecb_ms_adopt_triples_device");
+            rc = ms_reduce(h, h->rank_of_slot);
+            if (rc != ECB_OK) return rc;
+            h->sizes.n_samples = 0; h->sizes.nnz_n = h->n_triples;
+        }
     }
     h->sizes.all_alignments = h->hctr.all + h->extra_all;
     h->sizes.valid_alignments = valid;
@@ -2020,7 +2065,8 @@ int ecb_export_pairs(ecb_handle* h, uint32_t* ec, uint32_t* meta, uint32_t* coun
     const u64 nt = h->n_triples;
     u32* x = nullptr;
     POOL(h, P_MS_X, x, 3 * nt);
-    k_ms_split<<<nblk(nt, TPB), TPB, 0, h->stream>>>(h->ms_okey, h->ms_ostart, nt, x, x + nt, x + 2 * nt);
+    if (h->adopted && !h->ms_adopted) return fail(h, ECB_ERR_STATE, "multisample across GPUs: no triples adopted yet (ecb_ms_adopt_triples_device)");
+    k_ms_split<<<nblk(nt, TPB), TPB, 0, h->stream>>>(h->ms_okey, h->ms_ostart, h->ms_ocount, nt, x, x + nt, x + 2 * nt);
     HIPCHK(h, hipMemcpyAsync(ec, x, nt * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(meta, x + nt, nt * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(count, x + 2 * nt, nt * 4, hipMemcpyDeviceToHost, h->stream));
@@ -2142,7 +2188,6 @@ int ecb_table_adopt_batch_device(ecb_handle* h, uint32_t n_tables, const void* c
     if (rc != ECB_OK) return rc;
     if (!h->adopted && (h->n_ecs() || h->n_reads || !h->c_rid.empty()))
         return fail(h, ECB_ERR_STATE, "adopt needs an empty handle (use ecb_table_merge_device to add to a built table)");
-    if (h->cfg.flags & ECB_F_MULTISAMPLE) return fail(h, ECB_ERR_STATE, "multisample is single-GPU in this build");
     u64 add_e = 0, add_p = 0;
     for (u32 t = 0; t < n_tables; ++t) {
         if (n_entries[t] && (!d_entries[t] || (n_pairs[t] && !d_pairs[t]))) return fail(h, ECB_ERR_ARG, "null table buffers");
@@ -2179,6 +2224,99 @@ int ecb_table_adopt_batch_device(ecb_handle* h, uint32_t n_tables, const void* c
 
 int ecb_table_adopt_device(ecb_handle* h, const void* d_entries, uint64_t n_entries, const void* d_pairs, uint64_t n_pairs) {
     return ecb_table_adopt_batch_device(h, 1, &d_entries, &n_entries, &d_pairs, &n_pairs);
+}
+
+int ecb_export_ec_keys_device(ecb_handle* h, void* d_keys) {
+    if (!h || !d_keys) return ECB_ERR_ARG;
+    if (!h->finalized) return fail(h, ECB_ERR_STATE, "export before finalize");
+    HIPCHK(h, hipSetDevice(h->device));
+    const u64 E = h->sizes.n_ecs;
+    k_export_keys<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->table, h->order, E, (uint4*)d_keys);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ECB_OK;
+}
+
+int ecb_ms_local_triples_device(ecb_handle* h, const void* d_keys, uint64_t n_ecs, uint64_t read_base,
+                                void* d_key, void* d_count, void* d_first, uint64_t* n_triples) {
+    if (!h || !n_triples) return ECB_ERR_ARG;
+    if (!(h->cfg.flags & ECB_F_MULTISAMPLE)) return fail(h, ECB_ERR_STATE, "handle was created without ECB_F_MULTISAMPLE");
+    if (h->finalized || h->adopted) return fail(h, ECB_ERR_STATE, "a shard's triples come from the handle its reads were pushed into");
+    *n_triples = 0;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->c_rid.empty()) {                         // the stream ends here: the carried read is complete
+        int rc0 = stage_and_process(h, nullptr, nullptr, nullptr, nullptr, 0);
+        if (rc0 != ECB_OK) return rc0;
+    }
+    if (!h->n_reads) return ECB_OK;
+    if (!d_keys || !d_key || !d_count || !d_first) return fail(h, ECB_ERR_ARG, "null buffers");
+    if (read_base + h->n_reads >= (1ull << 32) - 1) return fail(h, ECB_ERR_LIMIT, "more than 2^32-2 reads in total");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = sync_counters(h);
+    if (rc != ECB_OK) return rc;
+    u32* grank = nullptr;
+    POOL(h, P_MS_GRANK, grank, h->cap);
+    HIPCHK(h, hipMemsetAsync(grank, 0xFF, h->cap * sizeof(u32), h->stream));
+    k_set_global_rank<<<nblk(n_ecs, TPB), TPB, 0, h->stream>>>((const uint4*)d_keys, n_ecs, h->table, h->cap - 1, grank);
+    rc = ms_reduce(h, grank);
+    if (rc != ECB_OK) return rc;
+    const u64 nt = h->n_triples;
+    u64 last = 0;                                     // keys are sorted: an EC id of 0xFFFFFFFF would be the last one
+    HIPCHK(h, hipMemcpyAsync(&last, h->ms_okey + (nt - 1), sizeof(u64), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if ((last >> 32) == 0xFFFFFFFFull) return fail(h, ECB_ERR_CONTRACT, "a read's EC is missing from the merged EC list");
+    k_ms_out<<<nblk(nt, TPB), TPB, 0, h->stream>>>(h->ms_okey, h->ms_ofirst, h->ms_ostart, nt, (u32)read_base, (u64*)d_key, (u32*)d_count, (u32*)d_first);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *n_triples = nt;
+    return ECB_OK;
+}
+
+int ecb_ms_adopt_triples_device(ecb_handle* h, uint32_t n_tables, const void* const* d_key, const void* const* d_count,
+                                const void* const* d_first, const uint64_t* n, uint64_t* n_triples) {
+    if (!h) return ECB_ERR_ARG;
+    if (!(h->cfg.flags & ECB_F_MULTISAMPLE)) return fail(h, ECB_ERR_STATE, "handle was created without ECB_F_MULTISAMPLE");
+    if (!h->finalized || !h->adopted) return fail(h, ECB_ERR_STATE, "triples are adopted by the finalized handle that adopted the merged ECs");
+    if (n_tables && (!d_key || !d_count || !d_first || !n)) return fail(h, ECB_ERR_ARG, "null lists");
+    HIPCHK(h, hipSetDevice(h->device));
+    u64 tot = 0;
+    for (u32 t = 0; t < n_tables; ++t) { if (n[t] && (!d_key[t] || !d_count[t] || !d_first[t])) return fail(h, ECB_ERR_ARG, "null buffers"); tot += n[t]; }
+    if (tot >= (1ull << 32)) return fail(h, ECB_ERR_LIMIT, "more than 2^32-1 triples");
+    u64 *keys = nullptr, *keys2 = nullptr; u32 *vals = nullptr, *vals2 = nullptr, *flag = nullptr, *pos = nullptr, *cin = nullptr, *fin = nullptr;
+    POOL(h, P_MS_KEYS, keys, tot); POOL(h, P_MS_KEYS2, keys2, tot); POOL(h, P_MS_VALS, vals, tot); POOL(h, P_MS_VALS2, vals2, tot);
+    POOL(h, P_MS_FLAG, flag, tot); POOL(h, P_MS_POS, pos, tot); POOL(h, P_MS_CIN, cin, tot); POOL(h, P_MS_FIN, fin, tot);
+    u64 at = 0;
+    for (u32 t = 0; t < n_tables; ++t) {
+        if (!n[t]) continue;
+        HIPCHK(h, hipMemcpyAsync(keys + at, d_key[t], n[t] * 8, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(cin + at, d_count[t], n[t] * 4, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(fin + at, d_first[t], n[t] * 4, hipMemcpyDeviceToDevice, h->stream));
+        at += n[t];
+    }
+    u32 nt = 0;
+    if (tot) {
+        k_iota<<<nblk(tot, TPB), TPB, 0, h->stream>>>((int*)vals, tot);
+        size_t tmp_bytes = 0;
+        if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, tot, 0, 64, h->stream) != hipSuccess)
+            return fail(h, ECB_ERR_HIP, "rocprim::radix_sort_pairs (size query)");
+        char* tmp = nullptr;
+        POOL(h, P_MS_TMP, tmp, tmp_bytes);
+        if (rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, tot, 0, 64, h->stream) != hipSuccess)
+            return fail(h, ECB_ERR_HIP, "rocprim::radix_sort_pairs");
+        k_ms_heads<<<nblk(tot, TPB), TPB, 0, h->stream>>>(keys2, tot, flag);
+        int rc = excl_scan(h, flag, tot, pos, &nt);
+        if (rc != ECB_OK) return rc;
+        POOL(h, P_MS_OKEY, h->ms_okey, nt); POOL(h, P_MS_OFIRST, h->ms_ofirst, nt); POOL(h, P_MS_OCOUNT, h->ms_ocount, nt);
+        HIPCHK(h, hipMemsetAsync(h->ms_ocount, 0, (u64)nt * 4, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->ms_ofirst, 0xFF, (u64)nt * 4, h->stream));
+        k_ms_combine<<<nblk(tot, TPB), TPB, 0, h->stream>>>(keys2, vals2, flag, pos, tot, cin, fin, h->ms_okey, h->ms_ocount, h->ms_ofirst);
+        u64 last = 0;
+        HIPCHK(h, hipMemcpyAsync(&last, keys2 + (tot - 1), sizeof(u64), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if ((last >> 32) >= h->sizes.n_ecs) return fail(h, ECB_ERR_CONTRACT, "triple with an EC id beyond the merged ECs");
+    }
+    h->n_triples = nt; h->ms_adopted = true;
+    h->sizes.n_samples = 0; h->sizes.nnz_n = nt;
+    if (n_triples) *n_triples = nt;
+    return ECB_OK;
 }
 
 int ecb_counters(ecb_handle* h, uint64_t* all_alignments, uint64_t* valid_alignments, uint64_t* n_reads) {

@@ -56,6 +56,23 @@ class GpuEngine(object):
     def table_adopt(self, ent, n_entries, prs, n_pairs):
         self.b.table_adopt_device(ent, n_entries, prs, n_pairs)
 
+    # multisample across GPUs
+    def ec_keys(self, n_ecs):
+        keys = torch.empty(2 * max(n_ecs, 1), dtype=torch.int64, device=self.device)
+        self.b.export_ec_keys_device(keys)
+        return keys
+
+    def ms_local_triples(self, keys, n_ecs, read_base):
+        n_reads = self.b.table_sizes()[2]
+        key = torch.empty(max(n_reads, 1), dtype=torch.int64, device=self.device)
+        cnt = torch.empty(max(n_reads, 1), dtype=torch.int32, device=self.device)
+        first = torch.empty(max(n_reads, 1), dtype=torch.int32, device=self.device)
+        n = self.b.ms_local_triples_device(keys, n_ecs, read_base, key, cnt, first)
+        return key, cnt, first, n
+
+    def ms_adopt_triples(self, tables):
+        return self.b.ms_adopt_triples_device(tables)
+
     def table_merge_many(self, tables):
         """``tables``: [(entries, n_entries, pairs, n_pairs), ...] merged in that order, one host wait for all."""
         self.b.table_merge_batch_device(tables)
@@ -162,6 +179,50 @@ def exchange_and_merge(engine, make_part_engine, make_root_engine, group=None, r
                              for r in range(world) if sz2[r][0]])
     merged.add_counters(sum(s[3] for s in sizes), sum(s[4] for s in sizes), sum(s[2] for s in sizes))
     return merged
+
+
+def exchange_multisample(engine, merged, n_ecs, group=None, root=0):
+    """Multisample (``bam_utils_multisample.py``) after :func:`exchange_and_merge` and the root's finalize: the per-(EC, cell,
+    file) read counts, i.e. the merge of the workers' ``ec[key][cell]`` (``:503-576``).  The root broadcasts the keys of the
+    final ECs in rank order (16 bytes each); every rank looks its own ECs up in that list and reduces its reads to distinct
+    (global EC, cell, file) triples; the triples go to the root, which adds up the ones a cell has on two ranks.
+    ``merged`` / ``n_ecs``: the finalized root engine and its EC count on the root, ignored elsewhere.  Returns the number
+    of distinct triples on the root (then ``export_pairs`` works as on one GPU), None elsewhere."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = engine.device
+    nreads = engine.table_sizes()[2]
+    info = torch.tensor([nreads, n_ecs if rank == root else 0], dtype=torch.int64, device=dev)
+    allinfo = torch.empty(world * 2, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(allinfo, info, group=group)
+    allinfo = allinfo.view(world, 2).cpu().tolist()
+    read_base = sum(a[0] for a in allinfo[:rank])
+    n_ecs = allinfo[root][1]
+    keys = merged.ec_keys(n_ecs) if rank == root else torch.empty(2 * max(n_ecs, 1), dtype=torch.int64, device=dev)
+    dist.broadcast(keys, src=root, group=group)
+    key, cnt, first, n = engine.ms_local_triples(keys, n_ecs, read_base)
+    mine = torch.tensor([n], dtype=torch.int64, device=dev)
+    alln = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(alln, mine, group=group)
+    alln = alln.cpu().tolist()
+    if rank != root:
+        if n:
+            _p2p([dist.P2POp(dist.isend, t[:n], root, group) for t in (key, cnt, first)])
+            if dev.type == "cuda":
+                torch.cuda.current_stream(dev).synchronize()
+        return None
+    bufs, ops = {}, []
+    for r in range(world):
+        if r == root or not alln[r]:
+            continue
+        bufs[r] = (torch.empty(alln[r], dtype=torch.int64, device=dev), torch.empty(alln[r], dtype=torch.int32, device=dev),
+                   torch.empty(alln[r], dtype=torch.int32, device=dev))
+        ops += [dist.P2POp(dist.irecv, t, r, group) for t in bufs[r]]
+    _p2p(ops)
+    if dev.type == "cuda":
+        torch.cuda.current_stream(dev).synchronize()
+    tables = [((key, cnt, first) if r == root else bufs[r]) + (alln[r],) for r in range(world) if alln[r]]
+    return merged.ms_adopt_triples(tables)
 
 
 def reduce_ranges(range_min, range_max, group=None, device=None):

@@ -27,7 +27,8 @@ SYMBOLS = ("ecb_abi_version", "ecb_device_count", "ecb_create", "ecb_destroy", "
            "ecb_push", "ecb_push_device", "ecb_push_cells", "ecb_verify_device", "ecb_finalize", "ecb_export",
            "ecb_export_device", "ecb_export_ranges", "ecb_export_range_minmax", "ecb_export_pairs", "ecb_export_read_ec", "ecb_table_sizes",
            "ecb_table_export_device", "ecb_table_merge_device", "ecb_table_export_parts_device",
-           "ecb_table_adopt_device", "ecb_table_merge_batch_device", "ecb_table_adopt_batch_device", "ecb_counters", "ecb_add_counters", "ecb_profile",
+           "ecb_table_adopt_device", "ecb_table_merge_batch_device", "ecb_table_adopt_batch_device",
+           "ecb_export_ec_keys_device", "ecb_ms_local_triples_device", "ecb_ms_adopt_triples_device", "ecb_counters", "ecb_add_counters", "ecb_profile",
            "ecb_profile_read", "ecb_csr_to_hapcsc_device", "ecb_hapcsc_to_csr_device")
 
 
@@ -96,6 +97,9 @@ def load():
     lib.ecb_table_adopt_device.argtypes = [vp, vp, u64, vp, u64]
     for f in (lib.ecb_table_merge_batch_device, lib.ecb_table_adopt_batch_device):
         f.argtypes = [vp, C.c_uint32, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64)]
+    lib.ecb_export_ec_keys_device.argtypes = [vp, vp]
+    lib.ecb_ms_local_triples_device.argtypes = [vp, vp, u64, u64, vp, vp, vp, C.POINTER(u64)]
+    lib.ecb_ms_adopt_triples_device.argtypes = [vp, C.c_uint32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
     lib.ecb_counters.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     lib.ecb_add_counters.argtypes = [vp, u64, u64, u64]
     lib.ecb_profile.argtypes = [vp, C.c_int]
@@ -307,6 +311,29 @@ class EcBuilder(object):
 
     def table_adopt_device(self, entries, n_entries, pairs, n_pairs):
         self._chk(self._lib.ecb_table_adopt_device(self._h, _dev_ptr(entries), n_entries, _dev_ptr(pairs), n_pairs))
+
+    # -- multisample across GPUs ----------------------------------------------
+    def export_ec_keys_device(self, keys):
+        """After finalize: the 16-byte key of every EC in rank order into ``keys`` (int64 tensor of 2 * n_ecs)."""
+        self._chk(self._lib.ecb_export_ec_keys_device(self._h, _dev_ptr(keys)))
+
+    def ms_local_triples_device(self, keys, n_ecs, read_base, out_key, out_count, out_first):
+        """A shard's (EC, cell, file) triples with global EC ids -> number of triples written."""
+        n = C.c_uint64()
+        self._chk(self._lib.ecb_ms_local_triples_device(self._h, _dev_ptr(keys), n_ecs, read_base, _dev_ptr(out_key),
+                                                        _dev_ptr(out_count), _dev_ptr(out_first), C.byref(n)))
+        return n.value
+
+    def ms_adopt_triples_device(self, tables):
+        """``tables``: [(key int64 tensor, count int32 tensor, first int32 tensor, n), ...] -> number of distinct triples."""
+        k = len(tables)
+        pk, pc = (C.c_void_p * k)(*[t[0].data_ptr() for t in tables]), (C.c_void_p * k)(*[t[1].data_ptr() for t in tables])
+        pf, nn = (C.c_void_p * k)(*[t[2].data_ptr() for t in tables]), (C.c_uint64 * k)(*[t[3] for t in tables])
+        out = C.c_uint64()
+        self._chk(self._lib.ecb_ms_adopt_triples_device(self._h, k, pk, pc, pf, nn, C.byref(out)))
+        if self.sizes is not None:
+            self.sizes["nnz_n"] = out.value
+        return out.value
 
     def counters(self):
         """-> (all_alignments, valid_alignments, n_reads) so far."""

@@ -170,6 +170,18 @@ int ecb_table_merge_batch_device(ecb_handle* h, uint32_t n_tables, const void* c
                                  const void* const* d_pairs, const uint64_t* n_pairs);
 int ecb_table_adopt_batch_device(ecb_handle* h, uint32_t n_tables, const void* const* d_entries, const uint64_t* n_entries,
                                  const void* const* d_pairs, const uint64_t* n_pairs);
+/* Multisample across GPUs (the shards' handles and the root's adopting handle all carry ECB_F_MULTISAMPLE).  After the ECs
+ * were merged and the root finalized: ecb_export_ec_keys_device writes the 16-byte key of every EC in rank order
+ * (n_ecs * 16 bytes; broadcast it).  A shard looks its own ECs up in that list and reduces its reads to distinct
+ * (EC, cell, file) triples with GLOBAL EC ids -- ecb_ms_local_triples_device: key = EC << 32 | meta (sorted), count,
+ * first read (read_base added); buffers of n_reads elements, *n_triples written.  The root combines the shards' triples
+ * (a cell whose reads straddle two shards: counts added, first = min) with ecb_ms_adopt_triples_device, after which
+ * ecb_export_pairs works as on one GPU.  (bam_utils_multisample.py:503-576: the merge of the workers' ec[key][cell].) */
+int ecb_export_ec_keys_device(ecb_handle* h, void* d_keys);
+int ecb_ms_local_triples_device(ecb_handle* h, const void* d_keys, uint64_t n_ecs, uint64_t read_base,
+                                void* d_key, void* d_count, void* d_first, uint64_t* n_triples);
+int ecb_ms_adopt_triples_device(ecb_handle* h, uint32_t n_tables, const void* const* d_key, const void* const* d_count,
+                                const void* const* d_first, const uint64_t* n, uint64_t* n_triples);
 int ecb_counters(ecb_handle* h, uint64_t* all_alignments, uint64_t* valid_alignments, uint64_t* n_reads);
 int ecb_add_counters(ecb_handle* h, uint64_t all_alignments, uint64_t valid_alignments, uint64_t n_reads);
 

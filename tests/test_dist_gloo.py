@@ -26,6 +26,7 @@ class OracleEngine(object):
         self.n_haps = n_haps
         self.table = {}              # (lo, hi) -> [count, first, pairs]
         self.n_all = self.n_valid = self.n_reads = 0
+        self.read_ident, self.meta, self.triples = [], None, None     # multisample: EC identity and cell|file<<22 per read
 
     @staticmethod
     def _ident(pairs):
@@ -43,6 +44,7 @@ class OracleEngine(object):
         def close():
             pairs = tuple(sorted(row.items()))
             e = self.table.setdefault(self._ident(pairs), [0, cur, pairs])
+            self.read_ident.append(self._ident(pairs))
             e[0] += 1
             e[1] = min(e[1], cur)
 
@@ -93,6 +95,33 @@ class OracleEngine(object):
         before = len(self.table)
         self.table_merge(ent, n_entries, prs, n_pairs)
         assert len(self.table) == before + n_entries, "adopted parts must hold distinct ECs"
+
+    # multisample across ranks
+    def ec_keys(self, n_ecs):
+        rows = sorted(self.table.items(), key=lambda kv: kv[1][1])
+        assert len(rows) == n_ecs
+        return torch.tensor([x for (lo, hi), _ in rows for x in (lo, hi)], dtype=torch.int64)
+
+    def ms_local_triples(self, keys, n_ecs, read_base):
+        k = keys.tolist()
+        rank_of = {(k[2 * e], k[2 * e + 1]): e for e in range(n_ecs)}
+        acc = {}
+        for i, ident in enumerate(self.read_ident):
+            t = acc.setdefault((rank_of[ident] << 32) | int(self.meta[i]), [0, i + read_base])
+            t[0] += 1
+        ks = sorted(acc)
+        return (torch.tensor(ks or [0], dtype=torch.int64), torch.tensor([acc[x][0] for x in ks] or [0], dtype=torch.int32),
+                torch.tensor([acc[x][1] for x in ks] or [0], dtype=torch.int32), len(ks))
+
+    def ms_adopt_triples(self, tables):
+        acc = {}
+        for key, cnt, first, n in tables:
+            for x, c, f in zip(key[:n].tolist(), cnt[:n].tolist(), first[:n].tolist()):
+                t = acc.setdefault(x, [0, f])
+                t[0] += c
+                t[1] = min(t[1], f)
+        self.triples = sorted((x >> 32, x & 0xFFFFFFFF, c, f) for x, (c, f) in acc.items())
+        return len(self.triples)
 
     def table_merge_many(self, tables):
         for t in tables:
@@ -205,3 +234,52 @@ def test_range_extremes_reduce_over_ranks(tmp_path):
     exp = np.where(seen.any(axis=0), mx - mn + 1, 0)
     for r in range(world):
         assert np.array_equal(np.load(out % r), exp)
+
+
+def _meta_of(g):
+    """cell | file << 22 of global read g (any fixed function: cells straddle the shards)"""
+    return ((g * 2654435761) % 37) | ((g % 3) << 22)
+
+
+def _ms_worker(rank, world, port, spec_args, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = synth.SynthSpec(**spec_args)
+    R = spec.n_reads
+    a, b = rank * R // world, (rank + 1) * R // world
+    base = synth.generate(spec, 0, a)["n_reads"] if a else 0
+    t = synth.generate(spec, a, b)
+    eng = OracleEngine(spec.n_haps)
+    eng.build(t)
+    eng.meta = [_meta_of(base + i) for i in range(eng.n_reads)]
+    fresh = lambda: OracleEngine(spec.n_haps)
+    merged = ecdist.exchange_and_merge(eng, fresh, fresh, root=0)
+    n_ecs = len(merged.table) if rank == 0 else None
+    n = ecdist.exchange_multisample(eng, merged, n_ecs, root=0)
+    if rank == 0:
+        assert n == len(merged.triples)
+        np.save(out_path, np.array(merged.triples, dtype=np.int64))
+    else:
+        assert n is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multisample_triples_over_ranks(tmp_path, world):
+    """(EC, cell, file) read counts with the reads sharded over ranks == one process over the whole stream."""
+    spec_args = dict(n_reads=3000, n_loci=300, n_haps=4, paired=True)
+    out = str(tmp_path / "triples.npy")
+    mp.spawn(_ms_worker, args=(world, _free_port(), spec_args, out), nprocs=world, join=True)
+    got = np.load(out)
+    spec = synth.SynthSpec(**spec_args)
+    one = OracleEngine(spec.n_haps)
+    one.build(synth.generate(spec, 0, spec.n_reads))
+    rank_of = {k: e for e, (k, _) in enumerate(sorted(one.table.items(), key=lambda kv: kv[1][1]))}
+    acc = {}
+    for i, ident in enumerate(one.read_ident):
+        t = acc.setdefault((rank_of[ident], _meta_of(i)), [0, i])
+        t[0] += 1
+    exp = np.array(sorted((e, m, c, f) for (e, m), (c, f) in acc.items()), dtype=np.int64)
+    assert np.array_equal(got, exp)

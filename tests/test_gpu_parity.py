@@ -538,3 +538,71 @@ def test_multisample_triples_at_scale():
     assert np.array_equal(got_key, exp_key)
     assert np.array_equal(pr["count"], exp_cnt)
     assert np.array_equal(pr["first"], exp_first)
+
+
+def test_multisample_over_shards_equals_one_handle():
+    """Multisample across GPUs, device side on one card: three contiguous read shards (every cell has reads in all of them),
+    ECs merged by key range and adopted by a multisample root, the root's EC keys looked up by every shard
+    (ecb_ms_local_triples_device), the shards' triples combined on the root (ecb_ms_adopt_triples_device)
+    == export_pairs of one handle over the whole stream."""
+    import torch
+    from alntools_amd import dist as ecdist
+    spec = synth.SynthSpec(60000, 3000, 8, paired=True)
+    dev = torch.device("cuda:0")
+    whole = synth.generate(spec, 0, spec.n_reads, device=dev)
+    n_reads = whole["n_reads"]
+    g = np.arange(n_reads, dtype=np.uint64)
+    meta = (((g * np.uint64(2654435761)) % np.uint64(211)) | ((g % np.uint64(3)) << np.uint64(22))).astype(np.uint32)
+    with ecb.EcBuilder(spec.n_loci, spec.n_haps, multisample=True) as one:
+        one.push_device(whole["read_id"], whole["locus"], whole["hapflag"])
+        one.push_cells(meta, 0)
+        s1 = one.finalize()
+        exp = one.export_pairs()
+        exp_a = one.export()
+    cuts = [0, 17000, 25000, spec.n_reads]
+    P = 3
+    shards, pieces, sizes, base = [], [], [], 0
+    for a, b_ in zip(cuts[:-1], cuts[1:]):
+        t = synth.generate(spec, a, b_, device=dev)
+        b = ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=1 << 12, multisample=True)
+        b.push_device(t["read_id"], t["locus"], t["hapflag"])
+        b.push_cells(meta[base:base + t["n_reads"]], 0)
+        eng = ecdist.GpuEngine(b, dev)
+        nreads = b.table_sizes()[2]
+        pieces.append(eng.table_export_parts(base, P))
+        sizes.append((nreads,) + b.counters()[:2])
+        shards.append((eng, base))
+        base += nreads
+    assert base == n_reads
+    root = ecdist.GpuEngine(ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=1 << 12, multisample=True), dev)
+    adopted = []
+    for q in range(P):
+        part = ecdist.GpuEngine(ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=1 << 12), dev)
+        part.table_merge_many([(ent[eoff[q] * 4:eoff[q + 1] * 4], eoff[q + 1] - eoff[q], prs[poff[q]:poff[q + 1]], poff[q + 1] - poff[q])
+                               for ent, prs, eoff, poff in pieces if eoff[q + 1] > eoff[q]])
+        pe_n, pp_n, _ = part.table_sizes()
+        adopted.append(part.table_export(0) + (pe_n, pp_n))
+        part.b.close()
+    root.table_adopt_many([(pe, pe_n, pp, pp_n) for pe, pp, pe_n, pp_n in adopted])
+    root.add_counters(sum(s[1] for s in sizes), sum(s[2] for s in sizes), base)
+    s = root.b.finalize()
+    assert s["n_ecs"] == s1["n_ecs"] and s["nnz_n"] == 0
+    with pytest.raises(ecb.EcbError):
+        root.b.export_pairs()                                            # no triples adopted yet
+    keys = root.ec_keys(s["n_ecs"])
+    tables = []
+    for eng, b0 in shards:
+        key, cnt, first, n = eng.ms_local_triples(keys, s["n_ecs"], b0)
+        assert n > 0 and bool((key[1:n] > key[:n - 1]).all())
+        tables.append((key, cnt, first, n))
+    nt = root.ms_adopt_triples(tables)
+    assert nt == s1["nnz_n"] and nt < sum(t[3] for t in tables)          # cells straddle the shards: triples were combined
+    got = root.b.export_pairs()
+    for k in ("ec", "cell", "file", "count", "first"):
+        assert np.array_equal(got[k], exp[k]), k
+    got_a = root.b.export()
+    for k in ("indptrA", "indicesA", "dataA"):
+        assert np.array_equal(got_a[k], exp_a[k]), k
+    for eng, _ in shards:
+        eng.b.close()
+    root.b.close()
