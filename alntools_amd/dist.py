@@ -200,6 +200,8 @@ def exchange_multisample(engine, merged, n_ecs, group=None, root=0):
     n_ecs = allinfo[root][1]
     keys = merged.ec_keys(n_ecs) if rank == root else torch.empty(2 * max(n_ecs, 1), dtype=torch.int64, device=dev)
     dist.broadcast(keys, src=root, group=group)
+    if dev.type == "cuda":
+        torch.cuda.current_stream(dev).synchronize()     # libecb works on its own stream: the keys must have landed
     key, cnt, first, n = engine.ms_local_triples(keys, n_ecs, read_base)
     mine = torch.tensor([n], dtype=torch.int64, device=dev)
     alln = torch.empty(world, dtype=torch.int64, device=dev)
