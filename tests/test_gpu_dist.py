@@ -1,0 +1,120 @@
+"""The multi-GPU protocol of alntools_amd/dist.py with real libecb handles in two processes sharing the one GPU of the
+test box.  RCCL refuses two ranks on one device, so the process group is gloo and a thin adapter stages the protocol's
+tensors through host memory; everything else (C ABI calls, kernels, message pattern) is what runs over RCCL on 8 GPUs."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+class HostStaged(object):
+    """GpuEngine seen through CPU tensors (gloo moves CPU tensors)."""
+    device = torch.device("cpu")
+
+    def __init__(self, eng):
+        self.e, self.dev = eng, eng.device
+
+    def _up(self, t):
+        return t.to(self.dev)
+
+    def table_sizes(self):
+        return self.e.table_sizes()
+
+    def counters(self):
+        return self.e.counters()
+
+    def add_counters(self, *a):
+        self.e.add_counters(*a)
+
+    def table_export(self, read_base):
+        ent, prs = self.e.table_export(read_base)
+        return ent.cpu(), prs.cpu()
+
+    def table_export_parts(self, read_base, n_parts):
+        ent, prs, eo, po = self.e.table_export_parts(read_base, n_parts)
+        return ent.cpu(), prs.cpu(), eo, po
+
+    def table_merge_many(self, tables):
+        self.e.table_merge_many([(self._up(a), n, self._up(b), m) for a, n, b, m in tables])
+
+    def table_adopt_many(self, tables):
+        self.e.table_adopt_many([(self._up(a), n, self._up(b), m) for a, n, b, m in tables])
+
+    def ec_keys(self, n_ecs):
+        return self.e.ec_keys(n_ecs).cpu()
+
+    def ms_local_triples(self, keys, n_ecs, read_base):
+        k, c, f, n = self.e.ms_local_triples(self._up(keys), n_ecs, read_base)
+        return k.cpu(), c.cpu(), f.cpu(), n
+
+    def ms_adopt_triples(self, tables):
+        return self.e.ms_adopt_triples([(self._up(k), self._up(c), self._up(f), n) for k, c, f, n in tables])
+
+
+def _meta(g):
+    g = g.astype(np.uint64)
+    return (((g * np.uint64(2654435761)) % np.uint64(101)) | ((g % np.uint64(3)) << np.uint64(22))).astype(np.uint32)
+
+
+def _worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from alntools_amd import dist as ecdist
+    from alntools_amd import ecb, synth
+    dev = torch.device("cuda:0")
+    spec = synth.SynthSpec(60000, 3000, 8, paired=True)
+    R = spec.n_reads
+    a, b_ = rank * R // world, (rank + 1) * R // world
+    base = synth.generate(spec, 0, a)["n_reads"] if a else 0
+    t = synth.generate(spec, a, b_, device=dev)
+    b = ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=1 << 12, multisample=True)
+    b.push_device(t["read_id"], t["locus"], t["hapflag"])
+    b.push_cells(_meta(np.arange(base, base + t["n_reads"])), 0)
+    eng = HostStaged(ecdist.GpuEngine(b, dev))
+    fresh = lambda ms: (lambda: HostStaged(ecdist.GpuEngine(ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=1 << 12, multisample=ms), dev)))
+    merged = ecdist.exchange_and_merge(eng, fresh(False), fresh(True), root=0)
+    n_ecs = None
+    if rank == 0:
+        s = merged.e.b.finalize()
+        n_ecs = s["n_ecs"]
+    nt = ecdist.exchange_multisample(eng, merged, n_ecs, root=0)
+    if rank == 0:
+        pr = merged.e.b.export_pairs()
+        out = merged.e.b.export()
+        np.savez(out_path, nt=nt, n_ecs=n_ecs, n_reads=s["n_reads"], all=s["all_alignments"], valid=s["valid_alignments"],
+                 **{"p_" + k: v for k, v in pr.items()}, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_processes_one_gpu_equal_one_handle(tmp_path):
+    from alntools_amd import ecb, synth
+    out = str(tmp_path / "merged.npz")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    spec = synth.SynthSpec(60000, 3000, 8, paired=True)
+    whole = synth.generate(spec, 0, spec.n_reads, device=torch.device("cuda:0"))
+    with ecb.EcBuilder(spec.n_loci, spec.n_haps, multisample=True) as one:
+        one.push_device(whole["read_id"], whole["locus"], whole["hapflag"])
+        one.push_cells(_meta(np.arange(whole["n_reads"])), 0)
+        s = one.finalize()
+        exp_p, exp_a = one.export_pairs(), one.export()
+    assert int(got["n_ecs"]) == s["n_ecs"] and int(got["nt"]) == s["nnz_n"] and int(got["n_reads"]) == s["n_reads"]
+    assert int(got["all"]) == s["all_alignments"] and int(got["valid"]) == s["valid_alignments"]
+    for k in ("ec", "cell", "file", "count", "first"):
+        assert np.array_equal(got["p_" + k], exp_p[k]), k
+    for k in ("indptrA", "indicesA", "dataA"):
+        assert np.array_equal(got[k], exp_a[k]), k
