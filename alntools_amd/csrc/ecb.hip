@@ -459,10 +459,12 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                         const u32 sg = L.seg[r_rl[k] + 1u];
                         const u32 s2 = sg & SMASK, e2 = (sg >> SBITS) & SMASK;
                         u32 o;
-                        do {
-                            if (++q[k] == e2) q[k] = s2;
+                        bool lapped = false, stuck = false;  // (a read's range always has a free slot: the second lap only keeps a
+                        do {                                 //  corrupted geometry from spinning a wave for ever)
+                            if (++q[k] == e2) { q[k] = s2; stuck = lapped; lapped = true; }
                             o = atomicCAS(&L.tkey[q[k]], 0u, r_key[k]);
-                        } while (o != 0u && o != r_key[k]);
+                        } while (o != 0u && o != r_key[k] && !stuck);
+                        if (stuck) bad |= ERR_CONTRACT;
                         made = (o == 0u);
                         atomicOr(&L.tmask[q[k]], r_bit[k]);
                     }
