@@ -874,7 +874,11 @@ __global__ void k_remap_read_slot(u32* read_slot, u64 n_reads, const Slot* old_t
 
 // occupied slots -> dense list (order irrelevant: ranks come from `first`); one global atomic per 4096 slots
 constexpr int TPB_COMPACT = 1024;
-__global__ __launch_bounds__(TPB_COMPACT) void k_compact(const Slot* table, u64 cap, u32* list, u64 max_list, u64* n_list) {
+// (finalize passes bitmap / list_fn: the slot being scanned already holds the EC's first read and key length, so the
+//  first-appearance bitmap is marked and both are written next to the list here -- coalesced -- instead of being gathered
+//  from the table again by separate kernels)
+__global__ __launch_bounds__(TPB_COMPACT) void k_compact(const Slot* table, u64 cap, u32* list, u64 max_list, u64* n_list,
+                                                         u32* bitmap, u64 n_bits, uint2* list_fn) {
     __shared__ u32 s_w[TPB_COMPACT / 64];
     __shared__ u64 s_base;
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
@@ -900,7 +904,15 @@ __global__ __launch_bounds__(TPB_COMPACT) void k_compact(const Slot* table, u64 
         const u64 base = s_base + s_w[w];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if ((occ >> k & 1u) && base + off[k] < max_list) list[base + off[k]] = (u32)(b + (u64)k * TPB_COMPACT + tid);
+            if ((occ >> k & 1u) && base + off[k] < max_list) {
+                const u64 i = b + (u64)k * TPB_COMPACT + tid;
+                list[base + off[k]] = (u32)i;
+                if (list_fn) {
+                    const u32 f = ~table[i].first_inv;
+                    list_fn[base + off[k]] = make_uint2(f, table[i].n);
+                    if (f < n_bits) atomicOr(&bitmap[f >> 5], 1u << (f & 31u));
+                }
+            }
         __syncthreads();
     }
 }
@@ -1036,12 +1048,6 @@ __global__ __launch_bounds__(TPB) void k_merge(const Slot* ent, u64 n, const uin
 // ---------------------------------------------------------------------------------------------
 // finalize: rank by first appearance, CSR emit
 // ---------------------------------------------------------------------------------------------
-__global__ void k_mark_first(const Slot* table, const u32* list, u64 n, u32* bitmap) {
-    const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const u32 f = ~table[list[e]].first_inv;
-    atomicOr(&bitmap[f >> 5], 1u << (f & 31u));
-}
 __global__ void k_popc(const u32* in, u64 n, u32* out) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i < n) out[i] = __popc(in[i]);
@@ -1090,15 +1096,18 @@ __global__ __launch_bounds__(TPB) void k_scan_apply(const u32* in, u64 n, const 
     for (int k = 0; k < SCAN_ITEMS; ++k) { const u64 i = b0 + (u64)threadIdx.x * SCAN_ITEMS + k; if (i < n) out[i] = ex; ex += v[k]; }
 }
 
-__global__ void k_rank(const Slot* table, const u32* list, u64 n, const u32* bitmap, const u32* wprefix,
+__global__ void k_rank(const u32* list, const uint2* list_fn, u64 n, u64 n_bits, const u32* bitmap, const u32* wprefix,
                        u32* order, u32* rowlen, u32* rank_of_slot) {
     const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (e >= n) return;
     const u32 si = list[e];
-    const u32 f = ~table[si].first_inv;
+    const uint2 fn = list_fn[e];
+    const u32 f = fn.x;
+    if (f >= n_bits) return;                       // (an EC without a first read: finalize's count check reports it)
     const u32 r = wprefix[f >> 5] + __popc(bitmap[f >> 5] & ((1u << (f & 31u)) - 1u));
+    if (r >= n) return;
     order[r] = si;
-    rowlen[r] = table[si].n;
+    rowlen[r] = fn.y;
     rank_of_slot[si] = r;
 }
 
@@ -1325,7 +1334,7 @@ struct ecb_handle {
     // device scratch reused across calls (grown on demand, freed at destroy)
     enum { P_RESUME, P_SUMS, P_HIST, P_OFFS, P_PAIRS, P_CNT, P_PARTS, P_STARTS, P_WORK, P_LIST, P_BITMAP, P_WPOP, P_WPREFIX, P_ROWLEN, P_ORDER,
            P_WCOUNTS, P_RANK, P_INDPTR, P_COUNTS, P_INDICES, P_DATA, P_MS_KEYS, P_MS_KEYS2, P_MS_VALS, P_MS_VALS2, P_MS_TMP,
-           P_MS_FLAG, P_MS_POS, P_MS_OKEY, P_MS_OFIRST, P_MS_OSTART, P_MS_X, P_MS_OCOUNT, P_MS_GRANK, P_MS_CIN, P_MS_FIN, P_N };
+           P_MS_FLAG, P_MS_POS, P_MS_OKEY, P_MS_OFIRST, P_MS_OSTART, P_MS_X, P_MS_OCOUNT, P_MS_GRANK, P_MS_CIN, P_MS_FIN, P_LISTFN, P_N };
     void* pool[P_N] = {}; u64 pool_bytes[P_N] = {};
 
     // profiling
@@ -1670,12 +1679,12 @@ int ensure_counts(ecb_handle* h) {
     return ECB_OK;
 }
 
-int compact_table(ecb_handle* h) {
+int compact_table(ecb_handle* h, u32* bitmap = nullptr, u64 n_bits = 0, uint2* list_fn = nullptr) {
     u64* d_n = nullptr;
     POOL(h, P_CNT, d_n, 1);
     HIPCHK(h, hipMemsetAsync(d_n, 0, sizeof(u64), h->stream));
     POOL(h, P_LIST, h->list, h->n_ecs());
-    k_compact<<<(unsigned)std::min<u64>(2048, (h->cap + 4 * TPB_COMPACT - 1) / (4 * TPB_COMPACT)), TPB_COMPACT, 0, h->stream>>>(h->table, h->cap, h->list, std::max<u64>(h->n_ecs(), 1), d_n);
+    k_compact<<<(unsigned)std::min<u64>(2048, (h->cap + 4 * TPB_COMPACT - 1) / (4 * TPB_COMPACT)), TPB_COMPACT, 0, h->stream>>>(h->table, h->cap, h->list, std::max<u64>(h->n_ecs(), 1), d_n, bitmap, n_bits, list_fn);
     HIPCHK(h, hipMemcpyAsync(&h->n_list, d_n, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->n_list != h->n_ecs()) return fail(h, ECB_ERR_HIP, "internal: %llu occupied slots but %llu ECs created",
@@ -1942,24 +1951,24 @@ int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
     if (E == 0 || valid == 0) return fail(h, ECB_ERR_EMPTY, "no valid alignments: nothing to build (the reference fails here too)");
     if (E >= (1ull << 31) - 1) return fail(h, ECB_ERR_LIMIT, "more than 2^31-2 equivalence classes");
     free_results(h);
-    int rc = compact_table(h);
-    if (rc != ECB_OK) return rc;
-    // rank by first appearance: bitmap over read indices, popcount prefix
+    // rank by first appearance: bitmap over read indices (marked while the table is compacted), popcount prefix
     const u64 total_reads = h->n_reads + h->extra_reads;
     const u64 words = (total_reads + 31) / 32 + 1;
     u32 *bitmap = nullptr, *wpop = nullptr, *wprefix = nullptr, *rowlen = nullptr;
+    uint2* list_fn = nullptr;
     POOL(h, P_BITMAP, bitmap, words); POOL(h, P_WPOP, wpop, words); POOL(h, P_WPREFIX, wprefix, words);
-    POOL(h, P_ROWLEN, rowlen, E);
+    POOL(h, P_ROWLEN, rowlen, E); POOL(h, P_LISTFN, list_fn, E);
     POOL(h, P_ORDER, h->order, E); POOL(h, P_RANK, h->rank_of_slot, h->cap);
     POOL(h, P_INDPTR, h->indptr, E + 1); POOL(h, P_COUNTS, h->counts, E);
     HIPCHK(h, hipMemsetAsync(bitmap, 0, words * 4, h->stream));
-    k_mark_first<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->table, h->list, E, bitmap);
+    int rc = compact_table(h, bitmap, total_reads, list_fn);
+    if (rc != ECB_OK) return rc;
     k_popc<<<nblk(words, TPB), TPB, 0, h->stream>>>(bitmap, words, wpop);
     u32 tot = 0;
     rc = excl_scan(h, wpop, words, wprefix, &tot);
     if (rc != ECB_OK) return rc;
     if (tot != E) return fail(h, ECB_ERR_HIP, "internal: %u distinct first-appearance indices for %llu ECs", tot, (unsigned long long)E);
-    k_rank<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->table, h->list, E, bitmap, wprefix, h->order, rowlen, h->rank_of_slot);
+    k_rank<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->list, list_fn, E, total_reads, bitmap, wprefix, h->order, rowlen, h->rank_of_slot);
     u32 nnz = 0;
     {   // 64-bit check of the row-length total before trusting a 32-bit scan
         rc = excl_scan(h, rowlen, E, h->indptr, &nnz);
