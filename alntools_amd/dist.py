@@ -87,6 +87,55 @@ class GpuEngine(object):
         self.b.add_counters(a, v, r)
 
 
+class HostStagedEngine(object):
+    """A :class:`GpuEngine` seen through CPU tensors, for process groups that only move host memory (``gloo``): used to
+    run the multi-rank protocol with real libecb handles when RCCL cannot be (two ranks sharing one GPU in the tests and
+    in ``bench.py``'s ``ECB_DIST_BACKEND=gloo`` rehearsal).  Every table crosses PCIe twice: never a measurement."""
+    device = torch.device("cpu")
+
+    def __init__(self, eng):
+        self.e, self.dev, self.b = eng, eng.device, eng.b
+
+    def _up(self, t):
+        return t.to(self.dev)
+
+    def table_sizes(self):
+        return self.e.table_sizes()
+
+    def counters(self):
+        return self.e.counters()
+
+    def add_counters(self, *a):
+        self.e.add_counters(*a)
+
+    def table_export(self, read_base):
+        ent, prs = self.e.table_export(read_base)
+        return ent.cpu(), prs.cpu()
+
+    def table_export_parts(self, read_base, n_parts):
+        ent, prs, eo, po = self.e.table_export_parts(read_base, n_parts)
+        return ent.cpu(), prs.cpu(), eo, po
+
+    def table_merge(self, ent, n, prs, m):
+        self.e.table_merge(self._up(ent), n, self._up(prs), m)
+
+    def table_merge_many(self, tables):
+        self.e.table_merge_many([(self._up(a), n, self._up(b), m) for a, n, b, m in tables])
+
+    def table_adopt_many(self, tables):
+        self.e.table_adopt_many([(self._up(a), n, self._up(b), m) for a, n, b, m in tables])
+
+    def ec_keys(self, n_ecs):
+        return self.e.ec_keys(n_ecs).cpu()
+
+    def ms_local_triples(self, keys, n_ecs, read_base):
+        k, c, f, n = self.e.ms_local_triples(self._up(keys), n_ecs, read_base)
+        return k.cpu(), c.cpu(), f.cpu(), n
+
+    def ms_adopt_triples(self, tables):
+        return self.e.ms_adopt_triples([(self._up(k), self._up(c), self._up(f), n) for k, c, f, n in tables])
+
+
 def _p2p(ops):
     if not ops:
         return

@@ -107,6 +107,11 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libecb has no CPU path")
+    # ECB_DIST_BACKEND=gloo: functional rehearsal of the N > 1 code path with all ranks on ONE GPU (RCCL refuses that); tables
+    # are staged through host memory, so its numbers mean nothing
+    rehearsal = os.environ.get("ECB_DIST_BACKEND", "nccl") == "gloo"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     use_dist = world > 1 or bool(os.environ.get("ECB_FORCE_DIST"))   # ECB_FORCE_DIST: exercise the RCCL path at N = 1
@@ -114,7 +119,11 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    red_dev = torch.device("cpu") if rehearsal else device          # where the small reductions of the timing live
 
     R, T, H, paired, desc = WORKLOADS[args.workload]
     spec = synth.SynthSpec(R, T, H, paired=paired)
@@ -128,11 +137,16 @@ def main():
     ec_cap = 1 << int(os.environ.get("ECB_EC_CAP_LOG2", "24" if args.workload in ("c3", "c3h") else "22"))
     b = ecb.EcBuilder(T, H, device=local, ec_capacity=ec_cap, arena_capacity=1 << 26)
     eng = ecdist.GpuEngine(b, device)
+    if rehearsal:
+        eng = ecdist.HostStagedEngine(eng)
     root_eng = part_eng = None
     if use_dist:        # the key range this rank merges (1/world of the ECs), and on rank 0 the table that adopts all ranges
         part_eng = ecdist.GpuEngine(ecb.EcBuilder(T, H, device=local, ec_capacity=1 << 23, arena_capacity=1 << 26), device)
         if rank == 0:
             root_eng = ecdist.GpuEngine(ecb.EcBuilder(T, H, device=local, ec_capacity=1 << 23, arena_capacity=1 << 26), device)
+        if rehearsal:
+            part_eng = ecdist.HostStagedEngine(part_eng)
+            root_eng = ecdist.HostStagedEngine(root_eng) if root_eng is not None else None
 
     def make_root():
         root_eng.b.reset()
@@ -184,10 +198,10 @@ def main():
         bad, skipped = b.verify_device(rid, loc, hf)
         exact = {"reads_differing_from_their_ec_key": bad, "reads_not_rechecked": skipped}
     if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt[0])
-        tot = torch.tensor([st["records"], st["reads"], st["valid"]], dtype=torch.int64, device=device)
+        tot = torch.tensor([st["records"], st["reads"], st["valid"]], dtype=torch.int64, device=red_dev)
         dist.all_reduce(tot)
         total_records, total_reads, total_valid = [int(x) for x in tot.tolist()]
     else:

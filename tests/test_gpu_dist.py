@@ -1,5 +1,5 @@
 """The multi-GPU protocol of alntools_amd/dist.py with real libecb handles in two processes sharing the one GPU of the
-test box.  RCCL refuses two ranks on one device, so the process group is gloo and a thin adapter stages the protocol's
+test box.  RCCL refuses two ranks on one device, so the process group is gloo and dist.HostStagedEngine stages the protocol's
 tensors through host memory; everything else (C ABI calls, kernels, message pattern) is what runs over RCCL on 8 GPUs."""
 import os
 import socket
@@ -11,50 +11,6 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
-
-
-class HostStaged(object):
-    """GpuEngine seen through CPU tensors (gloo moves CPU tensors)."""
-    device = torch.device("cpu")
-
-    def __init__(self, eng):
-        self.e, self.dev = eng, eng.device
-
-    def _up(self, t):
-        return t.to(self.dev)
-
-    def table_sizes(self):
-        return self.e.table_sizes()
-
-    def counters(self):
-        return self.e.counters()
-
-    def add_counters(self, *a):
-        self.e.add_counters(*a)
-
-    def table_export(self, read_base):
-        ent, prs = self.e.table_export(read_base)
-        return ent.cpu(), prs.cpu()
-
-    def table_export_parts(self, read_base, n_parts):
-        ent, prs, eo, po = self.e.table_export_parts(read_base, n_parts)
-        return ent.cpu(), prs.cpu(), eo, po
-
-    def table_merge_many(self, tables):
-        self.e.table_merge_many([(self._up(a), n, self._up(b), m) for a, n, b, m in tables])
-
-    def table_adopt_many(self, tables):
-        self.e.table_adopt_many([(self._up(a), n, self._up(b), m) for a, n, b, m in tables])
-
-    def ec_keys(self, n_ecs):
-        return self.e.ec_keys(n_ecs).cpu()
-
-    def ms_local_triples(self, keys, n_ecs, read_base):
-        k, c, f, n = self.e.ms_local_triples(self._up(keys), n_ecs, read_base)
-        return k.cpu(), c.cpu(), f.cpu(), n
-
-    def ms_adopt_triples(self, tables):
-        return self.e.ms_adopt_triples([(self._up(k), self._up(c), self._up(f), n) for k, c, f, n in tables])
 
 
 def _meta(g):
@@ -77,8 +33,8 @@ def _worker(rank, world, port, out_path):
     b = ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=1 << 12, multisample=True)
     b.push_device(t["read_id"], t["locus"], t["hapflag"])
     b.push_cells(_meta(np.arange(base, base + t["n_reads"])), 0)
-    eng = HostStaged(ecdist.GpuEngine(b, dev))
-    fresh = lambda ms: (lambda: HostStaged(ecdist.GpuEngine(ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=1 << 12, multisample=ms), dev)))
+    eng = ecdist.HostStagedEngine(ecdist.GpuEngine(b, dev))
+    fresh = lambda ms: (lambda: ecdist.HostStagedEngine(ecdist.GpuEngine(ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=1 << 12, multisample=ms), dev)))
     merged = ecdist.exchange_and_merge(eng, fresh(False), fresh(True), root=0)
     n_ecs = None
     if rank == 0:
