@@ -680,6 +680,60 @@ __global__ __launch_bounds__(TPB_PART) void k_part_scatter(const u32* read_slot,
     }
 }
 
+// The scatter with its elements sorted by range in LDS first: a workgroup takes STAGE reads at a time, ranks them within their
+// range (LDS counters), lays them out range by range in LDS and writes them from there -- elements of one range leave in
+// runs of consecutive addresses (STAGE / n_buckets of them on average) instead of one 8-byte store per lane and range.
+constexpr u32 STAGE = 8 * TPB_PART;            // 8 192 elements = 64 KB of LDS
+constexpr u32 STAGE_MAX_BUCKETS = 4096;        // 3 x 16 KB of counters / starts / cursors beside the stage
+__global__ __launch_bounds__(TPB_PART) void k_part_scatter_staged(const u32* read_slot, u64 n_reads, u32 n_buckets, const u32* offs,
+                                                             uint2* pairs) {
+    extern __shared__ u32 sh[];                   // cnt[nb] | start[nb] | gcur[nb] | stage[STAGE] (uint2)
+    u32 *cnt = sh, *start = sh + n_buckets, *gcur = sh + 2 * n_buckets;
+    uint2* stage = reinterpret_cast<uint2*>(sh + ((3 * n_buckets + 1) & ~1u));      // (8-byte aligned)
+    __shared__ u32 s_wave[TPB_PART / 64];
+    const u64 G = gridDim.x, g = blockIdx.x, per = (n_reads + G - 1) / G;
+    const u64 r0 = g * per, r1 = min(r0 + per, n_reads);
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const u32 bpt = (n_buckets + TPB_PART - 1) / TPB_PART;            // ranges per thread in the scan (1 .. 4)
+    for (u32 b = tid; b < n_buckets; b += TPB_PART) gcur[b] = offs[(u64)b * G + g];
+    for (u64 rb = r0; rb < r1; rb += STAGE) {
+        for (u32 b = tid; b < n_buckets; b += TPB_PART) cnt[b] = 0;
+        __syncthreads();
+        u32 s[8], lr[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const u64 r = rb + (u64)k * TPB_PART + tid;
+            s[k] = r < r1 ? read_slot[r] : PENDING;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (s[k] != PENDING) lr[k] = atomicAdd(&cnt[s[k] >> BIN_BITS], 1u);
+        __syncthreads();
+        // exclusive scan of cnt[] -> start[]: bpt consecutive ranges per thread, DPP scan per wave, wave totals through LDS
+        u32 mine = 0;
+        for (u32 j = 0; j < bpt; ++j) { const u32 b = tid * bpt + j; mine += b < n_buckets ? cnt[b] : 0u; }
+        const u32 incl = wave_incl_scan(mine);
+        if (lane == 63) s_wave[w] = incl;
+        __syncthreads();
+        u32 run = incl - mine;
+        for (u32 k = 0; k < w; ++k) run += s_wave[k];
+        for (u32 j = 0; j < bpt; ++j) { const u32 b = tid * bpt + j; if (b < n_buckets) { start[b] = run; run += cnt[b]; } }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (s[k] != PENDING) stage[start[s[k] >> BIN_BITS] + lr[k]] = make_uint2(s[k], (u32)(rb + (u64)k * TPB_PART + tid));
+        __syncthreads();
+        u32 n_here = 0;
+        for (u32 k = 0; k < TPB_PART / 64; ++k) n_here += s_wave[k];
+        for (u32 i = tid; i < n_here; i += TPB_PART) {
+            const uint2 e = stage[i];
+            const u32 b = e.x >> BIN_BITS;
+            pairs[gcur[b] + (i - start[b])] = e;
+        }
+        __syncthreads();
+        for (u32 b = tid; b < n_buckets; b += TPB_PART) gcur[b] += cnt[b];
+    }
+}
+
 constexpr int TPB_COUNT = 1024;
 // A hot EC makes its range the tail of the kernel (C2: one range of 512 held 4 % of the reads): the host cuts ranges
 // far above the average into pieces.  One piece = one workgroup; the pieces of a cut range add into the slots with
@@ -1654,7 +1708,12 @@ int ensure_counts(ecb_handle* h) {
         u32 total = 0;
         int rc = excl_scan(h, hist, (u64)nb * G, offs, &total);
         if (rc == ECB_OK) {
-            k_part_scatter<<<G, TPB_PART, nb * 4, h->stream>>>(h->read_slot, R, nb, offs, pairs);
+            if (nb <= STAGE_MAX_BUCKETS) {
+                static bool attr_set = false;
+                if (!attr_set) { hipFuncSetAttribute((const void*)k_part_scatter_staged, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE_MAX_BUCKETS * 4 + 8 + STAGE * 8); attr_set = true; }
+                k_part_scatter_staged<<<G, TPB_PART, 3 * nb * 4 + 8 + STAGE * 8, h->stream>>>(h->read_slot, R, nb, offs, pairs);
+            } else                                     // (tables beyond 2^25 slots: the counters would crowd the stage out of LDS)
+                k_part_scatter<<<G, TPB_PART, nb * 4, h->stream>>>(h->read_slot, R, nb, offs, pairs);
             // work list of k_count_bins: ranges far above the average are cut into pieces (see CountWork)
             u32* d_starts = nullptr;
             POOL(h, P_STARTS, d_starts, (u64)nb + 1);
