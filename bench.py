@@ -141,9 +141,12 @@ def main():
         eng = ecdist.HostStagedEngine(eng)
     root_eng = part_eng = None
     if use_dist:        # the key range this rank merges (1/world of the ECs), and on rank 0 the table that adopts all ranges
-        part_eng = ecdist.GpuEngine(ecb.EcBuilder(T, H, device=local, ec_capacity=1 << 23, arena_capacity=1 << 26), device)
+        # (sized for the workload like the shard's table: a key range holds 1/world of the ECs; the adopting table only needs a
+        #  slot per EC -- both grow by themselves if the guess is short, and the smaller they are the less there is to clear and scan)
+        part_cap = max(1 << 20, (2 * ec_cap) // world)
+        part_eng = ecdist.GpuEngine(ecb.EcBuilder(T, H, device=local, ec_capacity=part_cap, arena_capacity=1 << 26), device)
         if rank == 0:
-            root_eng = ecdist.GpuEngine(ecb.EcBuilder(T, H, device=local, ec_capacity=1 << 23, arena_capacity=1 << 26), device)
+            root_eng = ecdist.GpuEngine(ecb.EcBuilder(T, H, device=local, ec_capacity=ec_cap // 4, arena_capacity=1 << 26), device)
         if rehearsal:
             part_eng = ecdist.HostStagedEngine(part_eng)
             root_eng = ecdist.HostStagedEngine(root_eng) if root_eng is not None else None
