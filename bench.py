@@ -147,7 +147,8 @@ def main():
         part_cap = max(1 << 20, (2 * ec_cap) // world)
         part_eng = ecdist.GpuEngine(ecb.EcBuilder(T, H, device=local, ec_capacity=part_cap, arena_capacity=1 << 26), device)
         if rank == 0:
-            root_eng = ecdist.GpuEngine(ecb.EcBuilder(T, H, device=local, ec_capacity=ec_cap // 4, arena_capacity=1 << 26), device)
+            root_eng = ecdist.GpuEngine(ecb.EcBuilder(T, H, device=local, ec_capacity=(1 << 22) if args.workload in ("c3", "c3h") else 1 << 20,
+                                                           arena_capacity=1 << 26), device)
         if rehearsal:
             part_eng = ecdist.HostStagedEngine(part_eng)
             root_eng = ecdist.HostStagedEngine(root_eng) if root_eng is not None else None
