@@ -1362,6 +1362,7 @@ struct ecb_handle {
     bool finalized = false;
     bool counted = false;             // Slot::count / first_inv hold the reads pushed so far (k_count ran)
     u64* wave_arena = nullptr; u64 wave_arena_n = 0;   // see StreamArgs::wave_arena
+    bool scatter_attr_set = false;
     bool adopted = false;             // the table holds adopted entries in consecutive slots (no hashing): finalize / export only
 
     Slot* table = nullptr; u64 cap = 0;
@@ -1709,8 +1710,11 @@ int ensure_counts(ecb_handle* h) {
         int rc = excl_scan(h, hist, (u64)nb * G, offs, &total);
         if (rc == ECB_OK) {
             if (nb <= STAGE_MAX_BUCKETS) {
-                static bool attr_set = false;
-                if (!attr_set) { hipFuncSetAttribute((const void*)k_part_scatter_staged, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE_MAX_BUCKETS * 4 + 8 + STAGE * 8); attr_set = true; }
+                if (!h->scatter_attr_set) {             // (per handle = per device: more than 64 KB of dynamic LDS has to be asked for)
+                    HIPCHK(h, hipFuncSetAttribute((const void*)k_part_scatter_staged, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  3 * STAGE_MAX_BUCKETS * 4 + 8 + STAGE * 8));
+                    h->scatter_attr_set = true;
+                }
                 k_part_scatter_staged<<<G, TPB_PART, 3 * nb * 4 + 8 + STAGE * 8, h->stream>>>(h->read_slot, R, nb, offs, pairs);
             } else                                     // (tables beyond 2^25 slots: the counters would crowd the stage out of LDS)
                 k_part_scatter<<<G, TPB_PART, nb * 4, h->stream>>>(h->read_slot, R, nb, offs, pairs);
