@@ -184,6 +184,19 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if use_dist and world > 1:
+        # set-up, not work: RCCL opens its point-to-point channels lazily, on the first message between two ranks
+        ping = torch.zeros(world, dtype=torch.int64, device=red_dev)
+        pong = torch.empty(world, dtype=torch.int64, device=red_dev)
+        ops = []
+        for r in range(world):
+            if r != rank:
+                ops += [dist.P2POp(dist.isend, ping[r:r + 1], r), dist.P2POp(dist.irecv, pong[r:r + 1], r)]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        dist.all_reduce(ping)
+        if not rehearsal:
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     b.profile(True)
