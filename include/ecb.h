@@ -149,7 +149,9 @@ int ecb_verify_device(ecb_handle* h, const void* d_read_id, const void* d_locus,
  * ranges per process, bam_utils.py:646-658).  A rank serialises its EC table (device buffers the
  * caller allocates: n_entries * 32 bytes and n_pairs * 8 bytes), the caller moves it (RCCL), and the
  * receiving rank merges it -- the reference's ordered merge, bam_utils.py:680-724.
- * read_base = number of reads on all lower ranks (makes "first appearance" global). */
+ * read_base = number of reads on all lower ranks (makes "first appearance" global).
+ * ecb_table_sizes: *n_pairs is an upper bound of the key pairs in use (buffer size); the export writes the keys of the
+ * entries packed behind each other, Slot.off relative to the start of d_pairs. */
 int ecb_table_sizes(ecb_handle* h, uint64_t* n_entries, uint64_t* n_pairs, uint64_t* n_reads);
 int ecb_table_export_device(ecb_handle* h, void* d_entries, void* d_pairs, uint64_t read_base);
 int ecb_table_merge_device(ecb_handle* h, const void* d_entries, uint64_t n_entries,
