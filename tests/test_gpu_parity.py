@@ -606,3 +606,49 @@ def test_multisample_over_shards_equals_one_handle():
     for eng, _ in shards:
         eng.b.close()
     root.b.close()
+
+
+def test_multi_gpu_entry_points_refuse_wrong_states():
+    """State machine of the table / multisample exchange calls: loud errors, never a silent wrong result."""
+    import torch
+    from alntools_amd import dist as ecdist
+    dev = torch.device("cuda:0")
+    spec = synth.SynthSpec(2000, 300, 4, paired=False)
+    t = synth.generate(spec, 0, spec.n_reads, device=dev)
+    b = ecb.EcBuilder(spec.n_loci, spec.n_haps)                          # not multisample
+    b.push_device(t["read_id"], t["locus"], t["hapflag"])
+    eng = ecdist.GpuEngine(b, dev)
+    ne, npairs, nreads = b.table_sizes()
+    ent = torch.empty(ne * 4, dtype=torch.int64, device=dev)
+    prs = torch.empty(npairs, dtype=torch.int64, device=dev)
+    with pytest.raises(ecb.EcbError):
+        b.table_export_parts_device(ent, prs, 0, 0)                      # 1 .. 64 parts
+    with pytest.raises(ecb.EcbError):
+        b.table_export_parts_device(ent, prs, 0, 65)
+    with pytest.raises(ecb.EcbError):
+        b.table_export_parts_device(ent, prs, (1 << 32) - 10, 2)         # read numbering beyond 2^32
+    eo, po = b.table_export_parts_device(ent, prs, 0, 64)                # the most parts: everything accounted for
+    assert eo[-1] == ne and po[-1] <= npairs and len(eo) == 65
+    with pytest.raises(ecb.EcbError):
+        t2 = synth.generate(spec, 0, 10, device=dev)
+        b.push_device(t2["read_id"], t2["locus"], t2["hapflag"])         # the table was exported: the stream is closed
+    keys = torch.zeros(2, dtype=torch.int64, device=dev)
+    out = (torch.empty(nreads, dtype=torch.int64, device=dev), torch.empty(nreads, dtype=torch.int32, device=dev),
+           torch.empty(nreads, dtype=torch.int32, device=dev))
+    with pytest.raises(ecb.EcbError):
+        b.ms_local_triples_device(keys, 1, 0, *out)                      # handle without ECB_F_MULTISAMPLE
+    with pytest.raises(ecb.EcbError):
+        b.export_ec_keys_device(keys)                                    # before finalize
+    with pytest.raises(ecb.EcbError):
+        b.ms_adopt_triples_device([out + (0,)])
+    ms = ecb.EcBuilder(spec.n_loci, spec.n_haps, multisample=True)
+    ms.push_device(t["read_id"], t["locus"], t["hapflag"])
+    with pytest.raises(ecb.EcbError):
+        ms.ms_local_triples_device(keys, 1, 0, *out)                     # cells were never pushed
+    ms.push_cells(np.zeros(nreads, np.uint32), 0)
+    with pytest.raises(ecb.EcbError):
+        ms.ms_local_triples_device(keys, 1, 0, *out)                     # its ECs are not in that key list
+    with pytest.raises(ecb.EcbError):
+        ms.ms_adopt_triples_device([out + (0,)])                         # not an adopting, finalized handle
+    b.close()
+    ms.close()
