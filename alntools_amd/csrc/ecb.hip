@@ -1363,6 +1363,7 @@ struct ecb_handle {
     bool counted = false;             // Slot::count / first_inv hold the reads pushed so far (k_count ran)
     u64* wave_arena = nullptr; u64 wave_arena_n = 0;   // see StreamArgs::wave_arena
     bool scatter_attr_set = false;
+    u64 resident_blocks = 0, rounds = 32;     // k_stream's launch shape (queried once)
     bool adopted = false;             // the table holds adopted entries in consecutive slots (no hashing): finalize / export only
 
     Slot* table = nullptr; u64 cap = 0;
@@ -1547,14 +1548,16 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     h->reads_hi = reads_after;
     // keep the table at most half full before a batch (it grows again, via k_slow, if a batch overfills it)
     while (h->n_ecs() * 2 > h->cap) { rc = grow_table(h, h->cap * 4); if (rc != ECB_OK) return rc; }
-    int cus = 256;
-    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
     // The stream is cut into ECB_ROUNDS x as many slices as waves are resident at once; the launch holds the resident
     // waves only, which claim slice after slice (`waves` below counts slices).
-    int bpc = 4;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_stream<false>, TPB, 0);
-    const u64 rounds = getenv("ECB_ROUNDS") ? std::max(1, atoi(getenv("ECB_ROUNDS"))) : 32;
-    const u64 resident_blocks = (u64)cus * std::max(bpc, 1);
+    if (!h->resident_blocks) {                         // (asked once per handle: two runtime queries per batch add up on a streamed BAM)
+        int cus = 256, bpc = 4;
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_stream<false>, TPB, 0);
+        h->resident_blocks = (u64)std::max(cus, 1) * std::max(bpc, 1);
+        h->rounds = getenv("ECB_ROUNDS") ? std::max(1, atoi(getenv("ECB_ROUNDS"))) : 32;
+    }
+    const u64 rounds = h->rounds, resident_blocks = h->resident_blocks;
     u64 waves = resident_blocks * NWAVE * rounds;
     waves = std::min<u64>(waves, (n + 2 * WT - 1) / (2 * WT));
     waves = std::max<u64>(waves, 1);
