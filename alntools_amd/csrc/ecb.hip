@@ -47,18 +47,39 @@ constexpr u32 PENDING = 0xFFFFFFFFu;
 constexpr u32 ARENA_CHUNK = 512;     // pairs a wave reserves from the key arena per global atomic
 constexpr u32 ARENA_REGIONS = 64;    // the key arena has this many allocation cursors (see arena_alloc)
 constexpr u32 MAX_LOCI = 1u << 27;   // (locus << 5 | hap) + 1 must fit 32 bits
+constexpr u32 INL = 5;               // (locus, mask) pairs of an EC's key held in its table slot; longer keys continue in the arena
+constexpr u32 DEAD_KEY = 0xFFFFFFFFu;   // Slot::n1 of a slot whose key could not be stored (arena exhausted: the run fails)
+constexpr u32 SPIN_MAX = 1u << 16;   // polls of a claimed slot's n1 before giving up (ERR_INTERNAL: the launch winds down; never seen)
 
 constexpr u32 ERR_CONTRACT = 1u;     // device error bits (Counters::err)
 constexpr u32 ERR_RANGE = 2u;
 constexpr u32 ERR_ARENA = 4u;
 constexpr u32 ERR_QUEUE = 8u;
+constexpr u32 ERR_INTERNAL = 16u;
 
-struct Slot {                        // 32 bytes, one EC
-    u64 lo, hi;                      // 126-bit set hash, both non-zero once claimed
-    u32 count;                       // reads in this EC
-    u32 first_inv;                   // ~(smallest read index)  (atomicMax on zero-initialised memory)
-    u32 off, n;                      // key = arena[off .. off+n): (locus, haplotype mask) pairs
+// One EC = one 64-byte line.  EC identity is EXACT: `lo` is only the hash that picks the slot; a lookup that finds its hash
+// compares the read's {locus -> haplotype mask} set with the key stored in the slot, pair by pair, before it calls the slot
+// its own (bam_utils.py:307-312 compares the sorted tid strings).  Two different target sets with the same 64-bit hash
+// simply live in two slots.  Keys of up to INL loci sit in the line the lookup fetches anyway, so the compare costs no
+// memory traffic; longer keys continue in the key arena.
+// Life of a slot: lo 0 -> hash (atomicCAS: claimed); the claimant stores off and the pairs (write-through), waits for them,
+// then stores n1 = n + 1 (published).  Nothing else ever changes lo, n1, off or the pairs until the table is cleared.
+struct alignas(64) Slot {
+    u64 lo;                          // 64-bit set hash, non-zero once claimed
+    u32 n1;                          // 0 until the key is complete, then number of pairs + 1
+    u32 off;                         // key pairs INL.. : arena[off .. off + n - INL)
+    u32 count;                       // reads in this EC                       (k_count)
+    u32 first_inv;                   // ~(smallest read index)                 (k_count; atomicMax on zero-initialised memory)
+    uint2 pair[INL];                 // key pairs 0 .. min(n, INL): (locus, haplotype mask), in no particular order
 };
+static_assert(sizeof(Slot) == 64, "one EC per 64-byte line");
+// what ranks exchange (ecb_table_export_* / merge / adopt): 32 bytes per EC, its key pairs packed in a list of their own
+struct Entry {
+    u64 lo, reserved;
+    u32 count, first_inv;
+    u32 off, n;                      // key = pairs[off .. off + n), sorted by locus
+};
+static_assert(sizeof(Entry) == 32, "exchange format");
 
 struct Counters {
     u64 all, valid;                  // records offered / passing the filter
@@ -69,6 +90,7 @@ struct Counters {
     u32 full;                        // set when a read found no EC-table slot: workgroups park, host grows the table
     u64 arena_reg[ARENA_REGIONS];    // next free pair of every arena region
     u64 next_slice;                  // k_stream: next unclaimed slice of the batch (zeroed per launch)
+    u64 n_mismatch;                  // exactness pass (ecb_verify_device): reads whose set differs from their EC's key
 };
 
 // The key arena is cut into equal regions with a cursor each; a wave allocates from the region its index picks and moves
@@ -88,41 +110,25 @@ __device__ __forceinline__ u64 arena_alloc(Counters* ctr, u64 arena_cap, u32 n, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// hashing: EC identity = the SET of (locus, haplotype) targets of a read (bam_utils.py:307 builds a
-// sorted string for the same purpose).  The set is held as {locus -> haplotype mask}; its hash is the sum
-// over loci of four 32-bit mixes of (locus, mask), finalised to 2 x 63 bits.  The sum commutes, so records
-// need no sorting, and OR-ing haplotype bits makes duplicate (read, target) records vanish by itself.
+// hashing: an EC is the SET of (locus, haplotype) targets of a read (bam_utils.py:307 builds a sorted string for the
+// same purpose).  The set is held as {locus -> haplotype mask}; its hash is the sum over loci of a 64-bit mix of
+// (locus, mask).  The sum commutes, so records need no sorting, and OR-ing haplotype bits makes duplicate
+// (read, target) records vanish by itself.  The hash only places the EC in the table: equality is decided on the key.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ u64 mix64(u64 z) {
-    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
-    z ^= z >> 27; z *= 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return z;
-}
 __device__ __forceinline__ u32 fmix32(u32 h) {           // murmur3 finaliser: a bijection with full avalanche
     h ^= h >> 16; h *= 0x85EBCA6Bu;
     h ^= h >> 13; h *= 0xC2B2AE35u;
     h ^= h >> 16;
     return h;
 }
-// four 32-bit hashes of one (locus, haplotype mask) pair of a read's target set
-__device__ __forceinline__ void pair_hash(u32 locus, u32 mask, u32* h) {
+__device__ __forceinline__ u64 pair_hash64(u32 locus, u32 mask) {
     const u32 x = fmix32(locus ^ 0x9E3779B9u), y = fmix32(mask * 0x9E3779B1u + 0x7F4A7C15u);
-    h[0] = fmix32(x + y);
-    h[1] = fmix32((x ^ 0x85EBCA77u) - (y << 7 | y >> 25));
-    h[2] = fmix32((x << 13 | x >> 19) ^ (y + 0xC2B2AE3Du));
-    h[3] = fmix32(~x + (y << 19 | y >> 13) * 0x27D4EB2Fu);
+    const u32 h0 = fmix32(x + y);
+    const u32 h1 = fmix32((x ^ 0x85EBCA77u) - (y << 7 | y >> 25));
+    return ((u64)h1 << 32) | h0;
 }
-// the sums of fmix32 outputs are already uniformly spread: the table key is the pair of sums itself
-__device__ __forceinline__ void finish_hash(u64 s0, u64 s1, u32 n, u64& lo, u64& hi) {
-    lo = (s0 + ((u64)n << 32) + n) | 1ull;
-    hi = s1 | 1ull;
-}
-__device__ __forceinline__ void pair_hash64(u32 locus, u32 mask, u64& a, u64& b) {
-    u32 h[4];
-    pair_hash(locus, mask, h);
-    a = ((u64)h[1] << 32) | h[0]; b = ((u64)h[3] << 32) | h[2];
-}
+// the sums of fmix32 outputs are already uniformly spread: the table hash is the sum itself (made non-zero)
+__device__ __forceinline__ u64 finish_hash(u64 s0, u32 n) { return (s0 + ((u64)n << 32) + n) | 1ull; }
 
 // record filter, bam_utils.py:264-270 (host bits 12/13 carry the two non-flag terms)
 __device__ __forceinline__ bool rec_valid(u32 hf) {
@@ -133,28 +139,71 @@ __device__ __forceinline__ bool rec_valid(u32 hf) {
     return true;
 }
 
-// EC-table lookup / insert.  Returns the slot index, or ~0 if no slot within MAX_PROBE (table too full).
-// *created is set for the one caller that claimed the slot.  Keys only ever go 0 -> value, so a plain
-// load that shows another key (or ours) can be trusted; a plain load that shows "empty" is re-checked by
-// the CAS.  Read counts and first appearances are NOT maintained here: per-read atomics on a skewed EC
-// distribution run at ~5 G/s chip-wide (measured), so k_stream only records the slot of every read and
-// k_count reduces them afterwards without global atomics.
-__device__ __forceinline__ u64 table_find_or_insert(Slot* table, u64 cap_mask, u64 lo, u64 hi, bool* created) {
-    u64 j = lo & cap_mask;
-    *created = false;
-    for (u32 probe = 0; probe < MAX_PROBE; ++probe, j = (j + 1) & cap_mask) {
+// ---------------------------------------------------------------------------------------------
+// EC-table lookup / insert with exact keys.
+//   table_lookup: probes from j.  Plain loads: a cached line can only be an OLDER state of the slot (empty -> claimed ->
+//     published, never back), so what a stale line can cost is an atomic or a trip through table_settle, never a wrong
+//     answer: "empty" is re-checked by the CAS, "not published" and "hash equal, key different" are both settled on fresh
+//     reads, and a match is a match (the pairs of a slot only ever go from zero to their final value).
+//   table_settle: the slot carries our hash but its key was not (visibly) complete, or did not compare equal.  Polls n1
+//     and re-reads the key with read-modify-write atomics, which execute at the memory side, and decides for good.
+//   Callers that create a slot publish it (store off + pairs write-through, s_waitcnt vmcnt(0), then n1) BEFORE any lane
+//   of their wave calls table_settle: the creator a lane waits for may sit in its own wave.
+// Read counts and first appearances are NOT maintained here: per-read atomics on a skewed EC distribution run at
+// ~5 G/s chip-wide (measured), so k_stream only records the slot of every read and k_count reduces them afterwards.
+// ---------------------------------------------------------------------------------------------
+enum { ST_NONE = 0, ST_HIT, ST_CREATED, ST_PENDING, ST_FULL, ST_OTHER, ST_STUCK };
+struct SlotView { u32 n, off; uint2 p[INL]; };
+
+__device__ __forceinline__ u64 fresh64(u64* p) { return atomicOr(p, 0ull); }      // a read that cannot be served from a stale cache line
+__device__ __forceinline__ void store_wt64(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // write-through
+__device__ __forceinline__ void store_wt32(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u64 pack2(uint2 v) { return ((u64)v.y << 32) | v.x; }
+__device__ __forceinline__ uint2 unpack2(u64 v) { return make_uint2((u32)v, (u32)(v >> 32)); }
+// pair i of the key of a PUBLISHED slot, outside the kernels that publish (finalize, export, rehash): plain loads
+__device__ __forceinline__ uint2 key_pair(const Slot& s, const uint2* arena, u32 i) { return i < INL ? s.pair[i] : arena[(u64)s.off + (i - INL)]; }
+
+template <class Cmp>
+__device__ __forceinline__ int table_lookup(Slot* table, u64 cap_mask, u64 lo, u64& j, u32& probes, const Cmp& cmp) {
+    for (; probes < MAX_PROBE; ++probes, j = (j + 1) & cap_mask) {
         Slot* s = table + j;
-        u64 clo = s->lo, chi = s->hi;
-        if (clo == lo && chi == hi) return j;
-        if (clo != 0ull && (clo != lo || (chi != 0ull && chi != hi))) continue;
-        clo = atomicCAS(&s->lo, 0ull, lo);
-        if (clo != 0ull && clo != lo) continue;
-        chi = atomicCAS(&s->hi, 0ull, hi);
-        if (chi == 0ull) *created = true;
-        else if (chi != hi) continue;
-        return j;
+        const uint4* q = reinterpret_cast<const uint4*>(s);
+        const uint4 a = q[0];                                     // lo, n1, off
+        u64 clo = ((u64)a.y << 32) | a.x;
+        if (clo == 0ull) {
+            clo = atomicCAS(&s->lo, 0ull, lo);
+            if (clo == 0ull) return ST_CREATED;
+            if (clo == lo) return ST_PENDING;                     // claimed with our hash a moment ago: its key decides
+            continue;
+        }
+        if (clo != lo) continue;
+        if (a.z == 0u) return ST_PENDING;
+        const uint4 b = q[1], c = q[2], d = q[3];                 // count, first_inv, pair 0 | pairs 1, 2 | pairs 3, 4
+        SlotView v;
+        v.n = a.z - 1u; v.off = a.w;
+        v.p[0] = make_uint2(b.z, b.w); v.p[1] = make_uint2(c.x, c.y); v.p[2] = make_uint2(c.z, c.w);
+        v.p[3] = make_uint2(d.x, d.y); v.p[4] = make_uint2(d.z, d.w);
+        if (a.z != DEAD_KEY && cmp(v)) return ST_HIT;
+        return ST_PENDING;                                        // a stale line or a true hash collision: settled on fresh reads
     }
-    return ~0ull;
+    return ST_FULL;
+}
+template <class Cmp>
+__device__ __forceinline__ int table_settle(Slot* s, const Cmp& cmp) {
+    u32 n1 = 0;
+    for (u32 spin = 0; spin < SPIN_MAX; ++spin) {
+        n1 = atomicOr(&s->n1, 0u);
+        if (n1) break;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    if (!n1) return ST_STUCK;
+    if (n1 == DEAD_KEY) return ST_OTHER;
+    SlotView v;
+    v.n = n1 - 1u;
+    v.off = atomicOr(&s->off, 0u);
+#pragma unroll
+    for (u32 i = 0; i < INL; ++i) v.p[i] = i < v.n ? unpack2(fresh64(reinterpret_cast<u64*>(&s->pair[i]))) : make_uint2(0u, 0u);
+    return cmp(v) ? ST_HIT : ST_OTHER;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -184,7 +233,7 @@ constexpr u32 SMASK = (1u << SBITS) - 1u;
 struct alignas(16) WaveLds {
     u32 tkey[TSLOTS];                // per-read {locus -> mask} tables, 1.5 slots per record of the read; key = locus + 1
     u32 tmask[TSLOTS];               // (contiguous with tkey: cleared together with 16-byte stores)
-    u64 acc[WMAXR][2];               // per read: set-hash sums (2 x 64 bits)
+    u64 acc[WMAXR];                  // per read: set-hash sum
     unsigned short ent[WT];          // table entries created in this tile: slot | read << 10 (SBITS = 10 at 8 records per lane)
     unsigned short npair[WMAXR];     // per read: number of (locus, mask) pairs
     u32 seg[WMAXR + 3];              // seg[rl + 1]: first table slot of read rl | end slot << 16; repacked for finished reads
@@ -204,6 +253,7 @@ struct StreamArgs {
     uint2* arena; u64 arena_cap;
     Counters* ctr;
     u32* read_slot;                  // slot of every read (indexed by read_id)
+    u64 reads_hi;                    // read_slot holds [0, reads_hi): a read index beyond it is a broken run counter
     u64* queue; u64 queue_cap;       // head record index of deferred reads
     u64* resume;                     // per wave {next record to process, records counted up to}
     u32* wave_counts;                // per wave {records offered, records valid, ECs created}: summed by k_sum_counts
@@ -237,6 +287,39 @@ __device__ __forceinline__ u32 group_mask(int lo, int hi) {
 }
 
 struct TileRegs { u32 rr[RPL], ll[RPL], hh[RPL]; };
+
+// "is the key of this slot the target set of my read?" -- the read's set is its {locus -> mask} table in LDS, region
+// [s2, e2) probed from s2 + (key & pm) exactly as phase (b) inserted it.  Both sides hold distinct loci, so equal sizes
+// and every stored pair found with the same mask means the sets are equal.
+struct LdsSetCmp {
+    const WaveLds* L;
+    u32 s2, e2, pm, np;
+    uint2* arena;
+    bool fresh;                      // arena pairs through read-modify-write atomics (table_settle) instead of write-through-coherent loads
+    __device__ __forceinline__ bool has(u32 locus, u32 mask) const {
+        const u32 key = locus + 1u;
+        u32 q = s2 + (key & pm);
+        for (u32 t = s2; t < e2; ++t) {                  // (bounded by the region: a read's table always has a free slot)
+            const u32 k = L->tkey[q];
+            if (k == key) return L->tmask[q] == mask;
+            if (k == 0u) return false;
+            if (++q == e2) q = s2;
+        }
+        return false;
+    }
+    __device__ __forceinline__ bool operator()(const SlotView& v) const {
+        if (v.n != np) return false;
+        bool same = true;
+#pragma unroll
+        for (u32 i = 0; i < INL; ++i) if (i < v.n) same &= has(v.p[i].x, v.p[i].y);
+        for (u32 i = INL; i < v.n && same; ++i) {
+            u64* src = reinterpret_cast<u64*>(arena + (u64)v.off + (i - INL));
+            const uint2 pr = unpack2(fresh ? fresh64(src) : __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            same &= has(pr.x, pr.y);
+        }
+        return same;
+    }
+};
 
 // -DECB_TIMING: profiling build.  Every wave adds up the shader clocks it spends in each phase of a tile (stalls are
 // charged to the phase whose s_waitcnt sits them out); k_stream adds them into StreamArgs::timing[8].
@@ -320,7 +403,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
             uint4* z = reinterpret_cast<uint4*>(L.tkey);      // tkey and tmask are contiguous
 #pragma unroll
             for (int t = 0; t < (2 * TSLOTS) / (4 * 64); ++t) z[t * 64 + lane] = make_uint4(0, 0, 0, 0);
-            L.acc[lane][0] = 0; L.acc[lane][1] = 0; L.npair[lane] = 0;
+            L.acc[lane] = 0; L.npair[lane] = 0;
         }
         // ---- (a) filter, heads -------------------------------------------------------------------
         // Written with integer bit arithmetic throughout: every instruction costs a 4-cycle issue slot, and
@@ -341,7 +424,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                 const u32 cnt4 = ((1u << clamp04(cnt_hi - i0, 0, 4)) - 1u) &
                                  ~((1u << clamp04(cnt_lo - i0, 0, 4)) - 1u);
                 u32 prev = lane == 0 ? wrap : up;
-                u32 ok4 = 0, head4 = 0, big4 = 0;
+                u32 ok4 = 0, head4 = 0, big4 = 0, hap_or = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int k = 4 * g + j;
@@ -355,12 +438,14 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                     r_rl[k] = R.rr[k] - base;
                     r_key[k] = R.ll[k] + 1u;
                     r_bit[k] = 1u << ((f >> ECB_HAP_SHIFT) & 31u);
+                    hap_or |= (f >> ECB_HAP_SHIFT) & (0u - ok);       // a haplotype index of 32 or more would alias a low bit above
                     ok4 |= ok << j;
                     head4 |= (step & 1u) << j;
                     big4 |= min(step >> 1, 1u) << j;                 // the run counter may only step by 0 or 1
                 }
                 ok4 &= in4; head4 &= in4;
                 bad |= ((big4 & in4) | (head4 & ~ok4)) ? ERR_CONTRACT : 0u;   // ... and only on a valid record
+                bad |= (hap_or & ~31u) ? ERR_RANGE : 0u;                      // (indices below 32 are checked against n_haplotypes per EC, at emit)
                 my_all += __popc(cnt4); my_valid += __popc(cnt4 & ok4);
                 m_ok |= ok4 << (4 * g); m_head |= head4 << (4 * g); m_own |= (head4 & own4) << (4 * g);
             }
@@ -479,42 +564,46 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
         TICK(3);
         for (u32 e = lane; e < n_ent; e += 64) {
             const u32 en = L.ent[e], qq = en & SMASK, rl = en >> SBITS;
-            u64 a, b;
-            pair_hash64(L.tkey[qq] - 1u, L.tmask[qq], a, b);
-            atomicAdd(&L.acc[rl][0], a); atomicAdd(&L.acc[rl][1], b);
+            atomicAdd(&L.acc[rl], pair_hash64(L.tkey[qq] - 1u, L.tmask[qq]));
             atomicAdd(reinterpret_cast<u32*>(&L.npair[rl & ~1u]), (rl & 1u) ? 0x10000u : 1u);   // two 16-bit counters per word
         }
         wave_sync();
 
         TICK(4);
-        // ---- (c) one lane per read: EC lookup; a new EC gets its key from the read's LDS table ---------
-        u64 slot = ~0ull;
-        bool created = false;
-        u32 np = 0;
+        // ---- (c) one lane per read: EC lookup with exact key compare; a new EC gets its key from the read's LDS table ---------
+        u64 j = 0;
+        u32 st = ST_NONE, probes = 0, np = 0;
+        u64 lo = 0;
         const bool on = lane < nproc && !(A.ablate & 3u);
         const u32 rd = base + lane;
-        if (on && VERIFY) {                                         // exactness pass: set of this read == key of its EC ?
-            const Slot s = A.table[A.read_slot[rd]];
-            bool same = s.n == L.npair[lane];
-            const u32 b2 = L.seg[lane + 1] & SMASK, f2 = (L.seg[lane + 1] >> SBITS) & SMASK;
-            for (u32 t = b2; t < f2 && same; ++t) {
-                const u32 kk = L.tkey[t];
-                if (!kk) continue;
-                bool found = false;
-                for (u32 i = 0; i < s.n; ++i) {
-                    const uint2 pr = A.arena[s.off + i];
-                    found |= (pr.x == kk - 1u) && (pr.y == L.tmask[t]);
-                }
-                same = found;
+        LdsSetCmp cmp;
+        cmp.L = &L; cmp.arena = A.arena; cmp.fresh = false; cmp.s2 = cmp.e2 = cmp.pm = cmp.np = 0;
+        if (on) {
+            const u32 sg = L.seg[lane + 1];
+            cmp.s2 = sg & SMASK; cmp.e2 = (sg >> SBITS) & SMASK; cmp.pm = sg >> (2 * SBITS);
+            np = L.npair[lane];
+            cmp.np = np;
+            lo = finish_hash(L.acc[lane], np);
+            if ((u64)rd >= A.reads_hi) bad |= ERR_CONTRACT;          // the run counter ran past what this batch announced
+        }
+        if (on && !bad && VERIFY) {                                 // exactness pass: set of this read == key of its EC ?
+            const u32 sl = A.read_slot[rd];
+            bool same = false;
+            if (sl != PENDING) {
+                const uint4* q = reinterpret_cast<const uint4*>(A.table + sl);
+                const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+                SlotView v;
+                v.n = a.z - 1u; v.off = a.w;
+                v.p[0] = make_uint2(b.z, b.w); v.p[1] = make_uint2(c.x, c.y); v.p[2] = make_uint2(c.z, c.w);
+                v.p[3] = make_uint2(d.x, d.y); v.p[4] = make_uint2(d.z, d.w);
+                same = a.z != 0u && a.z != DEAD_KEY && cmp(v);
             }
             if (!same) my_new += 1;                                 // (counted as "mismatches" in verify mode)
         }
-        else if (on) {
-            u64 lo, hi;
-            np = L.npair[lane];
-            finish_hash(L.acc[lane][0], L.acc[lane][1], np, lo, hi);
-            if (A.ablate & 4u) slot = lo & A.cap_mask;
-            else slot = table_find_or_insert(A.table, A.cap_mask, lo, hi, &created);
+        else if (on && !bad) {
+            j = lo & A.cap_mask;
+            if (A.ablate & 4u) st = ST_HIT;
+            else st = table_lookup(A.table, A.cap_mask, lo, j, probes, cmp);
         }
         TICK(5);
         // Take over the prefetched tile HERE, right behind the lookup's own wait and before this tile issues any store.
@@ -527,49 +616,70 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
             asm volatile("" : "+v"(R.rr[k])); asm volatile("" : "+v"(R.ll[k])); asm volatile("" : "+v"(R.hh[k]));
         }
         asm volatile("" : "+v"(parked));
-        if (on && !VERIFY) {
-            if (slot == ~0ull) {                                    // table too full here: defer the read, park
-                atomicExch(&A.ctr->full, 1u);
-                const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
-                if (qi < A.queue_cap) A.queue[qi] = tb + unslot(L.seg[lane + 1] & SMASK); else atomicOr(&A.ctr->err, ERR_QUEUE);
-            } else {
-                A.read_slot[rd] = (u32)slot;
-            }
-        }
-        {
-            const u64 cmask = __ballot(created);
-            if (cmask) {                                            // some read of this tile founded an EC
-                const u32 want = created ? np : 0u;
-                const u32 incl = wave_incl_scan(want);
-                const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
-                if (total > chunk_left) {                           // reserve another stretch of the key arena
-                    const u32 take = max(total, ARENA_CHUNK);
-                    u64 at = 0;
-                    if (lane == 0) at = arena_alloc(A.ctr, A.arena_cap, take, (u32)pw);
-                    chunk_at = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(at >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)at);
-                    chunk_left = take;
-                    if (chunk_at == ~0ull) { bad |= ERR_ARENA; chunk_left = 0; }
-                }
-                if (!(bad & ERR_ARENA)) {
-                    const u32 off = (u32)(chunk_at + (incl - want));   // the arena holds < 2^32 pairs (Slot::off)
-                    if (created) { A.table[slot].off = off; A.table[slot].n = np; }
-                    // The key is copied by the whole wave from the tile's entry queue (every (read, locus) entry once, any
+        if (!VERIFY) {
+            // Founders publish their keys, THEN lanes whose slot was claimed but not (visibly) complete settle it -- the
+            // founder such a lane waits for may be a lane of this very wave.  One round in all but a handful of tiles.
+            for (u32 round = 0;; ++round) {
+                const u64 cmask = __ballot(st == ST_CREATED);
+                if (cmask) {
+                    const bool cr = st == ST_CREATED;
+                    const u32 want = cr && np > INL ? np - INL : 0u;    // pairs beyond the slot's own go to the key arena
+                    u32 off = 0;
+                    if (__ballot(want != 0u)) {
+                        const u32 incl = wave_incl_scan(want);
+                        const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+                        if (total > chunk_left) {                       // reserve another stretch of the key arena
+                            const u32 take = max(total, ARENA_CHUNK);
+                            u64 at = 0;
+                            if (lane == 0) at = arena_alloc(A.ctr, A.arena_cap, take, (u32)pw);
+                            chunk_at = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(at >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)at);
+                            chunk_left = take;
+                            if (chunk_at == ~0ull) { bad |= ERR_ARENA; chunk_left = 0; }
+                        }
+                        if (!(bad & ERR_ARENA)) {
+                            off = (u32)(chunk_at + (incl - want));       // the arena holds < 2^32 pairs (Slot::off)
+                            chunk_at += total; chunk_left -= total;
+                        }
+                    }
+                    const bool dead = (bad & ERR_ARENA) != 0u;           // no room for a long key: the run fails; the slots are marked, not left claimed
+                    // The keys are copied by the whole wave from the tile's entry queue (every (read, locus) entry once, any
                     // order: rows are sorted when they are emitted), not by the founding lane walking its read's table:
                     // that serial walk with 1-3 lanes alive was ~400 issue slots per tile, a quarter of the kernel.
-                    for (u32 e0 = 0; e0 < n_ent; e0 += 64) {
+                    const u32 j32 = (u32)j;
+                    if (!dead) for (u32 e0 = 0; e0 < n_ent; e0 += 64) {
                         const u32 e = e0 + lane;
                         const u32 en = e < n_ent ? L.ent[e] : 0u, qq = en & SMASK, rl = en >> SBITS;
-                        const u32 o = __shfl(off, rl);                                  // (all lanes: the loop bound is uniform)
+                        const u32 o = __shfl(off, rl), jj = __shfl(j32, rl);            // (all lanes: the loop bound is uniform)
                         if (e < n_ent && (cmask >> rl & 1ull)) {
                             const u32 was = atomicSub(reinterpret_cast<u32*>(&L.npair[rl & ~1u]), (rl & 1u) ? 0x10000u : 1u);
                             const u32 pos = ((rl & 1u) ? was >> 16 : was & 0xFFFFu) - 1u;   // a place of its own among the read's pairs
-                            A.arena[(u64)o + pos] = make_uint2(L.tkey[qq] - 1u, L.tmask[qq]);
+                            uint2* dst = pos < INL ? &A.table[jj].pair[pos] : A.arena + ((u64)o + (pos - INL));
+                            store_wt64(reinterpret_cast<u64*>(dst), pack2(make_uint2(L.tkey[qq] - 1u, L.tmask[qq])));
                         }
                     }
-                    chunk_at += total; chunk_left -= total;
+                    if (cr) store_wt32(&A.table[j].off, off);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every pair is in memory before any n1 says so
+                    if (cr) { store_wt32(&A.table[j].n1, dead ? DEAD_KEY : np + 1u); st = ST_HIT; }
+                    my_new += (u32)__popcll(cmask);
+                }
+                if (!__ballot(st == ST_PENDING)) break;
+                if (round >= 64u) { if (st == ST_PENDING) { bad |= ERR_INTERNAL; st = ST_NONE; } break; }
+                if (st == ST_PENDING) {
+                    LdsSetCmp fc = cmp;
+                    fc.fresh = true;
+                    const int r = table_settle(A.table + j, fc);
+                    if (r == ST_HIT) st = ST_HIT;
+                    else if (r == ST_STUCK) { bad |= ERR_INTERNAL; st = ST_NONE; atomicExch(&A.ctr->full, 1u); }   // (every wave stops at its next tile)
+                    else { j = (j + 1) & A.cap_mask; ++probes; st = table_lookup(A.table, A.cap_mask, lo, j, probes, cmp); }
                 }
             }
-            if (!VERIFY) my_new += (u32)__popcll(__ballot(created));
+            if (st == ST_FULL) {                                    // table too full here: defer the read, park
+                atomicExch(&A.ctr->full, 1u);
+                const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
+                if (qi < A.queue_cap) A.queue[qi] = tb + unslot(L.seg[lane + 1] & SMASK); else atomicOr(&A.ctr->err, ERR_QUEUE);
+            } else if (st == ST_HIT) {
+                A.read_slot[rd] = (u32)j;
+            }
         }
         wave_sync();
 
@@ -599,7 +709,7 @@ __global__ void k_init_resume(u64* resume, u64 slices, u64 chunk) {
     if (b < slices) { resume[2 * b] = b * chunk; resume[2 * b + 1] = b * chunk; }
 }
 
-__global__ __launch_bounds__(1024) void k_sum_counts(const u32* wave_counts, u64 waves, Counters* ctr) {
+__global__ __launch_bounds__(1024) void k_sum_counts(const u32* wave_counts, u64 waves, Counters* ctr, u32 verify) {
     __shared__ u64 s[3][16];
     u64 a = 0, v = 0, e = 0;
     for (u64 i = threadIdx.x; i < waves; i += 1024) { a += wave_counts[3 * i]; v += wave_counts[3 * i + 1]; e += wave_counts[3 * i + 2]; }
@@ -610,7 +720,8 @@ __global__ __launch_bounds__(1024) void k_sum_counts(const u32* wave_counts, u64
     if (threadIdx.x == 0) {
         a = v = e = 0;
         for (int k = 0; k < 16; ++k) { a += s[0][k]; v += s[1][k]; e += s[2][k]; }
-        ctr->all += a; ctr->valid += v; ctr->n_ecs += e;
+        if (verify) ctr->n_mismatch += e;                  // the exactness pass counts differing reads, and recounts nothing
+        else { ctr->all += a; ctr->valid += v; ctr->n_ecs += e; }
     }
 }
 
@@ -739,13 +850,42 @@ constexpr int TPB_COUNT = 1024;
 // far above the average into pieces.  One piece = one workgroup; the pieces of a cut range add into the slots with
 // atomics, whole ranges are the only writer of their slots and just store.
 struct CountWork { u32 bucket, start, end, shared; };
-__global__ void k_bucket_starts(const u32* offs, u32 G, u32 n_buckets, u32 total, u32* starts) {
+__global__ void k_bucket_starts(const u32* offs, u32 G, u32 n_buckets, const u64* total, u32* starts) {
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < n_buckets) starts[b] = offs[(u64)b * G];
-    if (b == n_buckets) starts[b] = total;
+    if (b == n_buckets) starts[b] = (u32)*total;
 }
-__global__ __launch_bounds__(TPB_COUNT) void k_count_bins(const uint2* pairs, const CountWork* work, Slot* table) {
+// The work list is built on the device (one workgroup: a few thousand ranges), so that nothing between the stream kernel and
+// the CSR waits for the host.  work[0 .. *n_work): whole ranges, or pieces of `piece` elements of a range far above the average.
+__global__ __launch_bounds__(1024) void k_build_work(const u32* starts, u32 n_buckets, u32 piece, CountWork* work, u32 max_work, u32* n_work) {
+    __shared__ u32 s_w[16];
+    __shared__ u32 s_carry;
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (u32 b0 = 0; b0 < n_buckets; b0 += 1024) {
+        const u32 b = b0 + tid;
+        u32 s0 = 0, s1 = 0, np = 0;
+        if (b < n_buckets) { s0 = starts[b]; s1 = starts[b + 1]; }
+        const u32 len = s1 - s0;
+        const bool cut = len > piece + piece / 2;
+        if (len) np = cut ? (len + piece - 1) / piece : 1u;
+        const u32 incl = wave_incl_scan(np);
+        if (lane == 63) s_w[w] = incl;
+        __syncthreads();
+        u32 at = s_carry + incl - np, tot = 0;
+        for (u32 k = 0; k < 16; ++k) { if (k < w) at += s_w[k]; tot += s_w[k]; }
+        for (u32 k = 0; k < np; ++k)
+            if (at + k < max_work) work[at + k] = cut ? CountWork{b, s0 + k * piece, min(s0 + (k + 1) * piece, s1), 1u} : CountWork{b, s0, s1, 0u};
+        __syncthreads();
+        if (tid == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (tid == 0) *n_work = min(s_carry, max_work);
+}
+__global__ __launch_bounds__(TPB_COUNT) void k_count_bins(const uint2* pairs, const CountWork* work, const u32* n_work, Slot* table) {
     __shared__ u32 cnt[N_BINS], fst[N_BINS];
+    if (blockIdx.x >= *n_work) return;                     // (the grid is the list's upper bound: its length never visits the host)
     const CountWork wk = work[blockIdx.x];
     const u32 b = wk.bucket, lane = threadIdx.x & 63u;
     const u32 start = wk.start, end = wk.end;
@@ -822,9 +962,14 @@ struct SlowArgs {
     Slot* table; u64 cap_mask;
     uint2* arena; u64 arena_cap;
     Counters* ctr;
-    u32* read_slot;
+    u32* read_slot; u64 reads_hi;
     u64* requeue; u64* n_requeue;                           // reads that still found no slot
+    u32 verify;                                             // exactness pass: compare with the read's EC instead of inserting
 };
+
+__device__ __forceinline__ u64 slow_probe_start(u32 lc, u64 cap2) { return __umul64hi((u64)(lc * 0x9E3779B1u) << 32, cap2); }
+
+struct NeverEqual { __device__ __forceinline__ bool operator()(const SlotView&) const { return false; } };   // k_slow compares as a workgroup, below
 
 __global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
     const u64 q = blockIdx.x;
@@ -833,17 +978,17 @@ __global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
     const u64 cap2 = 2 * L;
     u32* key = A.scr_key + A.scr_off[q];
     u32* msk = A.scr_mask + A.scr_off[q];
-    __shared__ u64 s_acc[TPB / 64][2];
+    __shared__ u64 s_acc[TPB / 64];
     __shared__ u32 s_n[TPB / 64];
-    __shared__ u64 s_off;
-    __shared__ u32 s_created, s_cnt, s_fits;
+    __shared__ u64 s_lo, s_j;
+    __shared__ u32 s_np, s_st, s_n1, s_off, s_cnt, s_same, s_probes;
 
     for (u64 i = tid; i < L; i += TPB) {
         const u32 f = A.hf[h + i];
         if (!rec_valid(f)) continue;
         const u32 lc = A.loc[h + i], hap = (f >> ECB_HAP_SHIFT) & 0xFFu;
         if (lc >= A.n_loci || hap >= A.n_haps) { atomicOr(&A.ctr->err, ERR_RANGE); continue; }
-        u64 p = __umul64hi((u64)(lc * 0x9E3779B1u) << 32, cap2);
+        u64 p = slow_probe_start(lc, cap2);
         for (;;) {
             const u32 old = atomicCAS(&key[p], 0u, lc + 1u);
             if (old == 0u || old == lc + 1u) { atomicOr(&msk[p], 1u << hap); break; }
@@ -852,82 +997,163 @@ __global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
     }
     __threadfence();
     __syncthreads();
-    u64 a0 = 0, a1 = 0;
+    u64 a0 = 0;
     u32 np = 0;
     for (u64 p = tid; p < cap2; p += TPB) {
         const u32 k = __hip_atomic_load(&key[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (k) {
             const u32 m = __hip_atomic_load(&msk[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ++np;
-            u64 x, y; pair_hash64(k - 1u, m, x, y);         // same set hash as k_stream
-            a0 += x; a1 += y;
+            a0 += pair_hash64(k - 1u, m);                   // same set hash as k_stream
         }
     }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { a0 += __shfl_xor(a0, d); a1 += __shfl_xor(a1, d); }
+    for (int d = 32; d > 0; d >>= 1) a0 += __shfl_xor(a0, d);
     np = wave_sum(np);
-    if (lane == 0) { s_acc[tid >> 6][0] = a0; s_acc[tid >> 6][1] = a1; s_n[tid >> 6] = np; }
+    if (lane == 0) { s_acc[tid >> 6] = a0; s_n[tid >> 6] = np; }
     __syncthreads();
+    const u32 r0 = A.rid[h];
     if (tid == 0) {
-        a0 = a1 = 0; np = 0;
-        for (int w = 0; w < TPB / 64; ++w) { a0 += s_acc[w][0]; a1 += s_acc[w][1]; np += s_n[w]; }
-        u64 lo, hi; finish_hash(a0, a1, np, lo, hi);
-        bool created = false;
-        const u32 r0 = A.rid[h];
-        const u64 slot = table_find_or_insert(A.table, A.cap_mask, lo, hi, &created);
-        s_created = 0; s_cnt = 0; s_fits = 0; s_off = 0;
-        if (slot == ~0ull) {
-            A.requeue[atomicAdd(A.n_requeue, 1ull)] = h;
-        } else {
-            A.read_slot[r0] = (u32)slot;
-            if (created) {
-                const u64 off = arena_alloc(A.ctr, A.arena_cap, np, blockIdx.x);
-                atomicAdd(&A.ctr->n_ecs, 1ull);
-                s_created = 1; s_off = off; s_fits = (off != ~0ull);
-                if (s_fits) { A.table[slot].off = (u32)off; A.table[slot].n = np; }
-                else atomicOr(&A.ctr->err, ERR_ARENA);
+        a0 = 0; np = 0;
+        for (int w = 0; w < TPB / 64; ++w) { a0 += s_acc[w]; np += s_n[w]; }
+        s_np = np; s_lo = finish_hash(a0, np); s_j = s_lo & A.cap_mask; s_probes = 0; s_cnt = 0;
+        if ((u64)r0 >= A.reads_hi) { atomicOr(&A.ctr->err, ERR_CONTRACT); s_st = ST_NONE; }
+        else s_st = ST_PENDING;
+    }
+    __syncthreads();
+    np = s_np;
+    // is the key of slot s_j (n = s_n1 - 1 pairs: INL in the slot, the rest at s_off in the arena) the set in the scratch table?
+    // Every thread takes pairs tid, tid + TPB, ...; fresh reads (the slot may have been published a moment ago by another CU).
+    auto same_key = [&]() -> bool {
+        const u32 n = s_n1 - 1u;
+        if (tid == 0) s_same = (n == np) ? 1u : 0u;
+        __syncthreads();
+        if (n == np) {
+            Slot* sl = A.table + s_j;
+            bool ok = true;
+            for (u32 i = tid; i < n && ok; i += TPB) {
+                u64* src = reinterpret_cast<u64*>(i < INL ? &sl->pair[i] : A.arena + ((u64)s_off + (i - INL)));
+                const uint2 pr = unpack2(fresh64(src));
+                ok = false;
+                if (pr.x < A.n_loci) {
+                    u64 p = slow_probe_start(pr.x, cap2);
+                    for (u64 t = 0; t < cap2; ++t) {
+                        const u32 k = __hip_atomic_load(&key[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (k == pr.x + 1u) { ok = __hip_atomic_load(&msk[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pr.y; break; }
+                        if (k == 0u) break;
+                        if (++p == cap2) p = 0;
+                    }
+                }
+            }
+            if (!ok) atomicAnd(&s_same, 0u);
+        }
+        __syncthreads();
+        return s_same != 0u;
+    };
+    if (A.verify) {
+        if (s_st != ST_NONE) {
+            if (tid == 0) {
+                const u32 sl = A.read_slot[r0];
+                s_j = sl; s_n1 = sl == PENDING ? 0u : A.table[sl].n1; s_off = sl == PENDING ? 0u : A.table[sl].off;
+            }
+            __syncthreads();
+            bool same = false;
+            if (s_n1 != 0u && s_n1 != DEAD_KEY) same = same_key();
+            if (tid == 0 && !same) atomicAdd(&A.ctr->n_mismatch, 1ull);
+        }
+    } else {
+        // find or insert, one probe sequence driven by thread 0, key compares by the whole workgroup
+        for (u32 round = 0; round < 4 * MAX_PROBE && s_st == ST_PENDING; ++round) {
+            __syncthreads();
+            if (tid == 0) {
+                u64 j = s_j; u32 probes = s_probes;
+                int st = table_lookup(A.table, A.cap_mask, s_lo, j, probes, NeverEqual());   // ST_PENDING = "slot j carries my hash"
+                s_j = j; s_probes = probes; s_st = (u32)st; s_n1 = 0; s_off = 0;
+                if (st == ST_PENDING) {
+                    Slot* sl = A.table + j;
+                    u32 n1 = 0;
+                    for (u32 spin = 0; spin < SPIN_MAX && !n1; ++spin) { n1 = atomicOr(&sl->n1, 0u); if (!n1) __builtin_amdgcn_s_sleep(4); }
+                    s_n1 = n1;
+                    s_off = atomicOr(&sl->off, 0u);
+                    if (!n1) { atomicOr(&A.ctr->err, ERR_INTERNAL); s_st = ST_NONE; }
+                } else if (st == ST_CREATED) {
+                    u64 off = 0;
+                    if (np > INL) off = arena_alloc(A.ctr, A.arena_cap, np - INL, blockIdx.x);
+                    atomicAdd(&A.ctr->n_ecs, 1ull);
+                    s_off = (u32)off;
+                    if (off == ~0ull) { atomicOr(&A.ctr->err, ERR_ARENA); s_n1 = DEAD_KEY; }
+                } else if (st == ST_FULL) {
+                    A.requeue[atomicAdd(A.n_requeue, 1ull)] = h;
+                }
+            }
+            __syncthreads();
+            if (s_st == ST_PENDING) {
+                bool same = false;
+                if (s_n1 != DEAD_KEY) same = same_key();
+                __syncthreads();
+                if (tid == 0) {
+                    if (same) { s_st = ST_HIT; A.read_slot[r0] = (u32)s_j; }
+                    else { s_j = (s_j + 1) & A.cap_mask; s_probes += 1; if (s_probes >= MAX_PROBE) { s_st = ST_FULL; A.requeue[atomicAdd(A.n_requeue, 1ull)] = h; } }
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        if (s_st == ST_CREATED) {                           // publish: pairs (write-through) by everybody, then n1 by one
+            Slot* sl = A.table + s_j;
+            const bool dead = s_n1 == DEAD_KEY;
+            if (!dead) for (u64 p = tid; p < cap2; p += TPB) {
+                const u32 k = __hip_atomic_load(&key[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (k) {
+                    const u32 m = __hip_atomic_load(&msk[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const u32 pos = atomicAdd(&s_cnt, 1u);
+                    uint2* dst = pos < INL ? &sl->pair[pos] : A.arena + ((u64)s_off + (pos - INL));
+                    store_wt64(reinterpret_cast<u64*>(dst), pack2(make_uint2(k - 1u, m)));
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                store_wt32(&sl->off, s_off);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                store_wt32(&sl->n1, dead ? DEAD_KEY : np + 1u);
+                A.read_slot[r0] = (u32)s_j;
             }
         }
     }
     __syncthreads();
-    for (u64 p = tid; p < cap2; p += TPB) {
-        const u32 k = __hip_atomic_load(&key[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (k) {
-            if (s_created && s_fits) {
-                const u32 m = __hip_atomic_load(&msk[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                A.arena[s_off + atomicAdd(&s_cnt, 1u)] = make_uint2(k - 1u, m);
-            }
-            key[p] = 0; msk[p] = 0;
-        }
+    for (u64 p = tid; p < cap2; p += TPB) {                 // leave the scratch zeroed for the next round
+        if (__hip_atomic_load(&key[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { key[p] = 0; msk[p] = 0; }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // table maintenance: grow (rehash), compact, merge
 // ---------------------------------------------------------------------------------------------
-__global__ void k_rehash(const Slot* old_t, u64 old_cap, Slot* new_t, u64 new_mask) {
+// new_of_old[i] = where slot i went: the reads' slot ids are re-mapped through it (no second lookup, no hashing)
+__global__ void k_rehash(const Slot* old_t, u64 old_cap, Slot* new_t, u64 new_mask, u32* new_of_old) {
     for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < old_cap; i += (u64)gridDim.x * blockDim.x) {
         const Slot s = old_t[i];
-        if (!s.hi) continue;
+        if (!s.n1) continue;
         u64 j = s.lo & new_mask;
-        for (;; j = (j + 1) & new_mask) {                // new table is larger and keys are distinct
+        for (;; j = (j + 1) & new_mask) {                // the new table is larger; two ECs with one hash take two slots
             if (atomicCAS(&new_t[j].lo, 0ull, s.lo) == 0ull) {
-                new_t[j].hi = s.hi; new_t[j].count = s.count; new_t[j].first_inv = s.first_inv;
-                new_t[j].off = s.off; new_t[j].n = s.n;
+                Slot t = s;
+                uint4* d = reinterpret_cast<uint4*>(new_t + j);
+                const uint4* v = reinterpret_cast<const uint4*>(&t);
+                d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+                new_t[j].off = s.off; new_t[j].n1 = s.n1;
+                new_of_old[i] = (u32)j;
                 break;
             }
         }
     }
 }
 
-__global__ void k_remap_read_slot(u32* read_slot, u64 n_reads, const Slot* old_t, const Slot* new_t, u64 new_mask) {
+__global__ void k_remap_read_slot(u32* read_slot, u64 n_reads, const u32* new_of_old) {
     for (u64 r = blockIdx.x * (u64)blockDim.x + threadIdx.x; r < n_reads; r += (u64)gridDim.x * blockDim.x) {
         const u32 os = read_slot[r];
-        if (os == 0xFFFFFFFFu) continue;
-        const u64 lo = old_t[os].lo, hi = old_t[os].hi;
-        u64 j = lo & new_mask;
-        while (!(new_t[j].lo == lo && new_t[j].hi == hi)) j = (j + 1) & new_mask;
-        read_slot[r] = (u32)j;
+        if (os != PENDING) read_slot[r] = new_of_old[os];
     }
 }
 
@@ -946,7 +1172,7 @@ __global__ __launch_bounds__(TPB_COMPACT) void k_compact(const Slot* table, u64 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const u64 i = b + (u64)k * TPB_COMPACT + tid;
-            const bool o = i < cap && table[i].hi != 0ull;
+            const bool o = i < cap && table[i].n1 != 0u;
             const u64 m = __ballot(o);
             off[k] = tot + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
             tot += (u32)__popcll(m);
@@ -968,7 +1194,7 @@ __global__ __launch_bounds__(TPB_COMPACT) void k_compact(const Slot* table, u64 
                 list[base + off[k]] = (u32)i;
                 if (list_fn) {
                     const u32 f = ~table[i].first_inv;
-                    list_fn[base + off[k]] = make_uint2(f, table[i].n);
+                    list_fn[base + off[k]] = make_uint2(f, table[i].n1 - 1u);
                     if (f < n_bits) atomicOr(&bitmap[f >> 5], 1u << (f & 31u));
                 }
             }
@@ -990,7 +1216,7 @@ __global__ __launch_bounds__(TPB) void k_parts_count(const Slot* table, const u3
     for (u64 eb = e0; eb < e1; eb += TPB) {
         const u64 e = eb + threadIdx.x;
         u32 q = MAX_PARTS, np = 0;
-        if (e < e1) { const Slot& s = table[list[e]]; q = part_of(s.lo, n_parts); np = s.n; }
+        if (e < e1) { const Slot& s = table[list[e]]; q = part_of(s.lo, n_parts); np = s.n1 - 1u; }
         for (u32 t = 0; t < n_parts; ++t) {          // one LDS atomic per wave and part (few parts = few, hot counters)
             const u64 m = __ballot(q == t);
             if (!m) continue;
@@ -1005,10 +1231,14 @@ __global__ __launch_bounds__(TPB) void k_parts_count(const Slot* table, const u3
     }
 }
 // cur[0..n_parts) / cur[n_parts..2 n_parts): next free entry / pair of every part (start = the part's offset);
-// pair_base[q] = first pair of part q: Slot::off is written relative to it.  Two walks over the workgroup's entries:
-// count per part, reserve (one global atomic per part), then place.
+// pair_base[q] = first pair of part q: Entry::off is written relative to it.  Two walks over the workgroup's entries:
+// count per part, reserve (one global atomic per part), then place.  Keys leave SORTED by locus (ranked like the CSR rows
+// of k_emit_*): two exported keys are then equal iff they are equal element by element, which is what k_merge tests first.
+// Keys of more than EXPORT_SMALL pairs are queued for k_parts_sort_big (one wave each).
+constexpr u32 EXPORT_SMALL = 16;
 __global__ __launch_bounds__(TPB) void k_parts_export(const Slot* table, const u32* list, u64 n, const uint2* arena, u32 n_parts,
-                                                      u64* cur, const u64* pair_base, Slot* out_e, uint2* out_p, u32 read_base) {
+                                                      u64* cur, const u64* pair_base, Entry* out_e, uint2* out_p, u32 read_base,
+                                                      u64* big, u32* n_big) {
     __shared__ u32 ce[MAX_PARTS], cp[MAX_PARTS];
     __shared__ u64 be[MAX_PARTS], bp[MAX_PARTS];
     const u32 lane = threadIdx.x & 63u;
@@ -1019,13 +1249,13 @@ __global__ __launch_bounds__(TPB) void k_parts_export(const Slot* table, const u
         for (u64 eb = e0; eb < e1; eb += TPB) {
             const u64 e = eb + threadIdx.x;
             Slot s{};
-            u32 q = MAX_PARTS, re = 0, rp = 0;
-            if (e < e1) { s = table[list[e]]; q = part_of(s.lo, n_parts); }
+            u32 q = MAX_PARTS, re = 0, rp = 0, sn = 0;
+            if (e < e1) { s = table[list[e]]; q = part_of(s.lo, n_parts); sn = s.n1 - 1u; }
             for (u32 t = 0; t < n_parts; ++t) {      // rank within the workgroup: wave prefix + one LDS atomic per wave and part
                 const bool mine = q == t;
                 const u64 m = __ballot(mine);
                 if (!m) continue;
-                const u32 v = mine ? s.n : 0u, incl = wave_incl_scan(v);
+                const u32 v = mine ? sn : 0u, incl = wave_incl_scan(v);
                 const u32 tot = (u32)__builtin_amdgcn_readlane((int)incl, 63);   // (read here, with every lane alive: inside the branch below
                 u32 b_e = 0, b_p = 0;                                            //  the compiler sinks the scan's last add under exec = lane 0)
                 if (lane == 0) { b_e = atomicAdd(&ce[t], (u32)__popcll(m)); b_p = atomicAdd(&cp[t], tot); }
@@ -1034,10 +1264,22 @@ __global__ __launch_bounds__(TPB) void k_parts_export(const Slot* table, const u
             }
             if (pass == 1 && e < e1) {
                 const u64 po = bp[q] + rp;
-                for (u32 t = 0; t < s.n; ++t) out_p[po + t] = arena[s.off + t];
-                s.first_inv = ~(~s.first_inv + read_base);
-                s.off = (u32)(po - pair_base[q]);
-                out_e[be[q] + re] = s;
+                if (sn <= EXPORT_SMALL) {
+                    for (u32 i = 0; i < sn; ++i) {
+                        const uint2 pi = key_pair(s, arena, i);
+                        u32 r = 0;
+                        for (u32 k = 0; k < sn; ++k) r += key_pair(s, arena, k).x < pi.x;   // loci within a key are distinct
+                        out_p[po + r] = pi;
+                    }
+                } else {
+                    const u32 bi = atomicAdd(n_big, 1u);
+                    big[2 * (u64)bi] = po; big[2 * (u64)bi + 1] = ((u64)list[e] << 32) | sn;
+                }
+                Entry en;
+                en.lo = s.lo; en.reserved = 0; en.count = s.count;
+                en.first_inv = ~(~s.first_inv + read_base);
+                en.off = (u32)(po - pair_base[q]); en.n = sn;
+                out_e[be[q] + re] = en;
             }
         }
         __syncthreads();
@@ -1048,17 +1290,57 @@ __global__ __launch_bounds__(TPB) void k_parts_export(const Slot* table, const u
         __syncthreads();
     }
 }
-// adopt: entries known to be distinct ECs go to consecutive slots of an empty table, keys to the arena, no hashing
-__global__ void k_adopt(const Slot* ent, u64 n, Slot* table, u64 slot_base, u32 arena_base) {
+// long keys of an export: one wave per key, rank = number of smaller loci
+__global__ __launch_bounds__(TPB) void k_parts_sort_big(const Slot* table, const uint2* arena, const u64* big, u32 n_big, uint2* out_p) {
+    const u32 b = (blockIdx.x * TPB + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    if (b >= n_big) return;
+    const u64 po = big[2 * (u64)b];
+    const u32 n = (u32)big[2 * (u64)b + 1];
+    const Slot& s = table[big[2 * (u64)b + 1] >> 32];
+    for (u32 i = lane; i < n; i += 64) {
+        const uint2 pi = key_pair(s, arena, i);
+        u32 r = 0;
+        for (u32 k = 0; k < n; ++k) r += key_pair(s, arena, k).x < pi.x;
+        out_p[po + r] = pi;
+    }
+}
+// adopt: entries known to be distinct ECs go to consecutive slots of an empty table, no hashing.  The pair list was copied to
+// the arena at arena_base as it is: the slot takes its first INL pairs, the rest stay where they are.
+__global__ void k_adopt(const Entry* ent, u64 n, const uint2* pairs, Slot* table, u64 slot_base, u32 arena_base) {
     const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (e >= n) return;
-    Slot s = ent[e];
-    s.off += arena_base;
+    const Entry en = ent[e];
+    Slot s{};
+    s.lo = en.lo; s.n1 = en.n + 1u; s.off = arena_base + en.off + INL; s.count = en.count; s.first_inv = en.first_inv;
+    for (u32 i = 0; i < INL && i < en.n; ++i) s.pair[i] = pairs[(u64)en.off + i];
     table[slot_base + e] = s;
 }
 
+// The ordered merge of bam_utils.py:680-724, one thread per incoming EC: find its key in the table (exact compare) or
+// insert it; counts are added, first appearances minimised.
+struct ListCmp {                                   // incoming key = a sorted pair list; stored key = slot + arena
+    const uint2* inc; u32 n; uint2* arena; bool fresh;
+    __device__ __forceinline__ uint2 stored(const SlotView& v, u32 i) const {
+        if (i < INL) return v.p[i];
+        u64* src = reinterpret_cast<u64*>(arena + (u64)v.off + (i - INL));
+        return unpack2(fresh ? fresh64(src) : __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    __device__ __forceinline__ bool operator()(const SlotView& v) const {
+        if (v.n != n) return false;
+        bool same = true;                          // both sorted (keys that came from an export): element by element
+        for (u32 i = 0; i < n && same; ++i) { const uint2 a = stored(v, i), b = inc[i]; same = a.x == b.x && a.y == b.y; }
+        if (same) return true;
+        for (u32 i = 0; i < n; ++i) {              // the stored key may be one k_stream wrote, in no order: compare as sets
+            const uint2 a = stored(v, i);
+            bool found = false;
+            for (u32 k = 0; k < n && !found; ++k) found = inc[k].x == a.x && inc[k].y == a.y;
+            if (!found) return false;
+        }
+        return true;
+    }
+};
 constexpr u32 MERGE_PER_BLOCK = 16 * TPB;     // entries per workgroup (one EC-count atomic per workgroup, not per wave: ~18 ns each on one address)
-__global__ __launch_bounds__(TPB) void k_merge(const Slot* ent, u64 n, const uint2* pairs, u64 n_pairs, Slot* table, u64 cap_mask,
+__global__ __launch_bounds__(TPB) void k_merge(const Entry* ent, u64 n, const uint2* pairs, u64 n_pairs, Slot* table, u64 cap_mask,
                                                uint2* arena, u64 arena_cap, Counters* ctr) {
     __shared__ u32 s_new;
     if (threadIdx.x == 0) s_new = 0;
@@ -1069,34 +1351,61 @@ __global__ __launch_bounds__(TPB) void k_merge(const Slot* ent, u64 n, const uin
     for (u64 eb = e0; eb < e1; eb += TPB) {
         const u64 e = eb + threadIdx.x;
         const bool on = e < e1;
-        Slot s{};
+        Entry s{};
         if (on) s = ent[e];
-        const bool ok = on && (u64)s.off + s.n <= n_pairs;
+        const bool ok = on && (u64)s.off + s.n <= n_pairs && s.lo != 0ull;
         if (on && !ok) atomicOr(&ctr->err, ERR_CONTRACT);
+        ListCmp cmp{pairs + s.off, s.n, arena, false};
+        u64 j = s.lo & cap_mask;
+        u32 probes = 0;
+        int st = ST_NONE;
+        if (ok) st = table_lookup(table, cap_mask, s.lo, j, probes, cmp);
         bool created = false;
-        u64 j = ~0ull;
-        if (ok) {
-            j = table_find_or_insert(table, cap_mask, s.lo, s.hi, &created);
-            if (j == ~0ull) atomicAdd(&ctr->n_queue, 1ull);        // host sizes the table so this cannot happen
-            else {
-                atomicAdd(&table[j].count, s.count);                 // one pair of atomics per merged EC, not per read
-                atomicMax(&table[j].first_inv, s.first_inv);
+        for (u32 round = 0;; ++round) {            // publish, then settle: as in k_stream (the creator a lane waits for may be its neighbour)
+            const u64 cm = __ballot(st == ST_CREATED);
+            if (cm) {
+                const bool cr = st == ST_CREATED;
+                const u32 want = cr && s.n > INL ? s.n - INL : 0u;
+                u64 at = 0;
+                if (__ballot(want != 0u)) {                                 // key arena: one reservation per wave, not per created EC
+                    const u32 incl = wave_incl_scan(want);
+                    const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+                    if (lane == 0) at = arena_alloc(ctr, arena_cap, total, blockIdx.x * (TPB / 64) + (threadIdx.x >> 6));
+                    at = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(at >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)at);
+                    if (at == ~0ull) { if (lane == 0) atomicOr(&ctr->err, ERR_ARENA); }
+                    else at += incl - want;
+                }
+                my_new += (u32)__popcll(cm);
+                if (cr) {
+                    const bool dead = at == ~0ull;
+                    if (!dead) {
+                        for (u32 t = 0; t < s.n; ++t) {
+                            uint2* dst = t < INL ? &table[j].pair[t] : arena + (at + (t - INL));
+                            store_wt64(reinterpret_cast<u64*>(dst), pack2(pairs[(u64)s.off + t]));
+                        }
+                        store_wt32(&table[j].off, (u32)at);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    store_wt32(&table[j].n1, dead ? DEAD_KEY : s.n + 1u);
+                    st = ST_HIT; created = true;
+                }
+            }
+            if (!__ballot(st == ST_PENDING)) break;
+            if (round >= 64u) { if (st == ST_PENDING) { atomicOr(&ctr->err, ERR_INTERNAL); st = ST_NONE; } break; }
+            if (st == ST_PENDING) {
+                ListCmp fc = cmp;
+                fc.fresh = true;
+                const int r = table_settle(table + j, fc);
+                if (r == ST_HIT) st = ST_HIT;
+                else if (r == ST_STUCK) { atomicOr(&ctr->err, ERR_INTERNAL); st = ST_NONE; }
+                else { j = (j + 1) & cap_mask; ++probes; st = table_lookup(table, cap_mask, s.lo, j, probes, cmp); }
             }
         }
-        // key arena: one reservation per wave, not per created EC
-        const u64 cm = __ballot(created);
-        if (!cm) continue;
-        const u32 want = created ? s.n : 0u, incl = wave_incl_scan(want);
-        const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
-        my_new += (u32)__popcll(cm);
-        u64 at = 0;
-        if (lane == 0) at = arena_alloc(ctr, arena_cap, total, blockIdx.x * (TPB / 64) + (threadIdx.x >> 6));
-        at = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(at >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)at);
-        if (at == ~0ull) { if (lane == 0) atomicOr(&ctr->err, ERR_ARENA); continue; }
-        if (created) {
-            const u64 off = at + (incl - want);
-            for (u32 t = 0; t < s.n; ++t) arena[off + t] = pairs[s.off + t];
-            table[j].off = (u32)off; table[j].n = s.n;
+        (void)created;
+        if (st == ST_FULL) atomicAdd(&ctr->n_queue, 1ull);             // host sizes the table so this cannot happen
+        else if (st == ST_HIT) {
+            atomicAdd(&table[j].count, s.count);                      // one pair of atomics per merged EC, not per read
+            atomicMax(&table[j].first_inv, s.first_inv);
         }
     }
     if (lane == 0 && my_new) atomicAdd(&s_new, my_new);
@@ -1136,13 +1445,13 @@ __global__ __launch_bounds__(TPB) void k_scan_sums(const u32* in, u64 n, u32* su
     u32 tot; block_excl_scan(s, &tot);
     if (threadIdx.x == 0) sums[blockIdx.x] = tot;
 }
-__global__ __launch_bounds__(TPB) void k_scan_top(u32* sums, u64 nb, u32* grand) {   // one block
-    u32 carry = 0;
+__global__ __launch_bounds__(TPB) void k_scan_top(u32* sums, u64 nb, u64* grand) {   // one block; the grand total in 64 bits
+    u64 carry = 0;
     for (u64 b0 = 0; b0 < nb; b0 += TPB) {
         const u64 i = b0 + threadIdx.x;
         const u32 v = i < nb ? sums[i] : 0u;
         u32 tot; const u32 ex = block_excl_scan(v, &tot);
-        if (i < nb) sums[i] = carry + ex;
+        if (i < nb) sums[i] = (u32)carry + ex;
         carry += tot;
     }
     if (threadIdx.x == 0) *grand = carry;
@@ -1180,41 +1489,43 @@ __global__ __launch_bounds__(TPB) void k_emit_small(const Slot* table, const u32
     const u64 e = (u64)blockIdx.x * TPB + threadIdx.x;
     if (e >= n) return;
     const Slot s = table[order[e]];
+    const u32 sn = s.n1 - 1u;
     counts[e] = (int)s.count;
-    if (s.n > EMIT_SMALL) { big[atomicAdd(n_big, 1u)] = (u32)e; return; }
-    const uint2* src = arena + s.off;
+    if (sn > EMIT_SMALL) { big[atomicAdd(n_big, 1u)] = (u32)e; return; }
     const u32 dst = indptr[e];
     bool bad = false;
-    for (u32 i = 0; i < s.n; ++i) {
-        const uint2 pi = src[i];
+    for (u32 i = 0; i < sn; ++i) {
+        const uint2 pi = key_pair(s, arena, i);
         u32 r = 0;
-        for (u32 j = 0; j < s.n; ++j) r += src[j].x < pi.x;   // loci within a key are distinct
+        for (u32 j = 0; j < sn; ++j) r += key_pair(s, arena, j).x < pi.x;   // loci within a key are distinct
         indices[dst + r] = (int)pi.x;
         data[dst + r] = (int)pi.y;
         bad |= pi.x >= n_loci || (pi.y >> n_haps) != 0u;
     }
     if (bad) atomicOr(&ctr->err, ERR_RANGE);
 }
-__global__ __launch_bounds__(TPB) void k_emit_big(const Slot* table, const u32* order, const u32* big, u32 n_big,
+__global__ __launch_bounds__(TPB) void k_emit_big(const Slot* table, const u32* order, const u32* big, const u32* n_big,
                                                    const uint2* arena, const u32* indptr, int* indices, int* data,
                                                    u32 n_loci, u32 n_haps, Counters* ctr) {
-    const u32 b = (blockIdx.x * TPB + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
-    if (b >= n_big) return;
-    const u32 e = big[b];
-    const Slot s = table[order[e]];
-    const uint2* src = arena + s.off;
-    const u32 dst = indptr[e];
+    const u32 lane = threadIdx.x & 63u, nb = *n_big;
     bool bad = false;
-    for (u32 i = lane; i < s.n; i += 64) {
-        const uint2 pi = src[i];
-        u32 r = 0;
-        for (u32 j = 0; j < s.n; ++j) r += src[j].x < pi.x;
-        indices[dst + r] = (int)pi.x;
-        data[dst + r] = (int)pi.y;
-        bad |= pi.x >= n_loci || (pi.y >> n_haps) != 0u;
+    for (u32 b = (blockIdx.x * TPB + threadIdx.x) >> 6; b < nb; b += (gridDim.x * TPB) >> 6) {
+        const u32 e = big[b];
+        const Slot& s = table[order[e]];
+        const u32 sn = s.n1 - 1u;
+        const u32 dst = indptr[e];
+        for (u32 i = lane; i < sn; i += 64) {
+            const uint2 pi = key_pair(s, arena, i);
+            u32 r = 0;
+            for (u32 j = 0; j < sn; ++j) r += key_pair(s, arena, j).x < pi.x;
+            indices[dst + r] = (int)pi.x;
+            data[dst + r] = (int)pi.y;
+            bad |= pi.x >= n_loci || (pi.y >> n_haps) != 0u;
+        }
     }
     if (bad) atomicOr(&ctr->err, ERR_RANGE);
 }
+__global__ void k_set_last(u32* dst, const u64* v) { *dst = (u32)*v; }
 
 // multisample: key = EC rank << 32 | meta (cell, file) of every read
 __global__ void k_ms_keys(const u32* read_slot, const u32* rank_of_slot, const u32* meta, u64 n, u64* keys, u32* vals) {
@@ -1237,22 +1548,31 @@ __global__ void k_ms_split(const u64* okey, const u32* ostart, const u32* ocount
 }
 // multisample across GPUs: the keys of the final ECs in rank order; their ranks looked up in a shard's own table; the
 // shards' (EC, cell, file) triples combined on the root
-__global__ void k_export_keys(const Slot* table, const u32* order, u64 n, uint4* out) {
+__global__ void k_export_keys(const Slot* table, const u32* order, u64 n, u64* out) {
     const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const Slot& s = table[order[e]];
-    out[e] = make_uint4((u32)s.lo, (u32)(s.lo >> 32), (u32)s.hi, (u32)(s.hi >> 32));
+    if (e < n) out[e] = table[order[e]].lo;
 }
-__global__ void k_set_global_rank(const uint4* keys, u64 n, const Slot* table, u64 cap_mask, u32* grank) {
+// EC e of the merged result = (hash keys[e], CSR row e with ascending loci).  Find it in this shard's table, by its hash and
+// then by its key, pair for pair: grank[slot] = e.
+__global__ void k_set_global_rank(const u64* keys, const int* indptr, const int* indices, const int* data, u64 n,
+                                  const Slot* table, u64 cap_mask, const uint2* arena, u32* grank) {
     const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (e >= n) return;
-    const uint4 k = keys[e];
-    const u64 lo = ((u64)k.y << 32) | k.x, hi = ((u64)k.w << 32) | k.z;
+    const u64 lo = keys[e];
+    const u32 r0 = (u32)indptr[e], rn = (u32)indptr[e + 1] - r0;
     u64 j = lo & cap_mask;
     for (u64 probe = 0; probe <= cap_mask; ++probe, j = (j + 1) & cap_mask) {
-        const u64 clo = table[j].lo;
-        if (clo == 0ull) return;                                  // this shard never saw that EC
-        if (clo == lo && table[j].hi == hi) { grank[j] = (u32)e; return; }
+        const Slot& s = table[j];
+        if (s.lo == 0ull) return;                                 // this shard never saw that EC
+        if (s.lo != lo || s.n1 != rn + 1u) continue;
+        bool same = true;
+        for (u32 i = 0; i < rn && same; ++i) {
+            const uint2 pr = key_pair(s, arena, i);
+            u32 a = 0, b = rn;                                    // the row is sorted by locus
+            while (a < b) { const u32 m = (a + b) >> 1; if ((u32)indices[r0 + m] < pr.x) a = m + 1; else b = m; }
+            same = a < rn && (u32)indices[r0 + a] == pr.x && (u32)data[r0 + a] == pr.y;
+        }
+        if (same) { grank[j] = (u32)e; return; }
     }
 }
 __global__ void k_ms_out(const u64* okey, const u32* ofirst, const u32* ostart, u64 n, u32 read_base, u64* key, u32* count, u32* first) {
@@ -1364,12 +1684,14 @@ struct ecb_handle {
     u64* wave_arena = nullptr; u64 wave_arena_n = 0;   // see StreamArgs::wave_arena
     bool scatter_attr_set = false;
     u64 resident_blocks = 0, rounds = 32;     // k_stream's launch shape (queried once)
+    bool ctr_synced = false;          // hctr is what the device holds (no kernel that counts has been queued since the last read-back)
     bool adopted = false;             // the table holds adopted entries in consecutive slots (no hashing): finalize / export only
 
     Slot* table = nullptr; u64 cap = 0;
     uint2* arena = nullptr; u64 arena_cap = 0;
     Counters* ctr = nullptr;
     Counters hctr{};                  // last read-back
+    Counters* pin_ctr = nullptr;      // pinned staging for clear_counters
     u32* read_slot = nullptr; u64 read_slot_cap = 0;
     u32* meta = nullptr; u64 meta_cap = 0, meta_hi = 0;   // multisample: cell | file << 22 per read
     u64 n_triples = 0; u64* ms_okey = nullptr; u32 *ms_ofirst = nullptr, *ms_ostart = nullptr, *ms_ocount = nullptr;
@@ -1381,6 +1703,7 @@ struct ecb_handle {
     u64 n_reads = 0;
     u64 reads_hi = 0;                 // read_slot entries [0, reads_hi) may be set (n_reads, or more mid-batch)
     u64 extra_all = 0, extra_valid = 0, extra_reads = 0;   // counters merged in from other ranks
+    u64 n_mismatch = 0;               // ECB_F_VERIFY: reads the exactness pass found in a wrong EC, over all pushes
 
     // host-pointer staging
     u32 *st_rid = nullptr, *st_loc = nullptr, *st_hf = nullptr; int* st_pos = nullptr; u64 st_cap = 0;
@@ -1395,7 +1718,8 @@ struct ecb_handle {
     // device scratch reused across calls (grown on demand, freed at destroy)
     enum { P_RESUME, P_SUMS, P_HIST, P_OFFS, P_PAIRS, P_CNT, P_PARTS, P_STARTS, P_WORK, P_LIST, P_BITMAP, P_WPOP, P_WPREFIX, P_ROWLEN, P_ORDER,
            P_WCOUNTS, P_RANK, P_INDPTR, P_COUNTS, P_INDICES, P_DATA, P_MS_KEYS, P_MS_KEYS2, P_MS_VALS, P_MS_VALS2, P_MS_TMP,
-           P_MS_FLAG, P_MS_POS, P_MS_OKEY, P_MS_OFIRST, P_MS_OSTART, P_MS_X, P_MS_OCOUNT, P_MS_GRANK, P_MS_CIN, P_MS_FIN, P_LISTFN, P_N };
+           P_MS_FLAG, P_MS_POS, P_MS_OKEY, P_MS_OFIRST, P_MS_OSTART, P_MS_X, P_MS_OCOUNT, P_MS_GRANK, P_MS_CIN, P_MS_FIN, P_LISTFN,
+           P_REMAP, P_TOTALS, P_SLOW_LEN, P_SLOW_OFF, P_SLOW_NRE, P_SLOW_REQ, P_SLOW_REQ2, P_SLOW_KEY, P_SLOW_MASK, P_BIG, P_N };
     void* pool[P_N] = {}; u64 pool_bytes[P_N] = {};
 
     // profiling
@@ -1441,8 +1765,14 @@ int clear_counters(ecb_handle* h) {
     const u64 per = h->arena_cap / R;
     for (u32 r = 0; r < ARENA_REGIONS; ++r) c.arena_reg[r] = r < R ? r * per : h->arena_cap;
     h->hctr = c;
-    HIPCHK(h, hipMemcpyAsync(h->ctr, &h->hctr, sizeof(Counters), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->pin_ctr) {                               // pinned staging: queued behind the stream's work, no wait (rewritten only by the next reset,
+        *h->pin_ctr = c;                            //  which comes after the waits of a push and a finalize)
+        HIPCHK(h, hipMemcpyAsync(h->ctr, h->pin_ctr, sizeof(Counters), hipMemcpyHostToDevice, h->stream));
+    } else {
+        HIPCHK(h, hipMemcpyAsync(h->ctr, &h->hctr, sizeof(Counters), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    h->ctr_synced = true;
     return ECB_OK;
 }
 // pairs of the key arena handed out so far (an upper bound of the pairs in use: the tail of a wave's last chunk is idle)
@@ -1457,21 +1787,29 @@ u64 arena_used(const ecb_handle* h) {
 int sync_counters(ecb_handle* h) {
     HIPCHK(h, hipMemcpyAsync(&h->hctr, h->ctr, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->ctr_synced = true;
     if (h->hctr.err & ERR_CONTRACT) return fail(h, ECB_ERR_CONTRACT, "read_id run counter violates the tuple contract (see ecb.h)");
     if (h->hctr.err & ERR_RANGE) return fail(h, ECB_ERR_CONTRACT, "locus or haplotype index out of range in a valid record");
     if (h->hctr.err & ERR_ARENA) return fail(h, ECB_ERR_TABLE_FULL, "EC key arena exhausted (%llu pairs): raise arena_capacity", (unsigned long long)h->arena_cap);
     if (h->hctr.err & ERR_QUEUE) return fail(h, ECB_ERR_TABLE_FULL, "deferred-read queue exhausted");
+    if (h->hctr.err & ERR_INTERNAL) return fail(h, ECB_ERR_HIP, "internal: an EC-table slot was claimed but its key never published");
     return ECB_OK;
 }
 
 int grow_table(ecb_handle* h, u64 new_cap) {
     Slot* nt = nullptr;
+    u32* remap = nullptr;
+    if (new_cap > (1ull << 32)) return fail(h, ECB_ERR_LIMIT, "EC table beyond 2^32 slots");
+    POOL(h, P_REMAP, remap, h->cap);
     HIPCHK(h, hipMalloc(&nt, new_cap * sizeof(Slot)));
-    HIPCHK(h, hipMemsetAsync(nt, 0, new_cap * sizeof(Slot), h->stream));
-    k_rehash<<<2048, TPB, 0, h->stream>>>(h->table, h->cap, nt, new_cap - 1);
-    if (h->reads_hi)
-        k_remap_read_slot<<<2048, TPB, 0, h->stream>>>(h->read_slot, h->reads_hi, h->table, nt, new_cap - 1);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    hipError_t e = hipMemsetAsync(nt, 0, new_cap * sizeof(Slot), h->stream);
+    if (e == hipSuccess) {
+        k_rehash<<<2048, TPB, 0, h->stream>>>(h->table, h->cap, nt, new_cap - 1, remap);
+        if (h->reads_hi)
+            k_remap_read_slot<<<2048, TPB, 0, h->stream>>>(h->read_slot, h->reads_hi, remap);
+        e = hipStreamSynchronize(h->stream);
+    }
+    if (e != hipSuccess) { hipFree(nt); return fail(h, ECB_ERR_HIP, "grow_table: %s", hipGetErrorString(e)); }
     HIPCHK(h, hipFree(h->table));
     h->table = nt; h->cap = new_cap;
     return ECB_OK;
@@ -1493,17 +1831,16 @@ int ensure_read_slot(ecb_handle* h, u64 need) {
     return ECB_OK;
 }
 
-// deferred reads: measure, scratch, k_slow; grow the table and repeat while reads bounce
-int run_slow(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf, u64 n, u64* d_q, u64 nq) {
-    u64* d_requeue = nullptr;
+// deferred reads: measure, scratch, k_slow; grow the table and repeat while reads bounce.  All scratch lives in the
+// handle's pool (a stream of long reads pays no hipMalloc per round, and no early return can leak it).
+// verify: the exactness pass over the same reads (compare with the EC each was given; no insert, one round).
+int run_slow(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf, u64 n, u64* d_q, u64 nq, bool verify = false) {
     int rc = ECB_OK;
+    int flip = 0;
     while (nq) {
-        u64 *d_len = nullptr, *d_off = nullptr, *d_nre = nullptr;
-        HIPCHK(h, hipMalloc(&d_len, nq * sizeof(u64)));
-        HIPCHK(h, hipMalloc(&d_off, nq * sizeof(u64)));
-        HIPCHK(h, hipMalloc(&d_nre, sizeof(u64)));
-        u64* nre_buf = nullptr;
-        HIPCHK(h, hipMalloc(&nre_buf, nq * sizeof(u64)));
+        u64 *d_len = nullptr, *d_off = nullptr, *d_nre = nullptr, *nre_buf = nullptr;
+        POOL(h, P_SLOW_LEN, d_len, nq); POOL(h, P_SLOW_OFF, d_off, nq); POOL(h, P_SLOW_NRE, d_nre, 1);
+        if (flip) POOL(h, P_SLOW_REQ2, nre_buf, nq); else POOL(h, P_SLOW_REQ, nre_buf, nq);      // (d_q may be the other one)
         HIPCHK(h, hipMemsetAsync(d_nre, 0, sizeof(u64), h->stream));
         k_slow_len<<<(unsigned)nq, TPB, 0, h->stream>>>(d_rid, n, d_q, nq, d_len);
         std::vector<u64> len(nq), off(nq);
@@ -1512,44 +1849,31 @@ int run_slow(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf,
         u64 tot = 0;
         for (u64 i = 0; i < nq; ++i) { off[i] = tot; tot += 2 * len[i]; }
         u32 *sk = nullptr, *sm = nullptr;
-        HIPCHK(h, hipMalloc(&sk, std::max<u64>(tot, 1) * sizeof(u32)));
-        HIPCHK(h, hipMalloc(&sm, std::max<u64>(tot, 1) * sizeof(u32)));
-        HIPCHK(h, hipMemsetAsync(sk, 0, tot * sizeof(u32), h->stream));
-        HIPCHK(h, hipMemsetAsync(sm, 0, tot * sizeof(u32), h->stream));
+        const u64 had_k = h->pool_bytes[ecb_handle::P_SLOW_KEY], had_m = h->pool_bytes[ecb_handle::P_SLOW_MASK];
+        POOL(h, P_SLOW_KEY, sk, tot); POOL(h, P_SLOW_MASK, sm, tot);
+        // k_slow leaves its scratch zeroed: only a fresh (re)allocation needs clearing
+        if (h->pool_bytes[ecb_handle::P_SLOW_KEY] != had_k) HIPCHK(h, hipMemsetAsync(sk, 0, h->pool_bytes[ecb_handle::P_SLOW_KEY], h->stream));
+        if (h->pool_bytes[ecb_handle::P_SLOW_MASK] != had_m) HIPCHK(h, hipMemsetAsync(sm, 0, h->pool_bytes[ecb_handle::P_SLOW_MASK], h->stream));
         HIPCHK(h, hipMemcpyAsync(d_off, off.data(), nq * sizeof(u64), hipMemcpyHostToDevice, h->stream));
         SlowArgs a{d_rid, d_loc, d_hf, d_q, d_len, d_off, sk, sm, h->cfg.n_loci, h->cfg.n_haplotypes,
-                   h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr, h->read_slot, nre_buf, d_nre};
+                   h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr, h->read_slot, h->reads_hi, nre_buf, d_nre, verify ? 1u : 0u};
         k_slow<<<(unsigned)nq, TPB, 0, h->stream>>>(a);
         u64 nre = 0;
         HIPCHK(h, hipMemcpyAsync(&nre, d_nre, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
-        rc = sync_counters(h);
-        hipFree(d_len); hipFree(d_off); hipFree(d_nre); hipFree(sk); hipFree(sm);
-        if (d_requeue) hipFree(d_requeue);
-        d_requeue = nre_buf; d_q = nre_buf; nq = nre;
-        if (rc != ECB_OK) break;
+        rc = sync_counters(h);                          // (waits: `off` lives on this stack frame)
+        if (rc != ECB_OK || verify) break;
+        d_q = nre_buf; nq = nre; flip ^= 1;
         if (nq) { rc = grow_table(h, h->cap * 4); if (rc != ECB_OK) break; }
     }
-    if (d_requeue) hipFree(d_requeue);
     return rc;
 }
 
-int excl_scan(ecb_handle* h, const u32* in, u64 n, u32* out, u32* total);
+int excl_scan(ecb_handle* h, const u32* in, u64 n, u32* out, u64* total);
 
-// one batch of whole reads, device-resident
-int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf, const int* d_pos, u64 n) {
-    if (n == 0) return ECB_OK;
-    u32 last_rid = 0;
-    HIPCHK(h, hipMemcpyAsync(&last_rid, d_rid + (n - 1), sizeof(u32), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    const u64 reads_after = (u64)(u32)(last_rid + 1u);
-    if (reads_after < h->n_reads) return fail(h, ECB_ERR_CONTRACT, "read_id went backwards across pushes");
-    int rc = ensure_read_slot(h, reads_after);
-    if (rc != ECB_OK) return rc;
-    h->reads_hi = reads_after;
-    // keep the table at most half full before a batch (it grows again, via k_slow, if a batch overfills it)
-    while (h->n_ecs() * 2 > h->cap) { rc = grow_table(h, h->cap * 4); if (rc != ECB_OK) return rc; }
-    // The stream is cut into ECB_ROUNDS x as many slices as waves are resident at once; the launch holds the resident
-    // waves only, which claim slice after slice (`waves` below counts slices).
+// Launch shape of k_stream over n records: the stream is cut into ECB_ROUNDS x as many slices as waves are resident at
+// once; the launch holds the resident waves only, which claim slice after slice.
+struct StreamPlan { u64 slices, chunk, blocks, pwaves; };
+int plan_stream(ecb_handle* h, u64 n, StreamPlan* P) {
     if (!h->resident_blocks) {                         // (asked once per handle: two runtime queries per batch add up on a streamed BAM)
         int cus = 256, bpc = 4;
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
@@ -1564,15 +1888,73 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     u64 chunk = (n + waves - 1) / waves;
     chunk = (chunk + 3) & ~(u64)3;
     waves = (n + chunk - 1) / chunk;
-    const u64 blocks = std::min<u64>((waves + NWAVE - 1) / NWAVE, resident_blocks);
-    const u64 pwaves = blocks * NWAVE;           // waves of the launch
+    P->slices = waves; P->chunk = chunk;
+    P->blocks = std::min<u64>((waves + NWAVE - 1) / NWAVE, resident_blocks);
+    P->pwaves = P->blocks * NWAVE;               // waves of the launch
     // a parked launch defers at most the reads of the tiles in flight
     const u64 need_q = waves * (u64)(WMAXR + 1) + 16;
     if (h->queue_cap < need_q) {
         if (h->queue) hipFree(h->queue);
+        h->queue = nullptr; h->queue_cap = 0;
+        HIPCHK(h, hipMalloc(&h->queue, need_q * sizeof(u64)));
         h->queue_cap = need_q;
-        HIPCHK(h, hipMalloc(&h->queue, h->queue_cap * sizeof(u64)));
     }
+    return ECB_OK;
+}
+
+// The exactness pass over one device-resident batch (whole reads, read ids continuing from prev_rid): every read's target
+// set is derived again from its records and compared, pair by pair, with the key of the EC the read was given.
+// Reads longer than a tile go through k_slow's compare.  *n_mismatch = reads in a wrong EC (0 = exact); *n_long = how many
+// took the long path.
+int verify_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf, u64 n, u32 prev_rid, u64* n_mismatch, u64* n_long) {
+    StreamPlan P;
+    int rc = plan_stream(h, n, &P);
+    if (rc != ECB_OK) return rc;
+    u64* d_resume = nullptr; u32* d_wcounts = nullptr;
+    POOL(h, P_RESUME, d_resume, 2 * P.slices); POOL(h, P_WCOUNTS, d_wcounts, 3 * P.pwaves);
+    k_init_resume<<<nblk(P.slices, TPB), TPB, 0, h->stream>>>(d_resume, P.slices, P.chunk);
+    HIPCHK(h, hipMemsetAsync(d_wcounts, 0, 3 * P.pwaves * sizeof(u32), h->stream));
+    HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));
+    HIPCHK(h, hipMemsetAsync(&h->ctr->full, 0, sizeof(u32), h->stream));
+    HIPCHK(h, hipMemsetAsync(&h->ctr->next_slice, 0, sizeof(u64), h->stream));
+    HIPCHK(h, hipMemsetAsync(&h->ctr->n_mismatch, 0, sizeof(u64), h->stream));
+    StreamArgs a{d_rid, d_loc, d_hf, n, P.chunk, prev_rid, h->cfg.n_loci, h->cfg.n_haplotypes,
+                 h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr, h->read_slot, h->reads_hi, h->queue, h->queue_cap, d_resume, d_wcounts, nullptr,
+                 0u, nullptr};
+    k_stream<true><<<(unsigned)P.blocks, TPB, 0, h->stream>>>(a);
+    k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, P.pwaves, h->ctr, 1u);
+    HIPCHK(h, hipGetLastError());
+    rc = sync_counters(h);
+    if (rc != ECB_OK) return rc;
+    const u64 nq = std::min<u64>(h->hctr.n_queue, h->queue_cap);
+    if (nq) {
+        rc = run_slow(h, d_rid, d_loc, d_hf, n, h->queue, nq, true);
+        if (rc != ECB_OK) return rc;
+    }
+    *n_mismatch = h->hctr.n_mismatch;
+    *n_long = nq;
+    HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));
+    h->hctr.n_queue = 0;
+    return ECB_OK;
+}
+
+// one batch of whole reads, device-resident
+int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf, const int* d_pos, u64 n) {
+    if (n == 0) return ECB_OK;
+    u32 last_rid = 0;
+    HIPCHK(h, hipMemcpyAsync(&last_rid, d_rid + (n - 1), sizeof(u32), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const u64 reads_after = (u64)(u32)(last_rid + 1u);
+    if (reads_after < h->n_reads) return fail(h, ECB_ERR_CONTRACT, "read_id went backwards across pushes");
+    int rc = ensure_read_slot(h, reads_after);
+    if (rc != ECB_OK) return rc;
+    h->reads_hi = reads_after;
+    // keep the table at most half full before a batch (it grows again, via k_slow, if a batch overfills it)
+    while (h->n_ecs() * 2 > h->cap) { rc = grow_table(h, h->cap * 4); if (rc != ECB_OK) return rc; }
+    StreamPlan P;
+    rc = plan_stream(h, n, &P);
+    if (rc != ECB_OK) return rc;
+    const u64 waves = P.slices, chunk = P.chunk, blocks = P.blocks, pwaves = P.pwaves;
     u64* d_resume = nullptr;
     POOL(h, P_RESUME, d_resume, 2 * waves);
     k_init_resume<<<nblk(waves, TPB), TPB, 0, h->stream>>>(d_resume, waves, chunk);
@@ -1593,12 +1975,13 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
         h->wave_arena = wa; h->wave_arena_n = pwaves;
     }
     StreamArgs a{d_rid, d_loc, d_hf, n, chunk, h->prev_rid, h->cfg.n_loci, h->cfg.n_haplotypes,
-                 h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr, h->read_slot, h->queue, h->queue_cap, d_resume, d_wcounts, h->wave_arena,
+                 h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr, h->read_slot, h->reads_hi, h->queue, h->queue_cap, d_resume, d_wcounts, h->wave_arena,
                  getenv("ECB_ABLATE") ? (u32)atoi(getenv("ECB_ABLATE")) : 0u, nullptr};
 #ifdef ECB_TIMING
     HIPCHK(h, hipMalloc(&a.timing, 8 * sizeof(u64)));
     HIPCHK(h, hipMemset(a.timing, 0, 8 * sizeof(u64)));
 #endif
+    h->ctr_synced = false;
     for (;;) {
         HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));   // per launch
         HIPCHK(h, hipMemsetAsync(&h->ctr->full, 0, sizeof(u32), h->stream));
@@ -1608,7 +1991,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
         if (h->prof) hipEventRecord(h->ev0, h->stream);
         k_stream<false><<<(unsigned)blocks, TPB, 0, h->stream>>>(a);
         if (h->prof) hipEventRecord(h->ev1, h->stream);
-        k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, pwaves, h->ctr);
+        k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, pwaves, h->ctr, 0u);
         HIPCHK(h, hipGetLastError());
         rc = sync_counters(h);
         if (h->prof) {
@@ -1638,6 +2021,13 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
 #endif
     if (rc != ECB_OK) return rc;
     if (h->prof) h->prof_records += n;
+    if (h->cfg.flags & ECB_F_VERIFY) {                  // belt and braces: the grouping is exact by construction (Slot), this re-derives it
+        u64 bad = 0, nl = 0;
+        rc = verify_batch(h, d_rid, d_loc, d_hf, n, h->prev_rid, &bad, &nl);
+        if (rc != ECB_OK) return rc;
+        h->n_mismatch += bad;
+        if (bad) return fail(h, ECB_ERR_VERIFY, "exactness pass: %llu read(s) of this batch sit in an EC whose key is not their target set", (unsigned long long)bad);
+    }
     h->prev_rid = last_rid;
     h->n_reads = reads_after;
     return ECB_OK;
@@ -1684,19 +2074,30 @@ void free_results(ecb_handle* h) {   // result buffers live in the pool: nothing
     h->indices = h->data = h->counts = nullptr;
 }
 
-int excl_scan(ecb_handle* h, const u32* in, u64 n, u32* out, u32* total) {
+// exclusive scan of u32 values, queued on the handle's stream; the sum (64 bits) is left in *d_total on the device
+// (a sum of 2^32 or more: the caller's limit check, `out` wrapped)
+int excl_scan_dev(ecb_handle* h, const u32* in, u64 n, u32* out, u64* d_total) {
     const u64 nb = std::max<u64>(1, (n + SCAN_BLOCK - 1) / SCAN_BLOCK);
     u32* sums = nullptr;
-    POOL(h, P_SUMS, sums, nb + 1);
+    POOL(h, P_SUMS, sums, nb);
     k_scan_sums<<<(unsigned)nb, TPB, 0, h->stream>>>(in, n, sums);
-    k_scan_top<<<1, TPB, 0, h->stream>>>(sums, nb, sums + nb);
+    k_scan_top<<<1, TPB, 0, h->stream>>>(sums, nb, d_total);
     k_scan_apply<<<(unsigned)nb, TPB, 0, h->stream>>>(in, n, sums, out);
-    HIPCHK(h, hipMemcpyAsync(total, sums + nb, sizeof(u32), hipMemcpyDeviceToHost, h->stream));
+    return ECB_OK;
+}
+// ... and with the sum brought to the host (one wait)
+int excl_scan(ecb_handle* h, const u32* in, u64 n, u32* out, u64* total) {
+    u64* d_tot = nullptr;
+    POOL(h, P_TOTALS, d_tot, 8);
+    int rc = excl_scan_dev(h, in, n, out, d_tot + 7);
+    if (rc != ECB_OK) return rc;
+    HIPCHK(h, hipMemcpyAsync(total, d_tot + 7, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return ECB_OK;
 }
 
-// reads per EC / first appearance, from read_slot[0, n_reads) (once, when the stream is closed)
+// reads per EC / first appearance, from read_slot[0, n_reads) (once, when the stream is closed).  Only queues kernels:
+// the totals and the work list of k_count_bins stay on the device.
 int ensure_counts(ecb_handle* h) {
     if (h->counted) return ECB_OK;
     const u64 R = h->n_reads;
@@ -1706,56 +2107,52 @@ int ensure_counts(ecb_handle* h) {
         const u32 G = (u32)std::min<u64>(PART_G, (R + 4095) / 4096);
         u32 *hist = nullptr, *offs = nullptr;
         uint2* pairs = nullptr;
+        u64* d_tot = nullptr;
         POOL(h, P_HIST, hist, (u64)nb * G); POOL(h, P_OFFS, offs, (u64)nb * G);
         POOL(h, P_PAIRS, pairs, R);
+        POOL(h, P_TOTALS, d_tot, 8);
         k_part_hist<<<G, TPB_PART, nb * 4, h->stream>>>(h->read_slot, R, nb, hist);
-        u32 total = 0;
-        int rc = excl_scan(h, hist, (u64)nb * G, offs, &total);
-        if (rc == ECB_OK) {
-            if (nb <= STAGE_MAX_BUCKETS) {
-                if (!h->scatter_attr_set) {             // (per handle = per device: more than 64 KB of dynamic LDS has to be asked for)
-                    HIPCHK(h, hipFuncSetAttribute((const void*)k_part_scatter_staged, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  3 * STAGE_MAX_BUCKETS * 4 + 8 + STAGE * 8));
-                    h->scatter_attr_set = true;
-                }
-                k_part_scatter_staged<<<G, TPB_PART, 3 * nb * 4 + 8 + STAGE * 8, h->stream>>>(h->read_slot, R, nb, offs, pairs);
-            } else                                     // (tables beyond 2^25 slots: the counters would crowd the stage out of LDS)
-                k_part_scatter<<<G, TPB_PART, nb * 4, h->stream>>>(h->read_slot, R, nb, offs, pairs);
-            // work list of k_count_bins: ranges far above the average are cut into pieces (see CountWork)
-            u32* d_starts = nullptr;
-            POOL(h, P_STARTS, d_starts, (u64)nb + 1);
-            k_bucket_starts<<<nblk((u64)nb + 1, TPB), TPB, 0, h->stream>>>(offs, G, nb, total, d_starts);
-            std::vector<u32> starts(nb + 1);
-            HIPCHK(h, hipMemcpyAsync(starts.data(), d_starts, ((u64)nb + 1) * sizeof(u32), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipStreamSynchronize(h->stream));
-            const u32 piece = std::max<u32>(32768u, 2u * (u32)((total + nb - 1) / nb));
-            std::vector<CountWork> work;
-            work.reserve(nb + total / piece + 1);
-            for (u32 b = 0; b < nb; ++b) {
-                const u32 s0 = starts[b], s1 = starts[b + 1];
-                if (s1 == s0) continue;
-                if (s1 - s0 <= piece + piece / 2) { work.push_back(CountWork{b, s0, s1, 0u}); continue; }
-                for (u32 a = s0; a < s1; a += piece) work.push_back(CountWork{b, a, std::min(a + piece, s1), 1u});
-            }
-            CountWork* d_work = nullptr;
-            POOL(h, P_WORK, d_work, work.size());
-            HIPCHK(h, hipMemcpyAsync(d_work, work.data(), work.size() * sizeof(CountWork), hipMemcpyHostToDevice, h->stream));
-            if (!work.empty()) k_count_bins<<<(unsigned)work.size(), TPB_COUNT, 0, h->stream>>>(pairs, d_work, h->table);
-            hipError_t e = hipStreamSynchronize(h->stream);               // (also: `work` lives on this stack frame)
-            if (e != hipSuccess) rc = fail(h, ECB_ERR_HIP, "k_count: %s", hipGetErrorString(e));
-        }
+        int rc = excl_scan_dev(h, hist, (u64)nb * G, offs, d_tot);
         if (rc != ECB_OK) return rc;
+        if (nb <= STAGE_MAX_BUCKETS) {
+            if (!h->scatter_attr_set) {             // (per handle = per device: more than 64 KB of dynamic LDS has to be asked for)
+                HIPCHK(h, hipFuncSetAttribute((const void*)k_part_scatter_staged, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              3 * STAGE_MAX_BUCKETS * 4 + 8 + STAGE * 8));
+                h->scatter_attr_set = true;
+            }
+            k_part_scatter_staged<<<G, TPB_PART, 3 * nb * 4 + 8 + STAGE * 8, h->stream>>>(h->read_slot, R, nb, offs, pairs);
+        } else                                     // (tables beyond 2^25 slots: the counters would crowd the stage out of LDS)
+            k_part_scatter<<<G, TPB_PART, nb * 4, h->stream>>>(h->read_slot, R, nb, offs, pairs);
+        // work list of k_count_bins: ranges far above the average are cut into pieces (see CountWork)
+        u32* d_starts = nullptr;
+        POOL(h, P_STARTS, d_starts, (u64)nb + 1);
+        k_bucket_starts<<<nblk((u64)nb + 1, TPB), TPB, 0, h->stream>>>(offs, G, nb, d_tot, d_starts);
+        const u32 piece = std::max<u32>(32768u, 2u * (u32)((R + nb - 1) / nb));
+        const u32 max_work = nb + (u32)(R / piece) + 1;
+        CountWork* d_work = nullptr;
+        POOL(h, P_WORK, d_work, (u64)max_work + 1);          // (+ 1: its length sits behind the list)
+        u32* d_nwork = reinterpret_cast<u32*>(d_work + max_work);
+        k_build_work<<<1, 1024, 0, h->stream>>>(d_starts, nb, piece, d_work, max_work, d_nwork);
+        k_count_bins<<<max_work, TPB_COUNT, 0, h->stream>>>(pairs, d_work, d_nwork, h->table);
+        HIPCHK(h, hipGetLastError());
     }
     h->counted = true;
     return ECB_OK;
 }
 
-int compact_table(ecb_handle* h, u32* bitmap = nullptr, u64 n_bits = 0, uint2* list_fn = nullptr) {
-    u64* d_n = nullptr;
-    POOL(h, P_CNT, d_n, 1);
+// occupied slots -> h->list (+ first-appearance bitmap and (first, key length) per entry for finalize); the number found
+// is left in *d_n on the device
+int compact_table_dev(ecb_handle* h, u64* d_n, u32* bitmap = nullptr, u64 n_bits = 0, uint2* list_fn = nullptr) {
     HIPCHK(h, hipMemsetAsync(d_n, 0, sizeof(u64), h->stream));
     POOL(h, P_LIST, h->list, h->n_ecs());
     k_compact<<<(unsigned)std::min<u64>(2048, (h->cap + 4 * TPB_COMPACT - 1) / (4 * TPB_COMPACT)), TPB_COMPACT, 0, h->stream>>>(h->table, h->cap, h->list, std::max<u64>(h->n_ecs(), 1), d_n, bitmap, n_bits, list_fn);
+    return ECB_OK;
+}
+int compact_table(ecb_handle* h) {
+    u64* d_n = nullptr;
+    POOL(h, P_CNT, d_n, 1);
+    int rc = compact_table_dev(h, d_n);
+    if (rc != ECB_OK) return rc;
     HIPCHK(h, hipMemcpyAsync(&h->n_list, d_n, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->n_list != h->n_ecs()) return fail(h, ECB_ERR_HIP, "internal: %llu occupied slots but %llu ECs created",
@@ -1781,7 +2178,7 @@ int ms_reduce(ecb_handle* h, const u32* ec_of_slot) {
     if (rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, R, 0, 64, h->stream) != hipSuccess)
         return fail(h, ECB_ERR_HIP, "rocprim::radix_sort_pairs");
     k_ms_heads<<<nblk(R, TPB), TPB, 0, h->stream>>>(keys2, R, flag);
-    u32 nt = 0;
+    u64 nt = 0;
     int rc = excl_scan(h, flag, R, pos, &nt);
     if (rc != ECB_OK) return rc;
     POOL(h, P_MS_OKEY, h->ms_okey, nt); POOL(h, P_MS_OFIRST, h->ms_ofirst, nt); POOL(h, P_MS_OSTART, h->ms_ostart, (u64)nt + 1);
@@ -1831,7 +2228,9 @@ int ecb_create(const ecb_config* cfg, ecb_handle** out) {
     if ((e = hipMalloc(&h->table, h->cap * sizeof(Slot))) != hipSuccess) return bail(ECB_ERR_HIP, "hipMalloc(table)", e);
     if ((e = hipMalloc(&h->arena, h->arena_cap * sizeof(uint2))) != hipSuccess) return bail(ECB_ERR_HIP, "hipMalloc(arena)", e);
     if ((e = hipMalloc(&h->ctr, sizeof(Counters))) != hipSuccess) return bail(ECB_ERR_HIP, "hipMalloc(counters)", e);
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->pin_ctr), sizeof(Counters), hipHostMallocDefault)) != hipSuccess) return bail(ECB_ERR_HIP, "hipHostMalloc", e);
     hipMemsetAsync(h->table, 0, h->cap * sizeof(Slot), h->stream);
+    hipMemsetAsync(h->arena, 0, h->arena_cap * sizeof(uint2), h->stream);     // stale arena bytes must never look like a key (see ecb_reset)
     clear_counters(h);
     if (cfg->flags & ECB_F_RANGES) {
         const u64 ns = (u64)cfg->n_loci * cfg->n_haplotypes;
@@ -1853,6 +2252,7 @@ void ecb_destroy(ecb_handle* h) {
     free_results(h);
     hipFree(h->table); hipFree(h->arena); hipFree(h->ctr); hipFree(h->read_slot); hipFree(h->meta);
     hipFree(h->rng_min); hipFree(h->rng_max); hipFree(h->queue); hipFree(h->wave_arena);
+    if (h->pin_ctr) hipHostFree(h->pin_ctr);
     for (int i = 0; i < ecb_handle::P_N; ++i) hipFree(h->pool[i]);
     hipFree(h->st_rid); hipFree(h->st_loc); hipFree(h->st_hf); hipFree(h->st_pos);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -1862,56 +2262,33 @@ void ecb_destroy(ecb_handle* h) {
 }
 
 int ecb_verify_device(ecb_handle* h, const void* d_read_id, const void* d_locus, const void* d_hapflag, size_t n,
-                      uint64_t* n_mismatch, uint64_t* n_skipped) {
-    if (!h || !n_mismatch || !n_skipped) return ECB_ERR_ARG;
+                      uint64_t* n_mismatch, uint64_t* n_long) {
+    if (!h || !n_mismatch || !n_long) return ECB_ERR_ARG;
     if (!n || !d_read_id || !d_locus || !d_hapflag) return fail(h, ECB_ERR_ARG, "null tuple stream");
     if (((uintptr_t)d_read_id | (uintptr_t)d_locus | (uintptr_t)d_hapflag) & 15) return fail(h, ECB_ERR_ARG, "device streams must be 16-byte aligned");
     HIPCHK(h, hipSetDevice(h->device));
-    int rc = sync_counters(h);
-    if (rc != ECB_OK) return rc;
-    const Counters before = h->hctr;
-    int cus = 256, bpc = 4;
-    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_stream<false>, TPB, 0);
-    u64 waves = std::min<u64>((u64)cus * std::max(bpc, 1) * NWAVE * 4, (n + 2 * WT - 1) / (2 * WT));
-    waves = std::max<u64>(waves, 1);
-    u64 chunk = ((n + waves - 1) / waves + 3) & ~(u64)3;
-    waves = (n + chunk - 1) / chunk;
-    const u64 blocks = (waves + NWAVE - 1) / NWAVE;
-    u64* d_resume = nullptr; u32* d_wcounts = nullptr;
-    POOL(h, P_RESUME, d_resume, 2 * waves); POOL(h, P_WCOUNTS, d_wcounts, 3 * blocks * NWAVE);
-    k_init_resume<<<nblk(waves, TPB), TPB, 0, h->stream>>>(d_resume, waves, chunk);
-    HIPCHK(h, hipMemsetAsync(d_wcounts, 0, 3 * blocks * NWAVE * sizeof(u32), h->stream));
-    HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));
-    const u64 need_q = waves * (u64)(WMAXR + 1) + 16;
-    if (h->queue_cap < need_q) {
-        if (h->queue) hipFree(h->queue);
-        h->queue_cap = need_q;
-        HIPCHK(h, hipMalloc(&h->queue, h->queue_cap * sizeof(u64)));
-    }
-    StreamArgs a{(const u32*)d_read_id, (const u32*)d_locus, (const u32*)d_hapflag, n, chunk, 0xFFFFFFFFu,
-                 h->cfg.n_loci, h->cfg.n_haplotypes, h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr,
-                 h->read_slot, h->queue, h->queue_cap, d_resume, d_wcounts, nullptr, 0u};
-    HIPCHK(h, hipMemsetAsync(&h->ctr->next_slice, 0, sizeof(u64), h->stream));
-    k_stream<true><<<(unsigned)blocks, TPB, 0, h->stream>>>(a);
-    k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, blocks * NWAVE, h->ctr);
-    rc = sync_counters(h);
-    if (rc != ECB_OK) return rc;
-    *n_mismatch = h->hctr.n_ecs - before.n_ecs;
-    *n_skipped = h->hctr.n_queue;
-    // the pass re-counted the records: put the stream's own counters back
-    Counters fix = h->hctr;
-    fix.all = before.all; fix.valid = before.valid; fix.n_ecs = before.n_ecs; fix.n_queue = 0;
-    h->hctr = fix;
-    HIPCHK(h, hipMemcpyAsync(h->ctr, &h->hctr, sizeof(Counters), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return ECB_OK;
+    u64 bad = 0, nl = 0;
+    const int rc = verify_batch(h, (const u32*)d_read_id, (const u32*)d_locus, (const u32*)d_hapflag, n, 0xFFFFFFFFu, &bad, &nl);
+    *n_mismatch = bad; *n_long = nl;
+    return rc;
 }
 
 int ecb_reset(ecb_handle* h) {
     if (!h) return ECB_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
     free_results(h);
+    // The used stretches of the key arena go back to zero: a key pair is only ever compared against bytes that are either
+    // zero (no haplotype mask: never equal to a pair) or final, whatever a cache still holds of them.
+    if (!h->ctr_synced) sync_counters(h);               // (the cursors; an error the run already reported is not this call's)
+    {
+        const u32 R = arena_regions(h->arena_cap);
+        const u64 per = h->arena_cap / R;
+        for (u32 r = 0; r < R; ++r) {
+            const u64 used = std::min<u64>(h->hctr.arena_reg[r], (u64)(r + 1) * per) - r * per;
+            if (used) HIPCHK(h, hipMemsetAsync(h->arena + r * per, 0, used * sizeof(uint2), h->stream));
+        }
+        if (h->hctr.arena_top) HIPCHK(h, hipMemsetAsync(h->arena, 0, std::min<u64>(h->hctr.arena_top, h->arena_cap) * sizeof(uint2), h->stream));
+    }
 #if defined(ECB_TIMING) || defined(ECB_EXPERIMENTS)     // experiment builds only (tools/exp_hits.py: a pass over a table that holds every EC already)
     if (!getenv("ECB_KEEP_TABLE"))
 #endif
@@ -1924,11 +2301,12 @@ int ecb_reset(ecb_handle* h) {
         k_fill_i32<<<nblk(ns, TPB), TPB, 0, h->stream>>>(h->rng_min, ns, INT_MAX);
         k_fill_i32<<<nblk(ns, TPB), TPB, 0, h->stream>>>(h->rng_max, ns, INT_MIN);
     }
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    // (no wait: everything above is ordered on the handle's stream, where all later work goes too)
     h->prev_rid = 0xFFFFFFFFu; h->n_reads = 0; h->reads_hi = 0; h->meta_hi = 0; h->n_triples = 0; h->ms_ocount = nullptr; h->ms_adopted = false;
     h->extra_all = h->extra_valid = h->extra_reads = 0;
     h->c_rid.clear(); h->c_loc.clear(); h->c_hf.clear(); h->c_pos.clear();
     h->finalized = false; h->counted = false; h->adopted = false; h->sizes = ecb_sizes{}; h->n_list = 0;
+    h->n_mismatch = 0;
     return ECB_OK;
 }
 
@@ -2012,7 +2390,7 @@ int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
             int rc = stage_and_process(h, nullptr, nullptr, nullptr, nullptr, 0);
             if (rc != ECB_OK) return rc;
         }
-        int rc = sync_counters(h);
+        int rc = h->ctr_synced ? ECB_OK : sync_counters(h);
         if (rc != ECB_OK) return rc;
         rc = ensure_counts(h);
         if (rc != ECB_OK) return rc;
@@ -2022,48 +2400,48 @@ int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
     if (E == 0 || valid == 0) return fail(h, ECB_ERR_EMPTY, "no valid alignments: nothing to build (the reference fails here too)");
     if (E >= (1ull << 31) - 1) return fail(h, ECB_ERR_LIMIT, "more than 2^31-2 equivalence classes");
     free_results(h);
+    // Everything below is queued on the stream; the host waits once, at the end, and checks what the device counted.
     // rank by first appearance: bitmap over read indices (marked while the table is compacted), popcount prefix
     const u64 total_reads = h->n_reads + h->extra_reads;
     const u64 words = (total_reads + 31) / 32 + 1;
+    const u64 nnz_max = std::min<u64>(E * INL + arena_used(h), (1ull << 32) - 1);     // every key pair there can be
     u32 *bitmap = nullptr, *wpop = nullptr, *wprefix = nullptr, *rowlen = nullptr;
     uint2* list_fn = nullptr;
+    u64* d_tot = nullptr;                            // [0] occupied slots, [1] distinct first reads, [2] nnz, [3] long rows (u32)
     POOL(h, P_BITMAP, bitmap, words); POOL(h, P_WPOP, wpop, words); POOL(h, P_WPREFIX, wprefix, words);
     POOL(h, P_ROWLEN, rowlen, E); POOL(h, P_LISTFN, list_fn, E);
     POOL(h, P_ORDER, h->order, E); POOL(h, P_RANK, h->rank_of_slot, h->cap);
     POOL(h, P_INDPTR, h->indptr, E + 1); POOL(h, P_COUNTS, h->counts, E);
+    POOL(h, P_INDICES, h->indices, nnz_max); POOL(h, P_DATA, h->data, nnz_max);
+    POOL(h, P_TOTALS, d_tot, 8);
+    u32* big = nullptr;
+    POOL(h, P_MS_X, big, E);
+    u32* d_nbig = reinterpret_cast<u32*>(d_tot + 3);
     HIPCHK(h, hipMemsetAsync(bitmap, 0, words * 4, h->stream));
-    int rc = compact_table(h, bitmap, total_reads, list_fn);
+    HIPCHK(h, hipMemsetAsync(d_tot, 0, 8 * sizeof(u64), h->stream));
+    int rc = compact_table_dev(h, d_tot, bitmap, total_reads, list_fn);
     if (rc != ECB_OK) return rc;
     k_popc<<<nblk(words, TPB), TPB, 0, h->stream>>>(bitmap, words, wpop);
-    u32 tot = 0;
-    rc = excl_scan(h, wpop, words, wprefix, &tot);
+    rc = excl_scan_dev(h, wpop, words, wprefix, d_tot + 1);
     if (rc != ECB_OK) return rc;
-    if (tot != E) return fail(h, ECB_ERR_HIP, "internal: %u distinct first-appearance indices for %llu ECs", tot, (unsigned long long)E);
     k_rank<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->list, list_fn, E, total_reads, bitmap, wprefix, h->order, rowlen, h->rank_of_slot);
-    u32 nnz = 0;
-    {   // 64-bit check of the row-length total before trusting a 32-bit scan
-        rc = excl_scan(h, rowlen, E, h->indptr, &nnz);
-        if (rc != ECB_OK) return rc;
-        if (arena_used(h) >= (1ull << 31)) return fail(h, ECB_ERR_LIMIT, "A has more than 2^31-1 non-zeros");
-        HIPCHK(h, hipMemcpyAsync(h->indptr + E, &nnz, 4, hipMemcpyHostToDevice, h->stream));
-    }
-    POOL(h, P_INDICES, h->indices, nnz); POOL(h, P_DATA, h->data, nnz);
-    {
-        u32 *big = nullptr, *d_nbig = nullptr, n_big = 0;
-        POOL(h, P_MS_X, big, E + 1);
-        d_nbig = big + E;
-        HIPCHK(h, hipMemsetAsync(d_nbig, 0, 4, h->stream));
-        k_emit_small<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->table, h->order, E, h->arena, h->indptr, h->indices, h->data,
-                                                           h->counts, h->cfg.n_loci, h->cfg.n_haplotypes, big, d_nbig, h->ctr);
-        HIPCHK(h, hipMemcpyAsync(&n_big, d_nbig, 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (n_big)
-            k_emit_big<<<nblk((u64)n_big * 64, TPB), TPB, 0, h->stream>>>(h->table, h->order, big, n_big, h->arena, h->indptr,
-                                                                         h->indices, h->data, h->cfg.n_loci,
-                                                                         h->cfg.n_haplotypes, h->ctr);
-        rc = sync_counters(h);
-        if (rc != ECB_OK) return rc;
-    }
+    rc = excl_scan_dev(h, rowlen, E, h->indptr, d_tot + 2);
+    if (rc != ECB_OK) return rc;
+    k_set_last<<<1, 1, 0, h->stream>>>(h->indptr + E, d_tot + 2);
+    k_emit_small<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->table, h->order, E, h->arena, h->indptr, h->indices, h->data,
+                                                       h->counts, h->cfg.n_loci, h->cfg.n_haplotypes, big, d_nbig, h->ctr);
+    // long rows, one wave each: a fixed launch that walks the queue (its length stays on the device)
+    k_emit_big<<<(unsigned)std::min<u64>(nblk(E * 64, TPB), 2048), TPB, 0, h->stream>>>(h->table, h->order, big, d_nbig, h->arena, h->indptr,
+                                                                                       h->indices, h->data, h->cfg.n_loci, h->cfg.n_haplotypes, h->ctr);
+    u64 tot[4] = {0, 0, 0, 0};
+    HIPCHK(h, hipMemcpyAsync(tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, h->stream));
+    rc = sync_counters(h);                           // the one wait
+    if (rc != ECB_OK) return rc;
+    h->n_list = tot[0];
+    if (tot[0] != E) return fail(h, ECB_ERR_HIP, "internal: %llu occupied slots but %llu ECs created", (unsigned long long)tot[0], (unsigned long long)E);
+    if (tot[1] != E) return fail(h, ECB_ERR_HIP, "internal: %llu distinct first-appearance indices for %llu ECs", (unsigned long long)tot[1], (unsigned long long)E);
+    if (tot[2] >= (1ull << 31)) return fail(h, ECB_ERR_LIMIT, "A has more than 2^31-1 non-zeros");
+    const u64 nnz = tot[2];
     h->sizes.n_ecs = E; h->sizes.nnz_a = nnz; h->sizes.n_samples = 1; h->sizes.nnz_n = E;
     if (h->cfg.flags & ECB_F_MULTISAMPLE) {
         if (h->adopted) {                            // multi-GPU: the triples arrive through ecb_ms_adopt_triples_device
@@ -2183,7 +2561,7 @@ int ecb_table_sizes(ecb_handle* h, uint64_t* n_entries, uint64_t* n_pairs, uint6
     rc = ensure_counts(h);
     if (rc != ECB_OK) return rc;
     if (n_entries) *n_entries = h->n_ecs();
-    if (n_pairs) *n_pairs = arena_used(h);
+    if (n_pairs) *n_pairs = h->n_ecs() * INL + arena_used(h);      // (an upper bound: up to INL pairs per EC sit in its slot)
     if (n_reads) *n_reads = h->n_reads;
     return ECB_OK;
 }
@@ -2215,7 +2593,7 @@ int ecb_table_merge_batch_device(ecb_handle* h, uint32_t n_tables, const void* c
     HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));
     for (u32 t = 0; t < n_tables; ++t)
         if (n_entries[t])
-            k_merge<<<nblk(n_entries[t], MERGE_PER_BLOCK), TPB, 0, h->stream>>>((const Slot*)d_entries[t], n_entries[t], (const uint2*)d_pairs[t],
+            k_merge<<<nblk(n_entries[t], MERGE_PER_BLOCK), TPB, 0, h->stream>>>((const Entry*)d_entries[t], n_entries[t], (const uint2*)d_pairs[t],
                                                                               n_pairs[t], h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr);
     rc = sync_counters(h);
     if (rc != ECB_OK) return rc;
@@ -2254,9 +2632,19 @@ int ecb_table_export_parts_device(ecb_handle* h, void* d_entries, void* d_pairs,
         cur[q] = entry_offsets[q]; cur[n_parts + q] = pair_offsets[q]; cur[2 * n_parts + q] = pair_offsets[q];
     }
     HIPCHK(h, hipMemcpyAsync(d_cnt, cur.data(), 3 * n_parts * sizeof(u64), hipMemcpyHostToDevice, h->stream));
-    if (E) k_parts_export<<<nblk(E, PARTS_PER_BLOCK), TPB, 0, h->stream>>>(h->table, h->list, E, h->arena, n_parts, d_cnt, d_cnt + 2 * n_parts,
-                                                               (Slot*)d_entries, (uint2*)d_pairs, (u32)read_base);
-    HIPCHK(h, hipStreamSynchronize(h->stream));      // (cur lives on this stack frame)
+    if (E) {
+        u64* big = nullptr;                            // long keys: (first pair, slot << 32 | length) + their number behind the list
+        POOL(h, P_BIG, big, 2 * E + 1);
+        u32* d_nbig = reinterpret_cast<u32*>(big + 2 * E);
+        HIPCHK(h, hipMemsetAsync(d_nbig, 0, sizeof(u64), h->stream));
+        k_parts_export<<<nblk(E, PARTS_PER_BLOCK), TPB, 0, h->stream>>>(h->table, h->list, E, h->arena, n_parts, d_cnt, d_cnt + 2 * n_parts,
+                                                                   (Entry*)d_entries, (uint2*)d_pairs, (u32)read_base, big, d_nbig);
+        u32 n_big = 0;
+        HIPCHK(h, hipMemcpyAsync(&n_big, d_nbig, sizeof(u32), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));      // (cur lives on this stack frame)
+        if (n_big) k_parts_sort_big<<<nblk((u64)n_big * 64, TPB), TPB, 0, h->stream>>>(h->table, h->arena, big, n_big, (uint2*)d_pairs);
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return ECB_OK;
 }
 
@@ -2293,7 +2681,7 @@ int ecb_table_adopt_batch_device(ecb_handle* h, uint32_t n_tables, const void* c
     }
     for (u32 t = 0; t < n_tables; ++t) {
         if (!n_entries[t]) continue;
-        k_adopt<<<nblk(n_entries[t], TPB), TPB, 0, h->stream>>>((const Slot*)d_entries[t], n_entries[t], h->table, have, (u32)top);
+        k_adopt<<<nblk(n_entries[t], TPB), TPB, 0, h->stream>>>((const Entry*)d_entries[t], n_entries[t], (const uint2*)d_pairs[t], h->table, have, (u32)top);
         if (n_pairs[t]) HIPCHK(h, hipMemcpyAsync(h->arena + top, d_pairs[t], n_pairs[t] * sizeof(uint2), hipMemcpyDeviceToDevice, h->stream));
         have += n_entries[t]; top += n_pairs[t];
     }
@@ -2313,13 +2701,13 @@ int ecb_export_ec_keys_device(ecb_handle* h, void* d_keys) {
     if (!h->finalized) return fail(h, ECB_ERR_STATE, "export before finalize");
     HIPCHK(h, hipSetDevice(h->device));
     const u64 E = h->sizes.n_ecs;
-    k_export_keys<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->table, h->order, E, (uint4*)d_keys);
+    k_export_keys<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->table, h->order, E, (u64*)d_keys);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return ECB_OK;
 }
 
-int ecb_ms_local_triples_device(ecb_handle* h, const void* d_keys, uint64_t n_ecs, uint64_t read_base,
-                                void* d_key, void* d_count, void* d_first, uint64_t* n_triples) {
+int ecb_ms_local_triples_device(ecb_handle* h, const void* d_keys, const void* d_indptr_a, const void* d_indices_a, const void* d_data_a,
+                                uint64_t n_ecs, uint64_t read_base, void* d_key, void* d_count, void* d_first, uint64_t* n_triples) {
     if (!h || !n_triples) return ECB_ERR_ARG;
     if (!(h->cfg.flags & ECB_F_MULTISAMPLE)) return fail(h, ECB_ERR_STATE, "handle was created without ECB_F_MULTISAMPLE");
     if (h->finalized || h->adopted) return fail(h, ECB_ERR_STATE, "a shard's triples come from the handle its reads were pushed into");
@@ -2330,7 +2718,7 @@ int ecb_ms_local_triples_device(ecb_handle* h, const void* d_keys, uint64_t n_ec
         if (rc0 != ECB_OK) return rc0;
     }
     if (!h->n_reads) return ECB_OK;
-    if (!d_keys || !d_key || !d_count || !d_first) return fail(h, ECB_ERR_ARG, "null buffers");
+    if (!d_keys || !d_indptr_a || !d_indices_a || !d_data_a || !d_key || !d_count || !d_first) return fail(h, ECB_ERR_ARG, "null buffers");
     if (read_base + h->n_reads >= (1ull << 32) - 1) return fail(h, ECB_ERR_LIMIT, "more than 2^32-2 reads in total");
     HIPCHK(h, hipSetDevice(h->device));
     int rc = sync_counters(h);
@@ -2338,7 +2726,8 @@ int ecb_ms_local_triples_device(ecb_handle* h, const void* d_keys, uint64_t n_ec
     u32* grank = nullptr;
     POOL(h, P_MS_GRANK, grank, h->cap);
     HIPCHK(h, hipMemsetAsync(grank, 0xFF, h->cap * sizeof(u32), h->stream));
-    k_set_global_rank<<<nblk(n_ecs, TPB), TPB, 0, h->stream>>>((const uint4*)d_keys, n_ecs, h->table, h->cap - 1, grank);
+    k_set_global_rank<<<nblk(n_ecs, TPB), TPB, 0, h->stream>>>((const u64*)d_keys, (const int*)d_indptr_a, (const int*)d_indices_a, (const int*)d_data_a,
+                                                              n_ecs, h->table, h->cap - 1, h->arena, grank);
     rc = ms_reduce(h, grank);
     if (rc != ECB_OK) return rc;
     const u64 nt = h->n_triples;
@@ -2373,7 +2762,7 @@ int ecb_ms_adopt_triples_device(ecb_handle* h, uint32_t n_tables, const void* co
         HIPCHK(h, hipMemcpyAsync(fin + at, d_first[t], n[t] * 4, hipMemcpyDeviceToDevice, h->stream));
         at += n[t];
     }
-    u32 nt = 0;
+    u64 nt = 0;
     if (tot) {
         k_iota<<<nblk(tot, TPB), TPB, 0, h->stream>>>((int*)vals, tot);
         size_t tmp_bytes = 0;
@@ -2445,14 +2834,15 @@ struct Scratch {                       // frees what it allocated
     template <class T> T* get(u64 n) { void* q = nullptr; if (hipMalloc(&q, std::max<u64>(n, 1) * sizeof(T)) != hipSuccess) return nullptr; p.push_back(q); return (T*)q; }
     ~Scratch() { for (void* q : p) hipFree(q); }
 };
-int cv_scan(hipStream_t st, const u32* in, u64 n, u32* out, u32* total, Scratch& sc) {
+int cv_scan(hipStream_t st, const u32* in, u64 n, u32* out, u64* total, Scratch& sc) {
     const u64 nb = std::max<u64>(1, (n + SCAN_BLOCK - 1) / SCAN_BLOCK);
-    u32* sums = sc.get<u32>(nb + 1);
+    u32* sums = sc.get<u32>(nb + 4);
     if (!sums) return ECB_ERR_HIP;
+    u64* grand = reinterpret_cast<u64*>(sums + ((nb + 1) & ~(u64)1));
     k_scan_sums<<<(unsigned)nb, TPB, 0, st>>>(in, n, sums);
-    k_scan_top<<<1, TPB, 0, st>>>(sums, nb, sums + nb);
+    k_scan_top<<<1, TPB, 0, st>>>(sums, nb, grand);
     k_scan_apply<<<(unsigned)nb, TPB, 0, st>>>(in, n, sums, out);
-    if (hipMemcpyAsync(total, sums + nb, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return ECB_ERR_HIP;
+    if (hipMemcpyAsync(total, grand, 8, hipMemcpyDeviceToHost, st) != hipSuccess) return ECB_ERR_HIP;
     return hipStreamSynchronize(st) == hipSuccess ? ECB_OK : ECB_ERR_HIP;
 }
 }  // namespace
@@ -2471,8 +2861,9 @@ extern "C" int ecb_csr_to_hapcsc_device(int device, uint32_t n_ecs, uint32_t n_l
     u32 *cnt = sc.get<u32>(nnz), *pos = sc.get<u32>(nnz);
     if (!cnt || !pos) return fail(nullptr, ECB_ERR_HIP, "out of device memory");
     k_cv_popc<<<nblk(nnz, TPB), TPB, 0, st>>>((const int*)d_data, nnz, cnt);
-    u32 tot = 0;
+    u64 tot = 0;
     if (cv_scan(st, cnt, nnz, pos, &tot, sc) != ECB_OK) return fail(nullptr, ECB_ERR_HIP, "scan");
+    if (tot >= (1ull << 32)) return fail(nullptr, ECB_ERR_LIMIT, "more than 2^32-1 set haplotype bits");
     *total = tot;
     if (!d_cscidx || !d_cscptr) return ECB_OK;
     u32 *keys = sc.get<u32>(tot), *vals = sc.get<u32>(tot), *keys2 = sc.get<u32>(tot);
@@ -2518,7 +2909,7 @@ extern "C" int ecb_hapcsc_to_csr_device(int device, uint32_t n_ecs, uint32_t n_l
     if (!tmp) return fail(nullptr, ECB_ERR_HIP, "out of device memory");
     if (rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, total, 0, 64, st) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "sort");
     k_ms_heads<<<nblk(total, TPB), TPB, 0, st>>>(keys2, total, flag);
-    u32 nnz = 0;
+    u64 nnz = 0;
     if (cv_scan(st, flag, total, pos, &nnz, sc) != ECB_OK) return fail(nullptr, ECB_ERR_HIP, "scan");
     k_cv_back_emit<<<nblk(total, TPB), TPB, 0, st>>>(keys2, vals2, flag, pos, total, n_loci, (int*)d_indices, (int*)d_data);
     k_cv_back_rowptr<<<nblk((u64)n_ecs + 1, TPB), TPB, 0, st>>>(keys2, pos, total, nnz, n_ecs, n_loci, (int*)d_indptr);

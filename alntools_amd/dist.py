@@ -27,6 +27,32 @@ ENTRY_WORDS = 4          # one table entry = 32 bytes = 4 x int64
 PAIR_WORDS = 1           # one (locus, mask) pair = 8 bytes = 1 x int64
 
 
+def ec_keys_words(n_ecs, nnz):
+    """int64 words of the packed EC list: hashes | indptr (int32, padded) | indices | data."""
+    return n_ecs + (n_ecs + 2) // 2 + 2 * ((nnz + 1) // 2)
+
+
+def pack_ec_keys(keys, indptr, indices, data):
+    """One int64 tensor (one broadcast): [hash per EC | indptr | indices | data], the int32 parts padded to whole words."""
+    n_ecs, nnz = keys.numel(), indices.numel()
+    out = torch.zeros(ec_keys_words(n_ecs, nnz), dtype=torch.int64, device=keys.device)
+    out[:n_ecs] = keys
+    w = out[n_ecs:].view(torch.int32)
+    a = 2 * ((n_ecs + 2) // 2)
+    b = a + 2 * ((nnz + 1) // 2)
+    w[:n_ecs + 1] = indptr
+    w[a:a + nnz] = indices
+    w[b:b + nnz] = data
+    return out
+
+
+def unpack_ec_keys(packed, n_ecs, nnz):
+    w = packed[n_ecs:].view(torch.int32)
+    a = 2 * ((n_ecs + 2) // 2)
+    b = a + 2 * ((nnz + 1) // 2)
+    return packed[:n_ecs], w[:n_ecs + 1], w[a:a + nnz], w[b:b + nnz]
+
+
 class GpuEngine(object):
     """Adapter from :class:`alntools_amd.ecb.EcBuilder` to the merge protocol."""
 
@@ -58,16 +84,24 @@ class GpuEngine(object):
 
     # multisample across GPUs
     def ec_keys(self, n_ecs):
-        keys = torch.empty(2 * max(n_ecs, 1), dtype=torch.int64, device=self.device)
+        """The merged ECs in rank order, as the shards need them to find their own: (hash per EC [int64], CSR A indptr,
+        indices, data [int32]) -- one packed int64 tensor plus its layout ``(n_ecs, nnz)``."""
+        nnz = self.b.sizes["nnz_a"]
+        keys = torch.empty(max(n_ecs, 1), dtype=torch.int64, device=self.device)
+        ip = torch.empty(n_ecs + 1, dtype=torch.int32, device=self.device)
+        ix = torch.empty(max(nnz, 1), dtype=torch.int32, device=self.device)
+        da = torch.empty(max(nnz, 1), dtype=torch.int32, device=self.device)
         self.b.export_ec_keys_device(keys)
-        return keys
+        self.b.export_device(ip, ix, da)
+        return pack_ec_keys(keys[:n_ecs], ip, ix[:nnz], da[:nnz]), nnz
 
-    def ms_local_triples(self, keys, n_ecs, read_base):
+    def ms_local_triples(self, packed, n_ecs, nnz, read_base):
+        keys, ip, ix, da = unpack_ec_keys(packed, n_ecs, nnz)
         n_reads = self.b.table_sizes()[2]
         key = torch.empty(max(n_reads, 1), dtype=torch.int64, device=self.device)
         cnt = torch.empty(max(n_reads, 1), dtype=torch.int32, device=self.device)
         first = torch.empty(max(n_reads, 1), dtype=torch.int32, device=self.device)
-        n = self.b.ms_local_triples_device(keys, n_ecs, read_base, key, cnt, first)
+        n = self.b.ms_local_triples_device(keys, ip, ix, da, n_ecs, read_base, key, cnt, first)
         return key, cnt, first, n
 
     def ms_adopt_triples(self, tables):
@@ -126,10 +160,11 @@ class HostStagedEngine(object):
         self.e.table_adopt_many([(self._up(a), n, self._up(b), m) for a, n, b, m in tables])
 
     def ec_keys(self, n_ecs):
-        return self.e.ec_keys(n_ecs).cpu()
+        packed, nnz = self.e.ec_keys(n_ecs)
+        return packed.cpu(), nnz
 
-    def ms_local_triples(self, keys, n_ecs, read_base):
-        k, c, f, n = self.e.ms_local_triples(self._up(keys), n_ecs, read_base)
+    def ms_local_triples(self, packed, n_ecs, nnz, read_base):
+        k, c, f, n = self.e.ms_local_triples(self._up(packed), n_ecs, nnz, read_base)
         return k.cpu(), c.cpu(), f.cpu(), n
 
     def ms_adopt_triples(self, tables):
@@ -232,26 +267,29 @@ def exchange_and_merge(engine, make_part_engine, make_root_engine, group=None, r
 
 def exchange_multisample(engine, merged, n_ecs, group=None, root=0):
     """Multisample (``bam_utils_multisample.py``) after :func:`exchange_and_merge` and the root's finalize: the per-(EC, cell,
-    file) read counts, i.e. the merge of the workers' ``ec[key][cell]`` (``:503-576``).  The root broadcasts the keys of the
-    final ECs in rank order (16 bytes each); every rank looks its own ECs up in that list and reduces its reads to distinct
-    (global EC, cell, file) triples; the triples go to the root, which adds up the ones a cell has on two ranks.
+    file) read counts, i.e. the merge of the workers' ``ec[key][cell]`` (``:503-576``).  The root broadcasts the final ECs in
+    rank order (hash + CSR A row: 110 MB at config 3); every rank finds its own ECs in that list -- by hash, then key against
+    row, so the match is exact -- and reduces its reads to distinct (global EC, cell, file) triples; the triples go to the
+    root, which adds up the ones a cell has on two ranks.
     ``merged`` / ``n_ecs``: the finalized root engine and its EC count on the root, ignored elsewhere.  Returns the number
     of distinct triples on the root (then ``export_pairs`` works as on one GPU), None elsewhere."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = engine.device
     nreads = engine.table_sizes()[2]
-    info = torch.tensor([nreads, n_ecs if rank == root else 0], dtype=torch.int64, device=dev)
-    allinfo = torch.empty(world * 2, dtype=torch.int64, device=dev)
+    keys, nnz = merged.ec_keys(n_ecs) if rank == root else (None, 0)
+    info = torch.tensor([nreads, n_ecs if rank == root else 0, nnz], dtype=torch.int64, device=dev)
+    allinfo = torch.empty(world * 3, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(allinfo, info, group=group)
-    allinfo = allinfo.view(world, 2).cpu().tolist()
+    allinfo = allinfo.view(world, 3).cpu().tolist()
     read_base = sum(a[0] for a in allinfo[:rank])
-    n_ecs = allinfo[root][1]
-    keys = merged.ec_keys(n_ecs) if rank == root else torch.empty(2 * max(n_ecs, 1), dtype=torch.int64, device=dev)
+    n_ecs, nnz = allinfo[root][1], allinfo[root][2]
+    if rank != root:
+        keys = torch.empty(ec_keys_words(n_ecs, nnz), dtype=torch.int64, device=dev)
     dist.broadcast(keys, src=root, group=group)
     if dev.type == "cuda":
         torch.cuda.current_stream(dev).synchronize()     # libecb works on its own stream: the keys must have landed
-    key, cnt, first, n = engine.ms_local_triples(keys, n_ecs, read_base)
+    key, cnt, first, n = engine.ms_local_triples(keys, n_ecs, nnz, read_base)
     mine = torch.tensor([n], dtype=torch.int64, device=dev)
     alln = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(alln, mine, group=group)

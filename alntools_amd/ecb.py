@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, os.environ.get("ECB_LIB", "libecb.so"))   # ECB_L
 
 F_RANGES = 1
 F_MULTISAMPLE = 2
+F_VERIFY = 4
 HAP_SHIFT = 16
 FLAG_MATE_OTHER_REF = 0x1000
 FLAG_NEXT_POS_NEG = 0x2000
@@ -98,7 +99,7 @@ def load():
     for f in (lib.ecb_table_merge_batch_device, lib.ecb_table_adopt_batch_device):
         f.argtypes = [vp, C.c_uint32, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64)]
     lib.ecb_export_ec_keys_device.argtypes = [vp, vp]
-    lib.ecb_ms_local_triples_device.argtypes = [vp, vp, u64, u64, vp, vp, vp, C.POINTER(u64)]
+    lib.ecb_ms_local_triples_device.argtypes = [vp, vp, vp, vp, vp, u64, u64, vp, vp, vp, C.POINTER(u64)]
     lib.ecb_ms_adopt_triples_device.argtypes = [vp, C.c_uint32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
     lib.ecb_counters.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     lib.ecb_add_counters.argtypes = [vp, u64, u64, u64]
@@ -161,10 +162,10 @@ class EcBuilder(object):
     """One handle = one GPU.  Push record tuples, finalize, read back CSR A and N."""
 
     def __init__(self, n_loci, n_haplotypes, device=0, track_ranges=False, ec_capacity=0,
-                 arena_capacity=0, max_batch_records=0, multisample=False):
+                 arena_capacity=0, max_batch_records=0, multisample=False, verify=False):
         self._lib = load()
         self._h = C.c_void_p()
-        flags = (F_RANGES if track_ranges else 0) | (F_MULTISAMPLE if multisample else 0)
+        flags = (F_RANGES if track_ranges else 0) | (F_MULTISAMPLE if multisample else 0) | (F_VERIFY if verify else 0)
         self.multisample = multisample
         cfg = Config(C.sizeof(Config), device, n_loci, n_haplotypes, flags, 0, ec_capacity,
                      arena_capacity, max_batch_records)
@@ -218,8 +219,8 @@ class EcBuilder(object):
                                             _dev_ptr(pos), n))
 
     def verify_device(self, read_id, locus, hapflag):
-        """Exactness pass over the device-resident stream that was pushed: -> (reads whose target set differs from
-        their EC's stored key, reads too long to be re-checked)."""
+        """Independent exactness pass over the device-resident stream that was pushed: -> (reads whose target set differs
+        from their EC's stored key, reads that took the long-read compare)."""
         bad, skipped = C.c_uint64(), C.c_uint64()
         self._chk(self._lib.ecb_verify_device(self._h, _dev_ptr(read_id), _dev_ptr(locus), _dev_ptr(hapflag),
                                               read_id.numel(), C.byref(bad), C.byref(skipped)))
@@ -314,14 +315,20 @@ class EcBuilder(object):
 
     # -- multisample across GPUs ----------------------------------------------
     def export_ec_keys_device(self, keys):
-        """After finalize: the 16-byte key of every EC in rank order into ``keys`` (int64 tensor of 2 * n_ecs)."""
+        """After finalize: the 8-byte set hash of every EC in rank order into ``keys`` (int64 tensor of n_ecs)."""
         self._chk(self._lib.ecb_export_ec_keys_device(self._h, _dev_ptr(keys)))
 
-    def ms_local_triples_device(self, keys, n_ecs, read_base, out_key, out_count, out_first):
-        """A shard's (EC, cell, file) triples with global EC ids -> number of triples written."""
+    def export_device(self, indptr, indices, data):
+        """After finalize: CSR A into int32 device tensors of E + 1 / nnz / nnz elements."""
+        self._chk(self._lib.ecb_export_device(self._h, _dev_ptr(indptr), _dev_ptr(indices), _dev_ptr(data), None, None, None))
+
+    def ms_local_triples_device(self, keys, indptr, indices, data, n_ecs, read_base, out_key, out_count, out_first):
+        """A shard's (EC, cell, file) triples with global EC ids (its ECs found in the merged result by hash ``keys`` and
+        then by key against the merged CSR rows) -> number of triples written."""
         n = C.c_uint64()
-        self._chk(self._lib.ecb_ms_local_triples_device(self._h, _dev_ptr(keys), n_ecs, read_base, _dev_ptr(out_key),
-                                                        _dev_ptr(out_count), _dev_ptr(out_first), C.byref(n)))
+        self._chk(self._lib.ecb_ms_local_triples_device(self._h, _dev_ptr(keys), _dev_ptr(indptr), _dev_ptr(indices), _dev_ptr(data),
+                                                        n_ecs, read_base, _dev_ptr(out_key), _dev_ptr(out_count), _dev_ptr(out_first),
+                                                        C.byref(n)))
         return n.value
 
     def ms_adopt_triples_device(self, tables):

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define ECB_ABI_VERSION 1
+#define ECB_ABI_VERSION 2
 
 #define ECB_OK               0
 #define ECB_ERR_ARG         -1   /* bad argument / configuration */
@@ -58,9 +58,11 @@ extern "C" {
 #define ECB_ERR_STATE       -6   /* call out of order (push after finalize, export before finalize) */
 #define ECB_ERR_EMPTY       -7   /* no valid alignment at all (the reference fails too: bam_utils.py:336-339) */
 #define ECB_ERR_LIMIT       -8   /* result exceeds the .bin format's int32 limits (bin_utils.py:214-232) */
+#define ECB_ERR_VERIFY      -9   /* ECB_F_VERIFY: the exactness pass found a read in an EC whose key is not its target set */
 
 #define ECB_F_RANGES        1u   /* track min/max reference_start per (locus, haplotype) */
 #define ECB_F_MULTISAMPLE   2u   /* per-read cell ids; N becomes EC x cell (bam_utils_multisample.py) */
+#define ECB_F_VERIFY        4u   /* run the exactness pass (see ecb_verify_device) over every batch before the push returns */
 
 #define ECB_HAP_SHIFT 16
 #define ECB_FLAG_MATE_OTHER_REF 0x1000u
@@ -137,13 +139,17 @@ int ecb_export_pairs(ecb_handle* h, uint32_t* ec, uint32_t* meta, uint32_t* coun
 /* EC index of every read, in read order (n_reads values). */
 int ecb_export_read_ec(ecb_handle* h, int32_t* ec_of_read);
 
-/* Exactness check.  EC identity on the device is a 126-bit hash of the read's target set; this pass re-derives the
- * {locus -> haplotype mask} set of every read from the records and compares it, pair by pair, with the key stored
- * for the EC the read was assigned to.  The records must be the device-resident stream that was pushed (one
- * ecb_push_device call covering the whole stream).  *n_mismatch counts reads whose set differs from their EC's key
- * (0 = the grouping is exact); *n_skipped counts reads longer than a tile, which this pass does not re-check. */
+/* Exactness.  EC identity is exact by construction: a read joins an EC only after its {locus -> haplotype mask} set has
+ * been compared, pair by pair, with the key stored for that EC (the reference compares the sorted tid strings,
+ * bam_utils.py:307-312); the 64-bit set hash only picks the table slot, and two target sets with one hash get two slots.
+ * The same holds for the multi-GPU merge (ecb_table_merge_*) and the multisample rank lookup.
+ * ecb_verify_device is the independent re-check used by the tests and by ECB_F_VERIFY: a second pass re-derives the set
+ * of every read from the records and compares it with the key of the EC the read was assigned to.  The records must be
+ * the device-resident stream that was pushed (one ecb_push_device call covering the whole stream).  *n_mismatch counts
+ * reads whose set differs from their EC's key (0 = the grouping is exact); *n_long counts reads longer than a tile,
+ * which are re-checked too, on the long-read path. */
 int ecb_verify_device(ecb_handle* h, const void* d_read_id, const void* d_locus, const void* d_hapflag, size_t n,
-                      uint64_t* n_mismatch, uint64_t* n_skipped);
+                      uint64_t* n_mismatch, uint64_t* n_long);
 
 /* Multi-GPU: one handle per GPU over contiguous read shards (the reference's contiguous chunk
  * ranges per process, bam_utils.py:646-658).  A rank serialises its EC table (device buffers the
@@ -151,7 +157,8 @@ int ecb_verify_device(ecb_handle* h, const void* d_read_id, const void* d_locus,
  * receiving rank merges it -- the reference's ordered merge, bam_utils.py:680-724.
  * read_base = number of reads on all lower ranks (makes "first appearance" global).
  * ecb_table_sizes: *n_pairs is an upper bound of the key pairs in use (buffer size); the export writes the keys of the
- * entries packed behind each other, Slot.off relative to the start of d_pairs. */
+ * entries, each sorted by locus, packed behind each other; an entry is 32 bytes {u64 hash, u64 reserved, u32 count,
+ * u32 ~first_read, u32 off, u32 n} with its key at pairs[off .. off + n) of its part.  The merge compares keys, not hashes. */
 int ecb_table_sizes(ecb_handle* h, uint64_t* n_entries, uint64_t* n_pairs, uint64_t* n_reads);
 int ecb_table_export_device(ecb_handle* h, void* d_entries, void* d_pairs, uint64_t read_base);
 int ecb_table_merge_device(ecb_handle* h, const void* d_entries, uint64_t n_entries,
@@ -173,14 +180,16 @@ int ecb_table_merge_batch_device(ecb_handle* h, uint32_t n_tables, const void* c
 int ecb_table_adopt_batch_device(ecb_handle* h, uint32_t n_tables, const void* const* d_entries, const uint64_t* n_entries,
                                  const void* const* d_pairs, const uint64_t* n_pairs);
 /* Multisample across GPUs (the shards' handles and the root's adopting handle all carry ECB_F_MULTISAMPLE).  After the ECs
- * were merged and the root finalized: ecb_export_ec_keys_device writes the 16-byte key of every EC in rank order
- * (n_ecs * 16 bytes; broadcast it).  A shard looks its own ECs up in that list and reduces its reads to distinct
+ * were merged and the root finalized: ecb_export_ec_keys_device writes the 8-byte set hash of every EC in rank order
+ * (n_ecs * 8 bytes; broadcast it together with the root's CSR A from ecb_export_device).  A shard finds its own ECs in
+ * that list -- by hash, then by comparing its stored key with the CSR row -- and reduces its reads to distinct
  * (EC, cell, file) triples with GLOBAL EC ids -- ecb_ms_local_triples_device: key = EC << 32 | meta (sorted), count,
  * first read (read_base added); buffers of n_reads elements, *n_triples written.  The root combines the shards' triples
  * (a cell whose reads straddle two shards: counts added, first = min) with ecb_ms_adopt_triples_device, after which
  * ecb_export_pairs works as on one GPU.  (bam_utils_multisample.py:503-576: the merge of the workers' ec[key][cell].) */
 int ecb_export_ec_keys_device(ecb_handle* h, void* d_keys);
-int ecb_ms_local_triples_device(ecb_handle* h, const void* d_keys, uint64_t n_ecs, uint64_t read_base,
+int ecb_ms_local_triples_device(ecb_handle* h, const void* d_keys, const void* d_indptr_a, const void* d_indices_a,
+                                const void* d_data_a, uint64_t n_ecs, uint64_t read_base,
                                 void* d_key, void* d_count, void* d_first, uint64_t* n_triples);
 int ecb_ms_adopt_triples_device(ecb_handle* h, uint32_t n_tables, const void* const* d_key, const void* const* d_count,
                                 const void* const* d_first, const uint64_t* n, uint64_t* n_triples);

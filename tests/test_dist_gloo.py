@@ -100,11 +100,17 @@ class OracleEngine(object):
     def ec_keys(self, n_ecs):
         rows = sorted(self.table.items(), key=lambda kv: kv[1][1])
         assert len(rows) == n_ecs
-        return torch.tensor([x for (lo, hi), _ in rows for x in (lo, hi)], dtype=torch.int64)
+        c = self.csr()
+        packed = ecdist.pack_ec_keys(torch.tensor([lo for (lo, hi), _ in rows], dtype=torch.int64),
+                                     torch.tensor(c["indptr"], dtype=torch.int32), torch.tensor(c["indices"], dtype=torch.int32),
+                                     torch.tensor(c["data"], dtype=torch.int32))
+        return packed, len(c["indices"])
 
-    def ms_local_triples(self, keys, n_ecs, read_base):
-        k = keys.tolist()
-        rank_of = {(k[2 * e], k[2 * e + 1]): e for e in range(n_ecs)}
+    def ms_local_triples(self, packed, n_ecs, nnz, read_base):
+        keys, ip, ix, da = (t.tolist() for t in ecdist.unpack_ec_keys(packed, n_ecs, nnz))
+        rank_of_key = {tuple(zip(ix[ip[e]:ip[e + 1]], da[ip[e]:ip[e + 1]])): e for e in range(n_ecs)}     # exact: the key itself
+        rank_of = {ident: rank_of_key[v[2]] for ident, v in self.table.items()}
+        assert all(keys[rank_of[ident]] == ident[0] for ident in self.table)
         acc = {}
         for i, ident in enumerate(self.read_ident):
             t = acc.setdefault((rank_of[ident] << 32) | int(self.meta[i]), [0, i + read_base])

@@ -589,10 +589,11 @@ def test_multisample_over_shards_equals_one_handle():
     assert s["n_ecs"] == s1["n_ecs"] and s["nnz_n"] == 0
     with pytest.raises(ecb.EcbError):
         root.b.export_pairs()                                            # no triples adopted yet
-    keys = root.ec_keys(s["n_ecs"])
+    keys, nnz = root.ec_keys(s["n_ecs"])
+    assert nnz == s["nnz_a"]
     tables = []
     for eng, b0 in shards:
-        key, cnt, first, n = eng.ms_local_triples(keys, s["n_ecs"], b0)
+        key, cnt, first, n = eng.ms_local_triples(keys, s["n_ecs"], nnz, b0)
         assert n > 0 and bool((key[1:n] > key[:n - 1]).all())
         tables.append((key, cnt, first, n))
     nt = root.ms_adopt_triples(tables)
@@ -633,10 +634,12 @@ def test_multi_gpu_entry_points_refuse_wrong_states():
         t2 = synth.generate(spec, 0, 10, device=dev)
         b.push_device(t2["read_id"], t2["locus"], t2["hapflag"])         # the table was exported: the stream is closed
     keys = torch.zeros(2, dtype=torch.int64, device=dev)
+    csr = (torch.tensor([0, 1], dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev),
+           torch.ones(1, dtype=torch.int32, device=dev))
     out = (torch.empty(nreads, dtype=torch.int64, device=dev), torch.empty(nreads, dtype=torch.int32, device=dev),
            torch.empty(nreads, dtype=torch.int32, device=dev))
     with pytest.raises(ecb.EcbError):
-        b.ms_local_triples_device(keys, 1, 0, *out)                      # handle without ECB_F_MULTISAMPLE
+        b.ms_local_triples_device(keys, *csr, 1, 0, *out)                # handle without ECB_F_MULTISAMPLE
     with pytest.raises(ecb.EcbError):
         b.export_ec_keys_device(keys)                                    # before finalize
     with pytest.raises(ecb.EcbError):
@@ -644,10 +647,10 @@ def test_multi_gpu_entry_points_refuse_wrong_states():
     ms = ecb.EcBuilder(spec.n_loci, spec.n_haps, multisample=True)
     ms.push_device(t["read_id"], t["locus"], t["hapflag"])
     with pytest.raises(ecb.EcbError):
-        ms.ms_local_triples_device(keys, 1, 0, *out)                     # cells were never pushed
+        ms.ms_local_triples_device(keys, *csr, 1, 0, *out)               # cells were never pushed
     ms.push_cells(np.zeros(nreads, np.uint32), 0)
     with pytest.raises(ecb.EcbError):
-        ms.ms_local_triples_device(keys, 1, 0, *out)                     # its ECs are not in that key list
+        ms.ms_local_triples_device(keys, *csr, 1, 0, *out)               # its ECs are not in that key list
     with pytest.raises(ecb.EcbError):
         ms.ms_adopt_triples_device([out + (0,)])                         # not an adopting, finalized handle
     b.close()

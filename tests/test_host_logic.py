@@ -112,7 +112,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     assert declared == set(ecb.SYMBOLS), declared ^ set(ecb.SYMBOLS)
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.ecb_abi_version() == 1
+    assert lib.ecb_abi_version() == 2
 
 
 def test_plain_c_program_links_against_the_abi(tmp_path):
