@@ -62,8 +62,11 @@ constexpr u32 ERR_INTERNAL = 16u;
 // its own (bam_utils.py:307-312 compares the sorted tid strings).  Two different target sets with the same 64-bit hash
 // simply live in two slots.  Keys of up to INL loci sit in the line the lookup fetches anyway, so the compare costs no
 // memory traffic; longer keys continue in the key arena.
-// Life of a slot: lo 0 -> hash (atomicCAS: claimed); the claimant stores off and the pairs (write-through), waits for them,
-// then stores n1 = n + 1 (published).  Nothing else ever changes lo, n1, off or the pairs until the table is cleared.
+// Life of a slot: lo 0 -> hash (atomicCAS: claimed); the claimant stores the pairs and the word {n1 = n + 1, off}, each
+// with one 8-byte write-through store, in any order and without waiting for any of them.  A reader needs no ordering
+// either: the haplotype mask of a key pair is never zero and slot and arena start out zeroed, so a key is complete exactly
+// when n1 is set and its n masks are non-zero -- anything less is "not published yet" and is polled again.  Nothing ever
+// changes lo, n1, off or a pair once written, until the table is cleared.
 struct alignas(64) Slot {
     u64 lo;                          // 64-bit set hash, non-zero once claimed
     u32 n1;                          // 0 until the key is complete, then number of pairs + 1
@@ -152,23 +155,53 @@ __device__ __forceinline__ bool rec_valid(u32 hf) {
 // Read counts and first appearances are NOT maintained here: per-read atomics on a skewed EC distribution run at
 // ~5 G/s chip-wide (measured), so k_stream only records the slot of every read and k_count reduces them afterwards.
 // ---------------------------------------------------------------------------------------------
-enum { ST_NONE = 0, ST_HIT, ST_CREATED, ST_PENDING, ST_FULL, ST_OTHER, ST_STUCK };
+enum { ST_NONE = 0, ST_LOOK, ST_HIT, ST_CREATED, ST_PENDING, ST_FULL, ST_OTHER, ST_STUCK };
+enum { CMP_EQUAL = 0, CMP_DIFFERENT, CMP_INCOMPLETE, CMP_UNSURE };
 struct SlotView { u32 n, off; uint2 p[INL]; };
 
 __device__ __forceinline__ u64 fresh64(u64* p) { return atomicOr(p, 0ull); }      // a read that cannot be served from a stale cache line
 __device__ __forceinline__ void store_wt64(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // write-through
-__device__ __forceinline__ void store_wt32(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u64 pack2(uint2 v) { return ((u64)v.y << 32) | v.x; }
 __device__ __forceinline__ uint2 unpack2(u64 v) { return make_uint2((u32)v, (u32)(v >> 32)); }
+__device__ __forceinline__ void publish_key(Slot* s, u32 n1, u32 off) { store_wt64(reinterpret_cast<u64*>(&s->n1), ((u64)off << 32) | n1); }   // n1 and off: one word
 // pair i of the key of a PUBLISHED slot, outside the kernels that publish (finalize, export, rehash): plain loads
 __device__ __forceinline__ uint2 key_pair(const Slot& s, const uint2* arena, u32 i) { return i < INL ? s.pair[i] : arena[(u64)s.off + (i - INL)]; }
+// ... and of a slot that may be in the middle of being published: a read that no cache can serve
+__device__ __forceinline__ uint2 key_pair_fresh(Slot* s, uint2* arena, u32 off, u32 i) {
+    return unpack2(fresh64(reinterpret_cast<u64*>(i < INL ? &s->pair[i] : arena + ((u64)off + (i - INL)))));
+}
 
+// ---------------------------------------------------------------------------------------------
+// EC-table lookup / insert with exact keys.  A comparator has two forms:
+//   quick(view)  on the line a lookup has just loaded: CMP_EQUAL (same size, every stored pair in my set), CMP_DIFFERENT (a
+//                stored pair -- complete, since its mask is non-zero -- is not in my set, or the sizes differ), CMP_INCOMPLETE
+//                (a mask still zero) or CMP_UNSURE (it would take more work to tell);
+//   full(slot, n, off)   reads the key itself, fresh (read-modify-write atomics): the first three, after whatever work it takes.
+//   table_lookup: probes from j, the whole line in one round trip.  Plain loads: a cached line can only be an OLDER state
+//     of the slot (zeros where values will be), so what a stale line can cost is an atomic or a trip through table_settle,
+//     never a wrong answer: "empty" is re-checked by the CAS, "not complete" is polled, and "equal" / "different" are
+//     decided on pairs that are final.
+//   table_settle: the slot carries our hash but its key was not (visibly) complete, or the quick look could not tell.
+//     Polls with read-modify-write atomics, which execute at the memory side, until the key is whole, and decides.
+//   Callers that create a slot publish it BEFORE any lane of their wave calls table_settle: the creator a lane waits for
+//   may sit in its own wave.
+// Read counts and first appearances are NOT maintained here: per-read atomics on a skewed EC distribution run at
+// ~5 G/s chip-wide (measured), so k_stream only records the slot of every read and k_count reduces them afterwards.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ SlotView make_view(uint4 a, uint4 b, uint4 c, uint4 d) {
+    SlotView v;
+    v.n = a.z - 1u; v.off = a.w;
+    v.p[0] = make_uint2(b.z, b.w); v.p[1] = make_uint2(c.x, c.y); v.p[2] = make_uint2(c.z, c.w);
+    v.p[3] = make_uint2(d.x, d.y); v.p[4] = make_uint2(d.z, d.w);
+    return v;
+}
 template <class Cmp>
-__device__ __forceinline__ int table_lookup(Slot* table, u64 cap_mask, u64 lo, u64& j, u32& probes, const Cmp& cmp) {
+__device__ __forceinline__ int table_lookup(Slot* table, u64 cap_mask, u64 lo, u64& j, u32& probes, const Cmp& cmp, u32 abl = 0u) {
     for (; probes < MAX_PROBE; ++probes, j = (j + 1) & cap_mask) {
         Slot* s = table + j;
         const uint4* q = reinterpret_cast<const uint4*>(s);
-        const uint4 a = q[0];                                     // lo, n1, off
+        uint4 a = q[0], b = a, c = a, d = a;                      // lo, n1, off | count, first_inv, pair 0 | pairs 1, 2 | pairs 3, 4
+        if (!(abl & 16u)) { b = q[1]; c = q[2]; d = q[3]; }       // (profiling only: 16 = first 16 bytes only, 8 = no key compare)
         u64 clo = ((u64)a.y << 32) | a.x;
         if (clo == 0ull) {
             clo = atomicCAS(&s->lo, 0ull, lo);
@@ -178,32 +211,28 @@ __device__ __forceinline__ int table_lookup(Slot* table, u64 cap_mask, u64 lo, u
         }
         if (clo != lo) continue;
         if (a.z == 0u) return ST_PENDING;
-        const uint4 b = q[1], c = q[2], d = q[3];                 // count, first_inv, pair 0 | pairs 1, 2 | pairs 3, 4
-        SlotView v;
-        v.n = a.z - 1u; v.off = a.w;
-        v.p[0] = make_uint2(b.z, b.w); v.p[1] = make_uint2(c.x, c.y); v.p[2] = make_uint2(c.z, c.w);
-        v.p[3] = make_uint2(d.x, d.y); v.p[4] = make_uint2(d.z, d.w);
-        if (a.z != DEAD_KEY && cmp(v)) return ST_HIT;
-        return ST_PENDING;                                        // a stale line or a true hash collision: settled on fresh reads
-    }
+        if (a.z == DEAD_KEY) continue;
+        if (abl & 8u) return ST_HIT;
+        const int r = cmp.quick(make_view(a, b, c, d));
+        if (r == CMP_EQUAL) return ST_HIT;
+        if (r != CMP_DIFFERENT) return ST_PENDING;
+    }                                                             // (same hash, another key: a true collision takes the next slot)
     return ST_FULL;
 }
 template <class Cmp>
 __device__ __forceinline__ int table_settle(Slot* s, const Cmp& cmp) {
-    u32 n1 = 0;
     for (u32 spin = 0; spin < SPIN_MAX; ++spin) {
-        n1 = atomicOr(&s->n1, 0u);
-        if (n1) break;
+        const u64 w = fresh64(reinterpret_cast<u64*>(&s->n1));
+        const u32 n1 = (u32)w;
+        if (n1 == DEAD_KEY) return ST_OTHER;
+        if (n1) {
+            const int r = cmp.full(s, n1 - 1u, (u32)(w >> 32));
+            if (r == CMP_EQUAL) return ST_HIT;
+            if (r == CMP_DIFFERENT) return ST_OTHER;
+        }
         __builtin_amdgcn_s_sleep(4);
     }
-    if (!n1) return ST_STUCK;
-    if (n1 == DEAD_KEY) return ST_OTHER;
-    SlotView v;
-    v.n = n1 - 1u;
-    v.off = atomicOr(&s->off, 0u);
-#pragma unroll
-    for (u32 i = 0; i < INL; ++i) v.p[i] = i < v.n ? unpack2(fresh64(reinterpret_cast<u64*>(&s->pair[i]))) : make_uint2(0u, 0u);
-    return cmp(v) ? ST_HIT : ST_OTHER;
+    return ST_STUCK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -227,17 +256,45 @@ constexpr int NWAVE = TPB / 64;
 #define ECB_WAVES_PER_SIMD 4
 #endif
 constexpr int SLOT_SHIFT = ECB_SLOT_SHIFT;           // table slots per record = 1 + 2^-SLOT_SHIFT (1: 1.5, 2: 1.25)
-constexpr int TSLOTS = WT + (WT >> SLOT_SHIFT);      // LDS table slots per wave tile
+constexpr int CPAD = 128;                             // table slots in front of the tile's own: room for the entries a read carries in
+constexpr int CMAX = 80;                              // (locus, mask) entries an unfinished read may carry into the next tile (1.5 slots each <= CPAD)
+constexpr int TSLOTS = CPAD + WT + (WT >> SLOT_SHIFT);   // LDS table slots per wave tile
+static_assert(CMAX + (CMAX >> SLOT_SHIFT) <= CPAD && (TSLOTS * 8) % (16 * 64) == 0, "carry pad / clear loop");
 constexpr u32 SBITS = (TSLOTS <= 1024) ? 10 : 11;   // bits of a table-slot index
 constexpr u32 SMASK = (1u << SBITS) - 1u;
 struct alignas(16) WaveLds {
-    u32 tkey[TSLOTS];                // per-read {locus -> mask} tables, 1.5 slots per record of the read; key = locus + 1
+    // per-read {locus -> mask} tables, 1.5 slots per record of the read: key = locus + 1, mask = OR of haplotype bits.  Two
+    // arrays, not one of pairs: at an 8-byte stride the compare-and-swaps of a wave land on the even banks only.
+#ifdef ECB_TAB_INTERLEAVED
+    uint2 tab[TSLOTS];
+#else
+    u32 tkey[TSLOTS];
     u32 tmask[TSLOTS];               // (contiguous with tkey: cleared together with 16-byte stores)
+#endif
     u64 acc[WMAXR];                  // per read: set-hash sum
-    unsigned short ent[WT];          // table entries created in this tile: slot | read << 10 (SBITS = 10 at 8 records per lane)
+    uint2 carry[CMAX];               // the entries of the read that is still open at the end of a tile (x = locus + 1, y = mask)
+    unsigned short ent[WT + CMAX];   // table entries created in this pass: slot | read << 10 (SBITS = 10 at 8 records per lane)
     unsigned short npair[WMAXR];     // per read: number of (locus, mask) pairs
     u32 seg[WMAXR + 3];              // seg[rl + 1]: first table slot of read rl | end slot << 16; repacked for finished reads
-};
+    u32 ws[5];                       // wave scalars that are touched once in a while (scalar registers are scarcer than the few LDS reads):
+};                                   //   [0,1] head record of the open read   [2,3] key-arena reservation: next pair   [4] ... pairs left
+static_assert(sizeof(WaveLds) * NWAVE * ECB_WAVES_PER_SIMD <= 160 * 1024, "four workgroups per CU");
+__device__ __forceinline__ u64 ws_get64(const WaveLds& L, int i) {
+    const u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)L.ws[i]), hi = (u32)__builtin_amdgcn_readfirstlane((int)L.ws[i + 1]);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ void ws_put64(WaveLds& L, int i, u64 v, u32 lane) { if (lane == 0) { L.ws[i] = (u32)v; L.ws[i + 1] = (u32)(v >> 32); } }
+#ifdef ECB_TAB_INTERLEAVED
+__device__ __forceinline__ u32* tab_key(WaveLds& L, u32 q) { return &L.tab[q].x; }
+__device__ __forceinline__ u32* tab_mask(WaveLds& L, u32 q) { return &L.tab[q].y; }
+__device__ __forceinline__ uint2 tab_get(const WaveLds& L, u32 q) { return L.tab[q]; }
+__device__ __forceinline__ uint4* tab_base(WaveLds& L) { return reinterpret_cast<uint4*>(L.tab); }
+#else
+__device__ __forceinline__ u32* tab_key(WaveLds& L, u32 q) { return &L.tkey[q]; }
+__device__ __forceinline__ u32* tab_mask(WaveLds& L, u32 q) { return &L.tmask[q]; }
+__device__ __forceinline__ uint2 tab_get(const WaveLds& L, u32 q) { return make_uint2(L.tkey[q], L.tmask[q]); }
+__device__ __forceinline__ uint4* tab_base(WaveLds& L) { return reinterpret_cast<uint4*>(L.tkey); }
+#endif
 __device__ __forceinline__ u32 tslot(u32 rec) { return rec + (rec >> SLOT_SHIFT); }   // first table slot of a read starting at `rec`
 __device__ __forceinline__ u32 unslot(u32 t) {                                          // inverse, t < 1024
     if (SLOT_SHIFT == 1) { const u32 m = (t * 683u) >> 11; return 2u * m + (t - 3u * m); }
@@ -295,29 +352,49 @@ struct LdsSetCmp {
     const WaveLds* L;
     u32 s2, e2, pm, np;
     uint2* arena;
-    bool fresh;                      // arena pairs through read-modify-write atomics (table_settle) instead of write-through-coherent loads
-    __device__ __forceinline__ bool has(u32 locus, u32 mask) const {
-        const u32 key = locus + 1u;
-        u32 q = s2 + (key & pm);
-        for (u32 t = s2; t < e2; ++t) {                  // (bounded by the region: a read's table always has a free slot)
-            const u32 k = L->tkey[q];
-            if (k == key) return L->tmask[q] == mask;
-            if (k == 0u) return false;
-            if (++q == e2) q = s2;
-        }
-        return false;
-    }
-    __device__ __forceinline__ bool operator()(const SlotView& v) const {
-        if (v.n != np) return false;
-        bool same = true;
+    __device__ __forceinline__ int quick(const SlotView& v) const {
+        if (v.n != np) return CMP_DIFFERENT;
+        uint2 t[INL];                                    // the INL first probes are issued together: one LDS round trip for the lot
 #pragma unroll
-        for (u32 i = 0; i < INL; ++i) if (i < v.n) same &= has(v.p[i].x, v.p[i].y);
-        for (u32 i = INL; i < v.n && same; ++i) {
-            u64* src = reinterpret_cast<u64*>(arena + (u64)v.off + (i - INL));
-            const uint2 pr = unpack2(fresh ? fresh64(src) : __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            same &= has(pr.x, pr.y);
+        for (u32 i = 0; i < INL; ++i) t[i] = tab_get(*L, i < v.n ? s2 + ((v.p[i].x + 1u) & pm) : s2);
+        bool eq = true;
+#pragma unroll
+        for (u32 i = 0; i < INL; ++i) eq &= i >= v.n || (t[i].x == v.p[i].x + 1u && t[i].y == v.p[i].y);
+        if (eq && v.n <= INL) return CMP_EQUAL;          // (the common end: every stored pair sits where its locus probes first, same mask)
+        if (!eq) {                                       // rare: a mask not written yet, a locus that probed on, or another key altogether
+#pragma unroll
+            for (u32 i = 0; i < INL; ++i) if (i < v.n && v.p[i].y == 0u) return CMP_INCOMPLETE;
+#pragma unroll
+            for (u32 i = 0; i < INL; ++i)
+                if (i < v.n && (t[i].x == 0u || (t[i].x == v.p[i].x + 1u && t[i].y != v.p[i].y))) return CMP_DIFFERENT;   // certainly not in my set
+            return CMP_UNSURE;                           // another locus of mine sits at the first probe: full() walks on
         }
-        return same;
+        for (u32 i = INL; i < v.n; ++i) {                // the rest of a long key, from the arena
+            const uint2 pr = unpack2(__hip_atomic_load(reinterpret_cast<u64*>(arena + (u64)v.off + (i - INL)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (pr.y == 0u) return CMP_INCOMPLETE;
+            const uint2 tt = tab_get(*L, s2 + ((pr.x + 1u) & pm));
+            if (tt.x == pr.x + 1u && tt.y == pr.y) continue;
+            return (tt.x == 0u || tt.x == pr.x + 1u) ? CMP_DIFFERENT : CMP_UNSURE;
+        }
+        return CMP_EQUAL;
+    }
+    __device__ __forceinline__ int full(Slot* s, u32 n, u32 off) const {
+        if (n != np) return CMP_DIFFERENT;
+        for (u32 i = 0; i < n; ++i) {
+            const uint2 pr = key_pair_fresh(s, arena, off, i);
+            if (pr.y == 0u) return CMP_INCOMPLETE;
+            const u32 key = pr.x + 1u;
+            u32 q = s2 + (key & pm);
+            bool found = false;
+            for (u32 n = s2; n < e2; ++n) {              // (bounded by the region: a read's table always has a free slot)
+                const uint2 t = tab_get(*L, q);
+                if (t.x == key) { found = t.y == pr.y; break; }
+                if (t.x == 0u) break;
+                if (++q == e2) q = s2;
+            }
+            if (!found) return CMP_DIFFERENT;
+        }
+        return CMP_EQUAL;
     }
 };
 
@@ -330,31 +407,47 @@ struct LdsSetCmp {
 #endif
 
 __device__ __forceinline__ void load_tile(const StreamArgs& A, u64 tb, u64 te, u32 lane, TileRegs& R) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    tb = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(tb >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)tb);   // (wave-uniform: say so)
+    if (tb + (u64)WT <= te) {
+        // a whole tile: wave-uniform base (scalar registers) + 16 bytes per lane, the second group 4 KB on -- the address costs
+        // one shift per tile, not six 64-bit additions
+        // (non-temporal: the stream is read once; without the hint it pushes the EC table's lines out of L2 -- measured 3 %)
+        const char* pr = reinterpret_cast<const char*>(A.rid + tb);
+        const char* pl = reinterpret_cast<const char*>(A.loc + tb);
+        const char* ph = reinterpret_cast<const char*>(A.hf + tb);
+        const u32 off = lane * 16u;                      // (32 bits: the loads take it as an offset to the scalar base)
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const u64 i0 = tb + (u64)g * 256 + 4u * lane;
-        if (i0 + 4 <= te) {
-            // (non-temporal: the stream is read once; without the hint it pushes the EC table's lines out of L2 -- measured 3 %)
-            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-            u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(A.rid + i0));
+        for (int g = 0; g < NG; ++g) {
+            u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pr + (off + (u32)g * 1024u)));
             R.rr[4 * g] = v.x; R.rr[4 * g + 1] = v.y; R.rr[4 * g + 2] = v.z; R.rr[4 * g + 3] = v.w;
-            v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(A.loc + i0));
+            v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pl + (off + (u32)g * 1024u)));
             R.ll[4 * g] = v.x; R.ll[4 * g + 1] = v.y; R.ll[4 * g + 2] = v.z; R.ll[4 * g + 3] = v.w;
-            v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(A.hf + i0));
+            v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ph + (off + (u32)g * 1024u)));
             R.hh[4 * g] = v.x; R.hh[4 * g + 1] = v.y; R.hh[4 * g + 2] = v.z; R.hh[4 * g + 3] = v.w;
-        } else {
+        }
+        return;
+    }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool in = i0 + j < te;
-                R.rr[4 * g + j] = in ? A.rid[i0 + j] : 0u;
-                R.ll[4 * g + j] = in ? A.loc[i0 + j] : 0u;
-                R.hh[4 * g + j] = in ? A.hf[i0 + j] : 0x4u;
-            }
+    for (int g = 0; g < NG; ++g) {                      // the stream's last tile: record by record
+        const u64 i0 = tb + (u64)g * 256 + 4u * lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool in = i0 + j < te;
+            R.rr[4 * g + j] = A.rid[in ? i0 + j : te - 1];          // (past the end: the last read id again -- no step, no head)
+            R.ll[4 * g + j] = in ? A.loc[i0 + j] : 0u;
+            R.hh[4 * g + j] = in ? A.hf[i0 + j] : 0x4u;
         }
     }
 }
 
 // VERIFY = false: the hot kernel.  VERIFY = true: the exactness pass (same tiling, compares instead of inserting).
+//
+// A wave walks its slice in tiles of WT records that start at multiples of WT: every record is loaded exactly once (plus
+// the tail a slice's last read hangs into the next slice).  The read that is still open at the end of a tile is not read
+// again: its {locus -> mask} entries so far (a few) are carried into the next tile, where they are put into that read's
+// table before the tile's own records.  A read that would carry more than CMAX entries goes to k_slow.  A tile with more
+// than WMAXR reads (short reads) is worked off in passes of WMAXR reads; every further pass loads the tile again.
 template <bool VERIFY>
 __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A) {
     __shared__ WaveLds wl[NWAVE];
@@ -364,343 +457,491 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
     // unclaimed slice of the stream when it has finished one.  (Slices bound to workgroups at launch left a SIMD slot
     // idle until the slowest of a workgroup's four waves was done, and the last round ragged: a fifth of the kernel.)
     const u64 pw = (u64)blockIdx.x * NWAVE + w;   // this wave
-    u32 my_all = 0, my_valid = 0, my_new = 0;     // per lane; a wave sees far fewer than 2^32 records
+    u32 s_all = 0, my_valid = 0, my_new = 0;      // wave total / per lane; a wave sees far fewer than 2^32 records
     u32 bad = 0;
     // this wave's current reservation in the key arena: what the last launch left of it is used first (a stream pushed in
     // many small batches would otherwise leave the tail of a 512-pair chunk behind per wave and launch)
-    u64 chunk_at = VERIFY ? 0ull : A.wave_arena[2 * pw];
-    u32 chunk_left = VERIFY ? 0u : (u32)A.wave_arena[2 * pw + 1];
+    if (!VERIFY && lane == 0) { const u64 ca = A.wave_arena[2 * pw]; L.ws[2] = (u32)ca; L.ws[3] = (u32)(ca >> 32); L.ws[4] = (u32)A.wave_arena[2 * pw + 1]; }
 #ifdef ECB_TIMING
     u64 tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
 #endif
   for (;;) {
-    u64 wid = 0;                                  // the slice
-    if (lane == 0) wid = atomicAdd(&A.ctr->next_slice, 1ull);
-    wid = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(wid >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)wid);
-    const u64 c0 = wid * A.chunk;
+    u32 wid = 0;                                  // the slice (fewer than 2^32 of them: a slice is at least a tile)
+    if (lane == 0) wid = (u32)atomicAdd(&A.ctr->next_slice, 1ull);
+    wid = (u32)__builtin_amdgcn_readfirstlane((int)wid);
+    const u64 c0 = (u64)wid * A.chunk;            // (a multiple of WT)
     if (c0 >= A.n) break;
     const u64 c1 = min(c0 + A.chunk, A.n);
-    u64 p = A.resume[2 * wid], counted = A.resume[2 * wid + 1];
-    if (p >= c1) continue;                        // finished before a relaunch
-
-    u32 base = (p == 0 ? A.prev_rid : A.rid[p - 1]) + 1u;     // read index of the first head >= p
+    // resume point: the first record not yet consumed by a finished read (a fresh slice: c0; after a park: the head of the
+    // read that was open, or the tile that was next), and how far the slice's records have been counted
+    const u64 p = A.resume[2 * (u64)wid], counted0 = A.resume[2 * (u64)wid + 1];
+    if (p >= A.n || p == ~0ull) continue;         // finished before a relaunch
+    u64 t0 = p & ~(u64)(WT - 1);                  // tile start
+    int p_rel = (int)(p - t0);                    // (only matters in the first tile after a park)
+    // read index of the first head at or after p; records before it that are not heads belong to the read before
+    u32 base = (p == 0 ? A.prev_rid : A.rid[p - 1]) + 1u;
+    bool open = false;                            // a read of mine is still open at the start of the tile (its index is `base`)
+                                                  // (the record index of its head: L.ws[0..1])
+    u32 carry_n = 0;                              // its entries so far, in L.carry
     TileRegs R;
-    load_tile(A, p & ~(u64)3, min((p & ~(u64)3) + (u64)WT, A.n), lane, R);
+    load_tile(A, t0, min(t0 + (u64)WT, A.n), lane, R);
     u32 parked = __hip_atomic_load(&A.ctr->full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("" : "+v"(parked));          // (settled before the loop: otherwise the loop header carries an s_waitcnt vmcnt(0) that every tile pays)
+    bool slice_done = false;
+    u32 r_lo = 0;                                 // first read of the tile this pass works on (tiles of short reads take several passes)
 
-    while (p < c1) {
+    while (!slice_done) {
         if (parked) break;            // the EC table filled up somewhere: the host grows it and relaunches
-        p = ((u64)(u32)__builtin_amdgcn_readfirstlane((u32)(p >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((u32)p);   // (the builtin returns int: no sign extension)
+        // (opaque per tile: the LDS addresses and constants derived from the lane index are cheap to recompute; hoisted out of
+        //  the loop they sat in registers the tile needs, and what did not fit was spilled and re-loaded BEHIND the prefetch)
+        u32 ln = lane;
+        asm volatile("" : "+v"(ln));
+        r_lo = (u32)__builtin_amdgcn_readfirstlane((int)r_lo);
+        t0 = ((u64)(u32)__builtin_amdgcn_readfirstlane((u32)(t0 >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((u32)t0);   // (the builtin returns int: no sign extension)
         base = (u32)__builtin_amdgcn_readfirstlane(base);
-        const u64 tb = p & ~(u64)3;
-        const u64 te = min(tb + (u64)WT, A.n);
+        const u64 te = min(t0 + (u64)WT, A.n);
+        const bool own = t0 < c1;                 // heads in this tile start reads of my slice (tiles do not straddle c1)
         // tile-relative bounds (all below 2^31)
-        const int p_rel = (int)(p - tb), te_rel = (int)(te - tb);
-        const int c1_rel = (int)min(c1 - tb, (u64)WT), cnt_lo = (int)(max(counted, tb) - tb), cnt_hi = min(te_rel, c1_rel);
-        // clear this wave's per-tile LDS state
-        {
-            uint4* z = reinterpret_cast<uint4*>(L.tkey);      // tkey and tmask are contiguous
-#pragma unroll
-            for (int t = 0; t < (2 * TSLOTS) / (4 * 64); ++t) z[t * 64 + lane] = make_uint4(0, 0, 0, 0);
-            L.acc[lane] = 0; L.npair[lane] = 0;
-        }
+        const int te_rel = (int)(te - t0);
+        // records offered / valid are counted tile by tile: every tile of my slice once (after a park the tiles before the
+        // one that was next have been counted: `counted0` is a tile boundary)
+        const bool count_tile = own && t0 >= counted0 && r_lo == 0u;
+        const bool plain = p_rel == 0 && te_rel == WT;      // a whole tile, nothing masked: all but the first after a park / the last of the stream
         // ---- (a) filter, heads -------------------------------------------------------------------
-        // Written with integer bit arithmetic throughout: every instruction costs a 4-cycle issue slot, and
+        // Written with integer bit arithmetic throughout: every instruction costs an issue slot, and
         // compare -> mask -> select chains were a third of this kernel's instruction count.
-        u32 r_key[RPL], r_bit[RPL], r_rl[RPL];    // locus + 1, haplotype bit, read index within the tile
-        u32 m_ok = 0, m_head = 0, m_own = 0;       // bit k: valid & in range / head / head of a read we own
+        // locus + 1; read index within the tile (10 bits, 1023 = before the tile's first read) | haplotype index << 10 -- one
+        // register for the two: phase (b) holds nine compare-and-swap results on top of these
+        u32 r_key[RPL], r_rh[RPL];
+        u32 m_ok = 0, m_head = 0;                  // bit k: valid & in range / head
         {
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                const int i0 = g * 256 + 4 * (int)lane;
-                // the record before this group's first: the previous lane's last record of the group, or (lane 0) the
+                const int i0 = g * 256 + 4 * (int)ln;
+                // the record before this group's first: the previous ln's last record of the group, or (ln 0) the
                 // previous group's very last record
                 const u32 up = lane_above(R.rr[4 * g + 3]);
-                const u32 wrap = g == 0 ? base - 1u : (u32)__builtin_amdgcn_readlane((int)R.rr[4 * (g > 0 ? g - 1 : 0) + 3], 63);
-                const u32 lo_in = (1u << clamp04(p_rel - i0, 0, 4)) - 1u;        // records before p
-                const u32 in4 = ((1u << clamp04(te_rel - i0, 0, 4)) - 1u) & ~lo_in;
-                const u32 own4 = ((1u << clamp04(c1_rel - i0, 0, 4)) - 1u) & ~lo_in;
-                const u32 cnt4 = ((1u << clamp04(cnt_hi - i0, 0, 4)) - 1u) &
-                                 ~((1u << clamp04(cnt_lo - i0, 0, 4)) - 1u);
-                u32 prev = lane == 0 ? wrap : up;
-                u32 ok4 = 0, head4 = 0, big4 = 0, hap_or = 0;
+                const u32 wrap = g == 0 ? base - 1u + (open ? 1u : 0u) : (u32)__builtin_amdgcn_readlane((int)R.rr[4 * (g > 0 ? g - 1 : 0) + 3], 63);
+                u32 in4 = 0xFu, te4 = 0xFu;                                      // records of the tile / at or after p
+                if (!plain) {
+                    te4 = (1u << clamp04(te_rel - i0, 0, 4)) - 1u;
+                    in4 = te4 & ~((1u << clamp04(p_rel - i0, 0, 4)) - 1u);
+                }
+                const u32 prev0 = ln == 0 ? wrap : up;
+                u32 ok4 = 0, head4 = 0, hap_or = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int k = 4 * g + j;
-                    const u32 f = R.hh[k], nf = ~f;
+                    const u32 f = R.hh[4 * g + j], nf = ~f;
                     // record filter (bam_utils.py:264-270): not unmapped, and if paired: read1, proper, mate on the same
                     // reference, next_pos >= 0  <=>  ((f ^ 2) & 0x3082) == 0
                     const u32 pair_ok = ((((f ^ 0x2u) & 0x3082u) - 1u) >> 31);
-                    const u32 ok = (nf >> 2) & (nf | pair_ok) & 1u;
-                    const u32 step = R.rr[k] - prev;
-                    prev = R.rr[k];
-                    r_rl[k] = R.rr[k] - base;
-                    r_key[k] = R.ll[k] + 1u;
-                    r_bit[k] = 1u << ((f >> ECB_HAP_SHIFT) & 31u);
-                    hap_or |= (f >> ECB_HAP_SHIFT) & (0u - ok);       // a haplotype index of 32 or more would alias a low bit above
-                    ok4 |= ok << j;
-                    head4 |= (step & 1u) << j;
-                    big4 |= min(step >> 1, 1u) << j;                 // the run counter may only step by 0 or 1
+                    ok4 |= ((nf >> 2) & (nf | pair_ok) & 1u) << j;
                 }
+                // The rest is per record position, and only for positions at which SOME lane holds a valid record: in a paired-end
+                // stream every second record is a mate the filter drops -- wave-uniform branches, two positions each.
+#pragma unroll
+                for (int par = 0; par < 2; ++par) {
+                    if (__ballot((ok4 & (par ? 0xAu : 0x5u)) != 0u) != 0ull) {
+#pragma unroll
+                        for (int j = par; j < 4; j += 2) {
+                            const int k = 4 * g + j;
+                            const u32 f = R.hh[k];
+                            const u32 step = R.rr[k] - (j == 0 ? prev0 : R.rr[k > 0 ? k - 1 : 0]);
+                            r_rh[k] = min(R.rr[k] - base, 1023u) | (((f >> ECB_HAP_SHIFT) & 31u) << 10);
+                            r_key[k] = R.ll[k] + 1u;
+                            hap_or |= f & (0u - ((ok4 >> j) & 1u));          // (a haplotype index of 32 or more would alias a low bit above)
+                            head4 |= (step & 1u) << j;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = par; j < 4; j += 2) { r_rh[4 * g + j] = 1023u; r_key[4 * g + j] = 0u; }
+                    }
+                }
+                // the run counter may only step by 0 or 1, and only on a valid record: then, and only then, the steps seen at the
+                // valid positions add up to the whole difference
+                const u32 big = (u32)(R.rr[4 * g + 3] - prev0 != (u32)__popc(head4));
+                if (count_tile) my_valid += __popc(ok4 & te4);
                 ok4 &= in4; head4 &= in4;
-                bad |= ((big4 & in4) | (head4 & ~ok4)) ? ERR_CONTRACT : 0u;   // ... and only on a valid record
-                bad |= (hap_or & ~31u) ? ERR_RANGE : 0u;                      // (indices below 32 are checked against n_haplotypes per EC, at emit)
-                my_all += __popc(cnt4); my_valid += __popc(cnt4 & ok4);
-                m_ok |= ok4 << (4 * g); m_head |= head4 << (4 * g); m_own |= (head4 & own4) << (4 * g);
+                bad |= ((p_rel == 0 ? big : 0u) | (head4 & ~ok4)) ? ERR_CONTRACT : 0u;   // (the tile a park resumes in was checked before the park)
+                bad |= (hap_or >> (ECB_HAP_SHIFT + 5)) ? ERR_RANGE : 0u;      // (indices below 32 are checked against n_haplotypes per EC, at emit)
+                m_ok |= ok4 << (4 * g); m_head |= head4 << (4 * g);
             }
         }
+        if (count_tile) s_all += (u32)te_rel;                      // records offered (bam_utils.py:261)
         TICK(0);
         if (__ballot(bad != 0u)) break;            // never index LDS with a broken run counter
-        const u32 sums = wave_sum(__popc(m_head) | (__popc(m_own) << 16));
-        const u32 nr = sums & 0xFFFFu, nown = sums >> 16;         // heads in [p, te) / in [p, c1): ours
-        {   // a head at record x starts its read and ends the one before it; stored as table-slot offsets
-            unsigned short* sh = reinterpret_cast<unsigned short*>(L.seg);
-#pragma unroll
-            for (int k = 0; k < RPL; ++k)
-                if ((m_head >> k & 1u) && r_rl[k] <= (u32)WMAXR) {
-                    // tslot(4*lane + c) = 6*lane + tslot(c) for even-multiple-of-4 offsets: one add per record
-                    const unsigned short x = (unsigned short)((4u + (4u >> SLOT_SHIFT)) * lane + tslot((k & 3) + (k >> 2) * 256));
-                    sh[2 * r_rl[k] + 2] = x;                           // start of read rl   (seg is indexed rl + 1)
-                    sh[2 * r_rl[k] + 1] = x;                           // end of read rl - 1 (lands in the unused seg[0] for rl = 0)
-                }
-            if (lane == 0 && nr <= (u32)WMAXR) {
-                const unsigned short x = (unsigned short)tslot((u32)te_rel);
-                sh[2 * nr + 1] = x;
-                sh[2 * nr + 2] = x;
-            }
-        }
-        wave_sync();
-        const bool last_complete = (te == A.n);                  // batches end on a read boundary
-        const u32 nrc = last_complete ? nr : (nr ? nr - 1u : 0u);
-        const u32 nproc = min(min(nrc, nown), (u32)WMAXR);
-        // Reads finished in this tile get their table geometry packed once: first slot (SBITS bits) | end slot (SBITS) | mask of
-        // the largest power of two within the range (10 bits).  Probing starts at first + (locus & mask): the loci of a read are
-        // mostly consecutive target ids, which low bits never collide on -- cheaper than a multiplicative hash and the
-        // collision path below becomes rare.
-        if (lane < nproc) {
-            const u32 sg = L.seg[lane + 1], s2 = sg & 0xFFFFu, e2 = sg >> 16;
-            L.seg[lane + 1] = s2 | (e2 << SBITS) | (min((1u << (31 - __clz((int)(e2 - s2)))) - 1u, 0x3FFu) << (2 * SBITS));
-        }
-        wave_sync();
-        const bool done = (te >= c1 && nown <= nproc);           // every read that starts in our slice
-        u64 p_next = te;
-        u32 base_next = base + nr;
-        bool giant = false;
-        if (!done && nproc < nr) {
-            // (readfirstlane: the value is wave-uniform; saying so keeps the tile addressing in scalar registers)
-            const u64 h = tb + unslot((u32)__builtin_amdgcn_readfirstlane(L.seg[nproc + 1]) & 0xFFFFu);   // first read not finished here
-            if (h == p) giant = true;                            // one read fills the whole tile: k_slow
-            else { p_next = h; base_next = base + nproc; }
-        }
-        if (done) p_next = c1;
+        const u32 nheads = wave_sum(__popc(m_head));
+        const u32 last_rid = (u32)__builtin_amdgcn_readlane((int)R.rr[RPL - 1], 63);   // (of a full tile; a short one ends the stream)
+        // reads with records in this tile: the open one (index 0) and one per head.  All but the last are complete here; the
+        // last one is too if the stream ends with the tile.  In a tile past my slice only the open read is mine, and it
+        // is complete as soon as a head shows up.
+        const u32 n_in = (open ? 1u : 0u) + nheads;
+        const bool ends = te == A.n;               // batches end on a read boundary
+        const u32 n_done = own ? (ends ? n_in : (n_in ? n_in - 1u : 0u)) : ((open && (nheads || ends)) ? 1u : 0u);
+        const u32 n_build = own ? n_in : (open ? 1u : 0u);     // reads whose tables are built: the unfinished one too (it is carried on)
+        const bool carry_out = own ? (!ends && n_in != 0u) : (open && !nheads && !ends);
+        const bool more = !ends && (t0 + (u64)WT < c1 || carry_out);
+        const bool again = r_lo + (u32)WMAXR < n_build;     // another pass over this tile follows
         TICK(1);
         // ---- prefetch the next tile while this one is hashed and looked up --------------------------
         TileRegs N;
         u32 parked_next = 0;
-        if (p_next < c1) {
-            load_tile(A, p_next & ~(u64)3, min((p_next & ~(u64)3) + (u64)WT, A.n), lane, N);
+        if (more || again) {
+            const u64 nt = again ? t0 : t0 + (u64)WT;
+            load_tile(A, nt, min(nt + (u64)WT, A.n), ln, N);
             parked_next = __hip_atomic_load(&A.ctr->full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (giant && lane == 0) {
-            const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
-            if (qi < A.queue_cap) A.queue[qi] = p; else atomicOr(&A.ctr->err, ERR_QUEUE);
-        }
+        bool taken = false;                        // N has been taken over into R
+        u32 new_carry = 0;
+        bool giant = false;
+        u32 last_pos = 0xFFFFFFFFu;                // tile-relative head of the tile's last read, if it started here (it may stay open)
 
-        // ---- (b) per-read {locus -> haplotype mask} tables in LDS ------------------------------------
-        // Staged so that the 8 records' LDS round trips overlap: segment reads, CAS on the locus, OR of the bit.
-        // A lane whose CAS created an entry queues it; every entry is hashed once when all masks are final.
-        TICK(2);
-        u32 n_ent = 0;
-        if (!(A.ablate & 1u)) {
-            u32 q[RPL], old[RPL], act = 0, coll = 0;
+        if (r_lo < n_build) {
+            const u32 nb = min(n_build - r_lo, (u32)WMAXR);            // tables built in this pass
+            const u32 nproc = r_lo < n_done ? min(n_done - r_lo, (u32)WMAXR) : 0u;   // reads finished in this pass (one ln each in (c))
+            // clear this wave's per-pass LDS state
+            {
+                uint4* z = tab_base(L);
+                u32 zz;
+                asm volatile("v_mov_b32 %0, 0" : "=v"(zz));          // (a zero the compiler cannot keep in four registers across the loop)
+                const uint4 zv = make_uint4(zz, zz, zz, zz);
 #pragma unroll
-            for (int k = 0; k < RPL; ++k) {
-                const u32 on = (m_ok >> k) & (u32)(r_rl[k] < nproc) & 1u;
-                act |= on << k;
-                const u32 sg = L.seg[on ? r_rl[k] + 1u : 0u];
-                q[k] = (sg & SMASK) + (r_key[k] & (sg >> (2 * SBITS)));
+                for (int t = 0; t < (TSLOTS * 8) / (16 * 64); ++t) z[t * 64 + ln] = zv;
+                *reinterpret_cast<uint2*>(&L.acc[ln]) = make_uint2(zz, zz); L.npair[ln] = (unsigned short)zz;
             }
-#pragma unroll
-            for (int k = 0; k < RPL; ++k)
-                if (act >> k & 1u) old[k] = atomicCAS(&L.tkey[q[k]], 0u, r_key[k]);
-#pragma unroll
-            for (int k = 0; k < RPL; ++k) {
-                const bool on = act >> k & 1u;
-                const bool made = on && old[k] == 0u;                // this lane created the (read, locus) entry
-                const bool hit = made || (on && old[k] == r_key[k]);
-                coll |= (u32)(on && !hit) << k;
-                if (hit) atomicOr(&L.tmask[q[k]], r_bit[k]);         // duplicate (read, target) records vanish here: bam_utils.py:322-325
-                const u64 mm = __ballot(made);
-                if (made) L.ent[n_ent + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u))] =
-                    (unsigned short)(q[k] | (r_rl[k] << SBITS));
-                n_ent += (u32)__popcll(mm);
-            }
-            if (__ballot(coll != 0u)) {                              // slot taken by another locus of the read: probe on (rare)
+            {   // a head at record x starts its read and ends the one before it; stored as table-slot offsets
+                unsigned short* sh = reinterpret_cast<unsigned short*>(L.seg);
+                u32 lx = (u32)CPAD + (4u + (4u >> SLOT_SHIFT)) * ln;
+                asm volatile("" : "+v"(lx));      // (opaque per pass: hoisted out of the loop, the eight sums below lived in registers and were spilled)
 #pragma unroll
                 for (int k = 0; k < RPL; ++k) {
-                    bool made = false;
-                    if (coll >> k & 1u) {
-                        const u32 sg = L.seg[r_rl[k] + 1u];
-                        const u32 s2 = sg & SMASK, e2 = (sg >> SBITS) & SMASK;
-                        u32 o;
-                        bool lapped = false, stuck = false;  // (a read's range always has a free slot: the second lap only keeps a
-                        do {                                 //  corrupted geometry from spinning a wave for ever)
-                            if (++q[k] == e2) { q[k] = s2; stuck = lapped; lapped = true; }
-                            o = atomicCAS(&L.tkey[q[k]], 0u, r_key[k]);
-                        } while (o != 0u && o != r_key[k] && !stuck);
-                        if (stuck) bad |= ERR_CONTRACT;
-                        made = (o == 0u);
-                        atomicOr(&L.tmask[q[k]], r_bit[k]);
+                    const u32 rel = (r_rh[k] & 1023u) - r_lo;
+                    if ((m_head >> k & 1u) && rel <= (u32)WMAXR) {
+                        // tslot(4*ln + c) = 6*ln + tslot(c) for even-multiple-of-4 offsets: one add per record
+                        const unsigned short x = (unsigned short)(lx + tslot((k & 3) + (k >> 2) * 256));
+                        sh[2 * rel + 2] = x;                           // start of read rel   (seg is indexed rel + 1)
+                        sh[2 * rel + 1] = x;                           // end of read rel - 1 (lands in the unused seg[0] for rel = 0)
                     }
-                    const u64 mm = __ballot(made);
-                    if (made) L.ent[n_ent + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u))] =
-                        (unsigned short)(q[k] | (r_rl[k] << SBITS));
-                    n_ent += (u32)__popcll(mm);
+                }
+                if (ln == 0) {
+                    if (open && r_lo == 0u) sh[2] = 0;                 // the open read's table starts with the pad its carried entries go to
+                    if (n_in - r_lo <= (u32)WMAXR) {                   // the tile's last read ends with the tile
+                        const unsigned short x = (unsigned short)((u32)CPAD + tslot((u32)te_rel));
+                        sh[2 * (n_in - r_lo) + 1] = x;
+                    }
                 }
             }
-        }
-        wave_sync();
-        TICK(3);
-        for (u32 e = lane; e < n_ent; e += 64) {
-            const u32 en = L.ent[e], qq = en & SMASK, rl = en >> SBITS;
-            atomicAdd(&L.acc[rl], pair_hash64(L.tkey[qq] - 1u, L.tmask[qq]));
-            atomicAdd(reinterpret_cast<u32*>(&L.npair[rl & ~1u]), (rl & 1u) ? 0x10000u : 1u);   // two 16-bit counters per word
-        }
-        wave_sync();
-
-        TICK(4);
-        // ---- (c) one lane per read: EC lookup with exact key compare; a new EC gets its key from the read's LDS table ---------
-        u64 j = 0;
-        u32 st = ST_NONE, probes = 0, np = 0;
-        u64 lo = 0;
-        const bool on = lane < nproc && !(A.ablate & 3u);
-        const u32 rd = base + lane;
-        LdsSetCmp cmp;
-        cmp.L = &L; cmp.arena = A.arena; cmp.fresh = false; cmp.s2 = cmp.e2 = cmp.pm = cmp.np = 0;
-        if (on) {
-            const u32 sg = L.seg[lane + 1];
-            cmp.s2 = sg & SMASK; cmp.e2 = (sg >> SBITS) & SMASK; cmp.pm = sg >> (2 * SBITS);
-            np = L.npair[lane];
-            cmp.np = np;
-            lo = finish_hash(L.acc[lane], np);
-            if ((u64)rd >= A.reads_hi) bad |= ERR_CONTRACT;          // the run counter ran past what this batch announced
-        }
-        if (on && !bad && VERIFY) {                                 // exactness pass: set of this read == key of its EC ?
-            const u32 sl = A.read_slot[rd];
-            bool same = false;
-            if (sl != PENDING) {
-                const uint4* q = reinterpret_cast<const uint4*>(A.table + sl);
-                const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
-                SlotView v;
-                v.n = a.z - 1u; v.off = a.w;
-                v.p[0] = make_uint2(b.z, b.w); v.p[1] = make_uint2(c.x, c.y); v.p[2] = make_uint2(c.z, c.w);
-                v.p[3] = make_uint2(d.x, d.y); v.p[4] = make_uint2(d.z, d.w);
-                same = a.z != 0u && a.z != DEAD_KEY && cmp(v);
+            wave_sync();
+            // Every read of the pass gets its table geometry packed once: first slot (SBITS bits) | end slot (SBITS) | mask of
+            // the largest power of two within the range (10 bits).  Probing starts at first + (locus & mask): the loci of a read are
+            // mostly consecutive target ids, which low bits never collide on -- cheaper than a multiplicative hash and the
+            // collision path below becomes rare.
+            u32 my_start = 0;
+            if (ln < nb) {
+                const u32 sg = L.seg[ln + 1], s2 = sg & 0xFFFFu, e2 = sg >> 16;
+                my_start = s2;
+                L.seg[ln + 1] = s2 | (e2 << SBITS) | (min((1u << (31 - __clz((int)(e2 - s2)))) - 1u, 0x3FFu) << (2 * SBITS));
             }
-            if (!same) my_new += 1;                                 // (counted as "mismatches" in verify mode)
-        }
-        else if (on && !bad) {
-            j = lo & A.cap_mask;
-            if (A.ablate & 4u) st = ST_HIT;
-            else st = table_lookup(A.table, A.cap_mask, lo, j, probes, cmp);
-        }
-        TICK(5);
-        // Take over the prefetched tile HERE, right behind the lookup's own wait and before this tile issues any store.
-        // vmcnt counts in order: wherever the compiler first touches these registers it waits for everything issued before
-        // that point, and at the end of the tile (where the moves sink to if left alone) or at the top of the next one
-        // (the parked flag) that meant sitting out the round trips of the founders' stores -- ~3000 clocks per tile on C3.
-        R = N; parked = parked_next;
+            if (r_lo + nb == n_build && n_build != 0u) {             // head of the tile's last read (kept if it stays open)
+                const u32 st_last = (u32)__builtin_amdgcn_readlane((int)my_start, (int)(nb - 1u));
+                if (!(open && n_in == 1u)) last_pos = unslot(st_last - (u32)CPAD);
+            }
+            wave_sync();
+
+            // ---- (b) per-read {locus -> haplotype mask} tables in LDS ------------------------------------
+            // Staged so that the 8 records' LDS round trips overlap: segment reads, CAS on the locus, OR of the bit.
+            // A ln whose CAS created an entry queues it; every entry is hashed once when all masks are final.
+            TICK(2);
+            u32 n_ent = 0;
+            const u32 rl_last = nb - 1u;                             // the pass's last read: if it stays open, its entries are kept
+            const bool keep = carry_out && r_lo + nb == n_build;
+            if (!(A.ablate & 1u)) {
+                // What the open read brought along goes in WITH the records, as one more compare-and-swap per lane in the same
+                // round (a chain of LDS round trips of its own cost a fifth of the tile): entry c of the carry list is lane c's
+                // ninth "record" -- its haplotype "bit" is the whole mask so far.  (More than 64 of them: a second such round.)
+                const bool cin = open && r_lo == 0u && carry_n != 0u;
+                u32 q[RPL + 1], old[RPL + 1], act = 0, coll = 0;
+                u32 c_key = 0, c_bit = 0;
+                if (cin && ln < carry_n) { const uint2 cv = L.carry[ln]; c_key = cv.x; c_bit = cv.y; act |= 1u << RPL; }
 #pragma unroll
-        for (int k = 0; k < RPL; ++k) {
-            asm volatile("" : "+v"(R.rr[k])); asm volatile("" : "+v"(R.ll[k])); asm volatile("" : "+v"(R.hh[k]));
-        }
-        asm volatile("" : "+v"(parked));
-        if (!VERIFY) {
-            // Founders publish their keys, THEN lanes whose slot was claimed but not (visibly) complete settle it -- the
-            // founder such a lane waits for may be a lane of this very wave.  One round in all but a handful of tiles.
-            for (u32 round = 0;; ++round) {
-                const u64 cmask = __ballot(st == ST_CREATED);
-                if (cmask) {
-                    const bool cr = st == ST_CREATED;
-                    const u32 want = cr && np > INL ? np - INL : 0u;    // pairs beyond the slot's own go to the key arena
-                    u32 off = 0;
-                    if (__ballot(want != 0u)) {
-                        const u32 incl = wave_incl_scan(want);
-                        const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
-                        if (total > chunk_left) {                       // reserve another stretch of the key arena
-                            const u32 take = max(total, ARENA_CHUNK);
-                            u64 at = 0;
-                            if (lane == 0) at = arena_alloc(A.ctr, A.arena_cap, take, (u32)pw);
-                            chunk_at = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(at >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)at);
-                            chunk_left = take;
-                            if (chunk_at == ~0ull) { bad |= ERR_ARENA; chunk_left = 0; }
-                        }
-                        if (!(bad & ERR_ARENA)) {
-                            off = (u32)(chunk_at + (incl - want));       // the arena holds < 2^32 pairs (Slot::off)
-                            chunk_at += total; chunk_left -= total;
-                        }
-                    }
-                    const bool dead = (bad & ERR_ARENA) != 0u;           // no room for a long key: the run fails; the slots are marked, not left claimed
-                    // The keys are copied by the whole wave from the tile's entry queue (every (read, locus) entry once, any
-                    // order: rows are sorted when they are emitted), not by the founding lane walking its read's table:
-                    // that serial walk with 1-3 lanes alive was ~400 issue slots per tile, a quarter of the kernel.
-                    const u32 j32 = (u32)j;
-                    if (!dead) for (u32 e0 = 0; e0 < n_ent; e0 += 64) {
-                        const u32 e = e0 + lane;
-                        const u32 en = e < n_ent ? L.ent[e] : 0u, qq = en & SMASK, rl = en >> SBITS;
-                        const u32 o = __shfl(off, rl), jj = __shfl(j32, rl);            // (all lanes: the loop bound is uniform)
-                        if (e < n_ent && (cmask >> rl & 1ull)) {
-                            const u32 was = atomicSub(reinterpret_cast<u32*>(&L.npair[rl & ~1u]), (rl & 1u) ? 0x10000u : 1u);
-                            const u32 pos = ((rl & 1u) ? was >> 16 : was & 0xFFFFu) - 1u;   // a place of its own among the read's pairs
-                            uint2* dst = pos < INL ? &A.table[jj].pair[pos] : A.arena + ((u64)o + (pos - INL));
-                            store_wt64(reinterpret_cast<u64*>(dst), pack2(make_uint2(L.tkey[qq] - 1u, L.tmask[qq])));
-                        }
-                    }
-                    if (cr) store_wt32(&A.table[j].off, off);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every pair is in memory before any n1 says so
-                    if (cr) { store_wt32(&A.table[j].n1, dead ? DEAD_KEY : np + 1u); st = ST_HIT; }
-                    my_new += (u32)__popcll(cmask);
+                for (int k = 0; k < RPL; ++k) {
+                    const u32 rel = (r_rh[k] & 1023u) - r_lo;
+                    act |= ((m_ok >> k) & (u32)(rel < nb) & 1u) << k;
                 }
-                if (!__ballot(st == ST_PENDING)) break;
-                if (round >= 64u) { if (st == ST_PENDING) { bad |= ERR_INTERNAL; st = ST_NONE; } break; }
-                if (st == ST_PENDING) {
-                    LdsSetCmp fc = cmp;
-                    fc.fresh = true;
-                    const int r = table_settle(A.table + j, fc);
-                    if (r == ST_HIT) st = ST_HIT;
-                    else if (r == ST_STUCK) { bad |= ERR_INTERNAL; st = ST_NONE; atomicExch(&A.ctr->full, 1u); }   // (every wave stops at its next tile)
-                    else { j = (j + 1) & A.cap_mask; ++probes; st = table_lookup(A.table, A.cap_mask, lo, j, probes, cmp); }
+                // Two rounds: the even record positions (and the carried entry), then the odd ones -- nine compare-and-swap
+                // results in flight at once are more registers than the kernel has, and in a paired-end stream the odd (or the
+                // even) positions are the mate records, which the filter drops: a round no lane has a record in is skipped.
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const u32 hmask = h ? 0x0AAu : 0x155u;           // positions of this round (bit RPL: the carried entry)
+                    if (__ballot((act & hmask) != 0u) == 0ull) continue;
+#pragma unroll
+                    for (int k = h; k <= RPL; k += 2)
+                        q[k] = L.seg[k < RPL ? ((act >> k & 1u) ? (r_rh[k < RPL ? k : 0] & 1023u) - r_lo + 1u : 0u) : 1u];
+#pragma unroll
+                    for (int k = h; k <= RPL; k += 2) {  // (all geometry reads are in flight before the first is used, and none hides in a lane branch)
+                        asm volatile("" : "+v"(q[k]));
+                        const u32 sg = q[k];
+                        q[k] = (act >> k & 1u) ? (sg & SMASK) + ((k < RPL ? r_key[k < RPL ? k : 0] : c_key) & (sg >> (2 * SBITS))) : ln;
+                    }
+#pragma unroll
+                    for (int k = h; k <= RPL; k += 2)    // (lanes without a record here swap nothing: they expect a value no slot ever holds, at a slot of their own)
+                        old[k] = atomicCAS(tab_key(L, q[k]), (act >> k & 1u) ? 0u : 0xFFFFFFFFu, k < RPL ? r_key[k < RPL ? k : 0] : c_key);
+#pragma unroll
+                    for (int k = h; k <= RPL; k += 2) {
+                        const u32 key = k < RPL ? r_key[k < RPL ? k : 0] : c_key, bit = k < RPL ? 1u << (r_rh[k < RPL ? k : 0] >> 10) : c_bit;
+                        const u32 rel = k < RPL ? (r_rh[k < RPL ? k : 0] & 1023u) - r_lo : 0u;
+                        const bool on = act >> k & 1u;
+                        const bool made = on && old[k] == 0u;                // this lane created the (read, locus) entry
+                        const bool hit = made || (on && old[k] == key);
+                        coll |= (u32)(on && !hit) << k;
+                        atomicOr(tab_mask(L, q[k]), hit ? bit : 0u);         // duplicate (read, target) records vanish here: bam_utils.py:322-325
+                        const u64 mm = __ballot(made);
+                        if (made) L.ent[n_ent + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u))] =
+                            (unsigned short)(q[k] | (rel << SBITS));
+                        n_ent += (u32)__popcll(mm);
+                    }
+                }
+                if (__ballot(coll != 0u) || (cin && carry_n > 64u)) {    // slot taken by another locus of the read: probe on (rare)
+#pragma unroll
+                    for (int k = 0; k <= RPL; ++k) {
+                        const u32 key = k < RPL ? r_key[k] : c_key, bit = k < RPL ? 1u << (r_rh[k < RPL ? k : 0] >> 10) : c_bit;
+                        const u32 rel = k < RPL ? (r_rh[k < RPL ? k : 0] & 1023u) - r_lo : 0u;
+                        const bool go = coll >> k & 1u;
+                        bool made = false;
+                        if (go) {
+                            const u32 sg = L.seg[rel + 1u];
+                            const u32 s2 = sg & SMASK, e2 = (sg >> SBITS) & SMASK;
+                            u32 o;
+                            bool lapped = false, stuck = false;  // (a read's range always has a free slot: the second lap only keeps a
+                            do {                                 //  corrupted geometry from spinning a wave for ever)
+                                if (++q[k] >= e2) { q[k] = s2; stuck = lapped; lapped = true; }
+                                o = atomicCAS(tab_key(L, q[k]), 0u, key);
+                            } while (o != 0u && o != key && !stuck);
+                            if (stuck) bad |= ERR_CONTRACT;
+                            made = (o == 0u);
+                            atomicOr(tab_mask(L, q[k]), bit);
+                        }
+                        const u64 mm = __ballot(made);
+                        if (made) L.ent[n_ent + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u))] =
+                            (unsigned short)(q[k] | (rel << SBITS));
+                        n_ent += (u32)__popcll(mm);
+                    }
+                    if (cin && carry_n > 64u) {                          // carried entries 64 .. CMAX - 1: a (rare) round of their own
+                        const bool go = ln + 64u < carry_n;
+                        const uint2 cv = L.carry[go ? ln + 64u : 0u];
+                        const u32 sg = L.seg[1], s2 = sg & SMASK, e2 = (sg >> SBITS) & SMASK;
+                        u32 qq = s2 + (cv.x & (sg >> (2 * SBITS)));
+                        bool made = false;
+                        if (go) {
+                            u32 o = atomicCAS(tab_key(L, qq), 0u, cv.x);
+                            bool lapped = false, stuck = false;
+                            while (o != 0u && o != cv.x && !stuck) {
+                                if (++qq >= e2) { qq = s2; stuck = lapped; lapped = true; }
+                                o = atomicCAS(tab_key(L, qq), 0u, cv.x);
+                            }
+                            if (stuck) bad |= ERR_CONTRACT;
+                            made = (o == 0u);
+                            atomicOr(tab_mask(L, qq), cv.y);
+                        }
+                        const u64 mm = __ballot(made);
+                        if (made) L.ent[n_ent + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u))] = (unsigned short)qq;
+                        n_ent += (u32)__popcll(mm);
+                    }
                 }
             }
-            if (st == ST_FULL) {                                    // table too full here: defer the read, park
-                atomicExch(&A.ctr->full, 1u);
-                const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
-                if (qi < A.queue_cap) A.queue[qi] = tb + unslot(L.seg[lane + 1] & SMASK); else atomicOr(&A.ctr->err, ERR_QUEUE);
-            } else if (st == ST_HIT) {
-                A.read_slot[rd] = (u32)j;
+            wave_sync();
+            TICK(3);
+            // every entry is hashed once, now that its mask is final; the entries of a read that stays open are not: they go to
+            // the carry list instead (same pass over the queue, no LDS round trips of their own)
+            u32 cn = 0;
+            for (u32 e0 = 0; e0 < n_ent; e0 += 64) {
+                const u32 e = e0 + ln;
+                const bool have = e < n_ent;
+                const u32 en = have ? L.ent[e] : 0u, qq = en & SMASK, rl = en >> SBITS;
+                const uint2 en2 = tab_get(L, qq);
+                const bool kept = have && keep && rl == rl_last;
+                if (have && !kept) {
+                    atomicAdd(&L.acc[rl], pair_hash64(en2.x - 1u, en2.y));
+                    atomicAdd(reinterpret_cast<u32*>(&L.npair[rl & ~1u]), (rl & 1u) ? 0x10000u : 1u);   // two 16-bit counters per word
+                }
+                if (keep) {
+                    const u64 mm = __ballot(kept);
+                    const u32 at = cn + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u));
+                    if (kept && at < (u32)CMAX) L.carry[at] = en2;
+                    cn += (u32)__popcll(mm);
+                }
             }
-        }
-        wave_sync();
+            if (keep) { new_carry = cn; giant = cn > (u32)CMAX; }
+            wave_sync();
 
-        TICK(6);
-        counted = max(counted, tb + (u64)cnt_hi);
-        p = p_next; base = base_next;
+            TICK(4);
+            // ---- (c) one ln per read: EC lookup with exact key compare; a new EC gets its key from the read's LDS table ---------
+            u64 j = 0;
+            u32 st = ST_NONE, probes = 0, np = 0;
+            u64 lo = 0;
+            const bool on = ln < nproc && !(A.ablate & 3u);
+            const u32 rd = base + r_lo + ln;
+            LdsSetCmp cmp;
+            cmp.L = &L; cmp.arena = A.arena; cmp.s2 = cmp.e2 = cmp.pm = cmp.np = 0;
+            if (on) {
+                const u32 sg = L.seg[ln + 1];
+                cmp.s2 = sg & SMASK; cmp.e2 = (sg >> SBITS) & SMASK; cmp.pm = sg >> (2 * SBITS);
+                np = L.npair[ln];
+                cmp.np = np;
+                lo = finish_hash(L.acc[ln], np);
+                j = lo & A.cap_mask;
+                if ((u64)rd >= A.reads_hi) bad |= ERR_CONTRACT;          // the run counter ran past what this batch announced
+                else st = ST_LOOK;
+            }
+            if (VERIFY) {                                               // exactness pass: set of this read == key of its EC ?
+                if (st == ST_LOOK) {
+                    const u32 sl = A.read_slot[rd];
+                    bool same = false;
+                    if (sl != PENDING) {
+                        const uint4* q = reinterpret_cast<const uint4*>(A.table + sl);
+                        const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+                        if (a.z != 0u && a.z != DEAD_KEY) {
+                            int r = cmp.quick(make_view(a, b, c, d));
+                            if (r == CMP_UNSURE) r = cmp.full(A.table + sl, a.z - 1u, a.w);
+                            same = r == CMP_EQUAL;
+                        }
+                    }
+                    if (!same) my_new += 1;                             // (counted as "mismatches" in verify mode)
+                }
+                R = N; parked = parked_next; taken = true;
+            } else {
+                // Lookup; founders publish their keys; THEN lanes whose slot was claimed but not (visibly) complete settle it --
+                // the founder such a ln waits for may be a ln of this very wave.  One round in all but a handful of tiles.
+                for (u32 round = 0;; ++round) {
+                    if (st == ST_LOOK) {
+                        if (A.ablate & 4u) st = ST_HIT;
+                        else st = table_lookup(A.table, A.cap_mask, lo, j, probes, cmp, A.ablate);
+                    }
+                    if (round == 0u) {
+                        TICK(5);
+                        // Take over the prefetched tile HERE, right behind the lookup's own wait and before this tile issues any store.
+                        // vmcnt counts in order: wherever the compiler first touches these registers it waits for everything issued before
+                        // that point, and at the end of the tile (where the moves sink to if left alone) or at the top of the next one
+                        // (the parked flag) that meant sitting out the round trips of the founders' stores -- ~3000 clocks per tile on C3.
+                        R = N; parked = parked_next; taken = true;
+#pragma unroll
+                        for (int k = 0; k < RPL; ++k) {
+                            asm volatile("" : "+v"(R.rr[k])); asm volatile("" : "+v"(R.ll[k])); asm volatile("" : "+v"(R.hh[k]));
+                        }
+                        asm volatile("" : "+v"(parked));
+                    }
+                    const u64 cmask = __ballot(st == ST_CREATED);
+                    if (cmask) {
+                        const bool cr = st == ST_CREATED;
+                        const u32 want = cr && np > INL ? np - INL : 0u;    // pairs beyond the slot's own go to the key arena
+                        u32 off = 0;
+                        if (__ballot(want != 0u)) {
+                            const u32 incl = wave_incl_scan(want);
+                            const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+                            u64 chunk_at = ws_get64(L, 2);
+                            u32 chunk_left = (u32)__builtin_amdgcn_readfirstlane((int)L.ws[4]);
+                            if (total > chunk_left) {                       // reserve another stretch of the key arena
+                                const u32 take = max(total, ARENA_CHUNK);
+                                u64 at = 0;
+                                if (ln == 0) at = arena_alloc(A.ctr, A.arena_cap, take, (u32)pw);
+                                chunk_at = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(at >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)at);
+                                chunk_left = take;
+                                if (chunk_at == ~0ull) { bad |= ERR_ARENA; chunk_left = 0; }
+                            }
+                            if (!(bad & ERR_ARENA)) {
+                                off = (u32)(chunk_at + (incl - want));       // the arena holds < 2^32 pairs (Slot::off)
+                                chunk_at += total; chunk_left -= total;
+                            }
+                            ws_put64(L, 2, chunk_at, ln);
+                            if (ln == 0) L.ws[4] = chunk_left;
+                        }
+                        const bool dead = (bad & ERR_ARENA) != 0u;           // no room for a long key: the run fails; the slots are marked, not left claimed
+                        // The keys are copied by the whole wave from the pass's entry queue (every (read, locus) entry once, any
+                        // order: rows are sorted when they are emitted), not by the founding ln walking its read's table:
+                        // that serial walk with 1-3 lanes alive was ~400 issue slots per tile, a quarter of the kernel.
+                        const u32 j32 = (u32)j;
+                        if (!dead) for (u32 e0 = 0; e0 < n_ent; e0 += 64) {
+                            const u32 e = e0 + ln;
+                            const u32 en = e < n_ent ? L.ent[e] : 0u, qq = en & SMASK, rl = en >> SBITS;
+                            const u32 o = __shfl(off, rl), jj = __shfl(j32, rl);            // (all lanes: the loop bound is uniform)
+                            if (e < n_ent && (cmask >> rl & 1ull) && !(A.ablate & 32u)) {    // (32: profiling, no key stores)
+                                const u32 was = atomicSub(reinterpret_cast<u32*>(&L.npair[rl & ~1u]), (rl & 1u) ? 0x10000u : 1u);
+                                const u32 pos = ((rl & 1u) ? was >> 16 : was & 0xFFFFu) - 1u;   // a place of its own among the read's pairs
+                                uint2* dst = pos < INL ? &A.table[jj].pair[pos] : A.arena + ((u64)o + (pos - INL));
+                                const uint2 en2 = tab_get(L, qq);
+                                store_wt64(reinterpret_cast<u64*>(dst), pack2(make_uint2(en2.x - 1u, en2.y)));
+                            }
+                        }
+                        if (cr) { publish_key(A.table + j, dead ? DEAD_KEY : np + 1u, off); st = ST_HIT; }   // (no wait: readers tell a whole key from its masks)
+                        my_new += (u32)__popcll(cmask);
+                    }
+                    if (!__ballot(st == ST_PENDING)) break;
+                    if (round >= 64u) { if (st == ST_PENDING) { bad |= ERR_INTERNAL; st = ST_NONE; } break; }
+                    if (st == ST_PENDING) {
+                        const int r = table_settle(A.table + j, cmp);
+                        if (r == ST_HIT) st = ST_HIT;
+                        else if (r == ST_STUCK) { bad |= ERR_INTERNAL; st = ST_NONE; atomicExch(&A.ctr->full, 1u); }   // (every wave stops at its next tile)
+                        else { j = (j + 1) & A.cap_mask; ++probes; st = ST_LOOK; }
+                    }
+                }
+                if (st == ST_FULL) {                                    // table too full here: defer the read, park
+                    atomicExch(&A.ctr->full, 1u);
+                    const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
+                    const u64 head = (open && r_lo == 0u && ln == 0u) ? ws_get64(L, 0) : t0 + unslot((L.seg[ln + 1] & SMASK) - (u32)CPAD);
+                    if (qi < A.queue_cap) A.queue[qi] = head; else atomicOr(&A.ctr->err, ERR_QUEUE);
+                } else if (st == ST_HIT) {
+                    A.read_slot[rd] = (u32)j;
+                }
+            }
+            wave_sync();
+            TICK(6);
+        }
+        if (!taken) {                                                // a tile without a read of mine (leading records of the slice)
+            R = N; parked = parked_next;
+#pragma unroll
+            for (int k = 0; k < RPL; ++k) {
+                asm volatile("" : "+v"(R.rr[k])); asm volatile("" : "+v"(R.ll[k])); asm volatile("" : "+v"(R.hh[k]));
+            }
+            asm volatile("" : "+v"(parked));
+        }
+        if (again) { r_lo += (u32)WMAXR; continue; }                 // same tile, next WMAXR reads (p_rel stays: the tile is loaded again)
+        r_lo = 0; p_rel = 0;
+        // state for the next tile
+        if (carry_out && !giant) {
+            if (last_pos != 0xFFFFFFFFu) ws_put64(L, 0, t0 + last_pos, ln);   // (else: the open read stays the open read)
+            open = true; carry_n = new_carry; base = last_rid;
+        } else {
+            if (carry_out && giant) {                                // more entries than a tile's pad takes: one workgroup for this read (k_slow)
+                const u64 head = last_pos != 0xFFFFFFFFu ? t0 + last_pos : ws_get64(L, 0);
+                if (ln == 0) {
+                    const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
+                    if (qi < A.queue_cap) A.queue[qi] = head; else atomicOr(&A.ctr->err, ERR_QUEUE);
+                }
+            }
+            open = false; carry_n = 0; base = last_rid + 1u;          // (the rest of a giant read is skipped: not a head, not open)
+        }
+        slice_done = !more;
+        t0 += (u64)WT;
     }
+    // where a relaunch takes this slice up: at the head of the read that is open, else at the tile that comes next
+    u64 p_out = open ? ws_get64(L, 0) : t0;
+    const u64 counted = max(counted0, min(r_lo ? t0 + (u64)WT : t0, c1));   // (every tile before t0 has been counted; t0 itself once its first pass is through)
     const bool stop = __ballot(bad != 0u) || parked;
-    if (__ballot(bad != 0u)) { if (bad) atomicOr(&A.ctr->err, bad); p = c1; }
-    if (lane == 0) { A.resume[2 * wid] = p; A.resume[2 * wid + 1] = counted; }
+    if (__ballot(bad != 0u)) { if (bad) atomicOr(&A.ctr->err, bad); p_out = ~0ull; }
+    else if (slice_done) p_out = ~0ull;
+    if (lane == 0) { A.resume[2 * (u64)wid] = p_out; A.resume[2 * (u64)wid + 1] = counted; }
     if (stop) break;
   }
     // records offered / valid: one atomic pair per wave
-    const u32 wa = wave_sum(my_all), wv = wave_sum(my_valid);
+    const u32 wa = s_all, wv = wave_sum(my_valid);
     // per-wave totals go to their own words: thousands of waves adding to three shared counters serialise (~50 ns each)
     const u32 wn = VERIFY ? wave_sum(my_new) : my_new;
 #ifdef ECB_TIMING
     if (lane == 0 && A.timing) for (int i = 0; i < 8; ++i) atomicAdd(A.timing + i, tacc[i]);
 #endif
     if (lane == 0) { A.wave_counts[3 * pw] = wa; A.wave_counts[3 * pw + 1] = wv; A.wave_counts[3 * pw + 2] = wn; }
-    if (!VERIFY && lane == 0) { A.wave_arena[2 * pw] = chunk_at; A.wave_arena[2 * pw + 1] = chunk_left; }
+    if (!VERIFY && lane == 0) { A.wave_arena[2 * pw] = ((u64)L.ws[3] << 32) | L.ws[2]; A.wave_arena[2 * pw + 1] = L.ws[4]; }
 }
 
 // resume points of a fresh batch: slice b starts (and has counted its records up to) record b * chunk
@@ -969,8 +1210,6 @@ struct SlowArgs {
 
 __device__ __forceinline__ u64 slow_probe_start(u32 lc, u64 cap2) { return __umul64hi((u64)(lc * 0x9E3779B1u) << 32, cap2); }
 
-struct NeverEqual { __device__ __forceinline__ bool operator()(const SlotView&) const { return false; } };   // k_slow compares as a workgroup, below
-
 __global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
     const u64 q = blockIdx.x;
     const u32 tid = threadIdx.x, lane = tid & 63u;
@@ -981,7 +1220,7 @@ __global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
     __shared__ u64 s_acc[TPB / 64];
     __shared__ u32 s_n[TPB / 64];
     __shared__ u64 s_lo, s_j;
-    __shared__ u32 s_np, s_st, s_n1, s_off, s_cnt, s_same, s_probes;
+    __shared__ u32 s_np, s_st, s_n1, s_off, s_cnt, s_diff, s_inc, s_probes;
 
     for (u64 i = tid; i < L; i += TPB) {
         const u32 f = A.hf[h + i];
@@ -1022,43 +1261,53 @@ __global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
     }
     __syncthreads();
     np = s_np;
-    // is the key of slot s_j (n = s_n1 - 1 pairs: INL in the slot, the rest at s_off in the arena) the set in the scratch table?
-    // Every thread takes pairs tid, tid + TPB, ...; fresh reads (the slot may have been published a moment ago by another CU).
-    auto same_key = [&]() -> bool {
-        const u32 n = s_n1 - 1u;
-        if (tid == 0) s_same = (n == np) ? 1u : 0u;
-        __syncthreads();
-        if (n == np) {
+    // Is the key of slot s_j the set in the scratch table?  Thread 0 polls the slot's {n1, off} word; every thread takes
+    // pairs tid, tid + TPB, ... with fresh reads (the slot may be in the middle of being published by another CU: a pair
+    // whose mask is still zero sends everybody round again).  CMP_EQUAL / CMP_DIFFERENT, or CMP_INCOMPLETE = gave up.
+    auto same_key = [&]() -> int {
+        for (u32 spin = 0; spin < SPIN_MAX; ++spin) {
+            __syncthreads();
+            if (tid == 0) {
+                const u64 w = fresh64(reinterpret_cast<u64*>(&A.table[s_j].n1));
+                s_n1 = (u32)w; s_off = (u32)(w >> 32); s_diff = 0; s_inc = 0;
+            }
+            __syncthreads();
+            const u32 n1 = s_n1;
+            if (n1 == DEAD_KEY) return CMP_DIFFERENT;
+            if (n1 == 0u) { __builtin_amdgcn_s_sleep(8); continue; }
+            const u32 n = n1 - 1u;
+            if (n != np) return CMP_DIFFERENT;
             Slot* sl = A.table + s_j;
-            bool ok = true;
-            for (u32 i = tid; i < n && ok; i += TPB) {
+            bool diff = false, inc = false;
+            for (u32 i = tid; i < n && !diff && !inc; i += TPB) {
                 u64* src = reinterpret_cast<u64*>(i < INL ? &sl->pair[i] : A.arena + ((u64)s_off + (i - INL)));
                 const uint2 pr = unpack2(fresh64(src));
-                ok = false;
+                if (pr.y == 0u) { inc = true; break; }
+                diff = true;
                 if (pr.x < A.n_loci) {
                     u64 p = slow_probe_start(pr.x, cap2);
                     for (u64 t = 0; t < cap2; ++t) {
                         const u32 k = __hip_atomic_load(&key[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (k == pr.x + 1u) { ok = __hip_atomic_load(&msk[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pr.y; break; }
+                        if (k == pr.x + 1u) { diff = __hip_atomic_load(&msk[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr.y; break; }
                         if (k == 0u) break;
                         if (++p == cap2) p = 0;
                     }
                 }
             }
-            if (!ok) atomicAnd(&s_same, 0u);
+            if (diff) atomicOr(&s_diff, 1u);
+            if (inc) atomicOr(&s_inc, 1u);
+            __syncthreads();
+            if (s_diff) return CMP_DIFFERENT;                     // (a complete pair that is not mine settles it, whatever is still missing)
+            if (!s_inc) return CMP_EQUAL;
+            __builtin_amdgcn_s_sleep(8);
         }
-        __syncthreads();
-        return s_same != 0u;
+        return CMP_INCOMPLETE;
     };
     if (A.verify) {
         if (s_st != ST_NONE) {
-            if (tid == 0) {
-                const u32 sl = A.read_slot[r0];
-                s_j = sl; s_n1 = sl == PENDING ? 0u : A.table[sl].n1; s_off = sl == PENDING ? 0u : A.table[sl].off;
-            }
+            if (tid == 0) s_j = A.read_slot[r0];
             __syncthreads();
-            bool same = false;
-            if (s_n1 != 0u && s_n1 != DEAD_KEY) same = same_key();
+            const bool same = s_j != (u64)PENDING && same_key() == CMP_EQUAL;
             if (tid == 0 && !same) atomicAdd(&A.ctr->n_mismatch, 1ull);
         }
     } else {
@@ -1067,16 +1316,10 @@ __global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
             __syncthreads();
             if (tid == 0) {
                 u64 j = s_j; u32 probes = s_probes;
-                int st = table_lookup(A.table, A.cap_mask, s_lo, j, probes, NeverEqual());   // ST_PENDING = "slot j carries my hash"
-                s_j = j; s_probes = probes; s_st = (u32)st; s_n1 = 0; s_off = 0;
-                if (st == ST_PENDING) {
-                    Slot* sl = A.table + j;
-                    u32 n1 = 0;
-                    for (u32 spin = 0; spin < SPIN_MAX && !n1; ++spin) { n1 = atomicOr(&sl->n1, 0u); if (!n1) __builtin_amdgcn_s_sleep(4); }
-                    s_n1 = n1;
-                    s_off = atomicOr(&sl->off, 0u);
-                    if (!n1) { atomicOr(&A.ctr->err, ERR_INTERNAL); s_st = ST_NONE; }
-                } else if (st == ST_CREATED) {
+                struct Defer { __device__ int quick(const SlotView&) const { return CMP_UNSURE; } };   // ST_PENDING = "slot j carries my hash": compared below
+                const int st = table_lookup(A.table, A.cap_mask, s_lo, j, probes, Defer());
+                s_j = j; s_probes = probes; s_st = (u32)st; s_off = 0; s_n1 = 0;
+                if (st == ST_CREATED) {
                     u64 off = 0;
                     if (np > INL) off = arena_alloc(A.ctr, A.arena_cap, np - INL, blockIdx.x);
                     atomicAdd(&A.ctr->n_ecs, 1ull);
@@ -1088,18 +1331,18 @@ __global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
             }
             __syncthreads();
             if (s_st == ST_PENDING) {
-                bool same = false;
-                if (s_n1 != DEAD_KEY) same = same_key();
+                const int r = same_key();
                 __syncthreads();
                 if (tid == 0) {
-                    if (same) { s_st = ST_HIT; A.read_slot[r0] = (u32)s_j; }
+                    if (r == CMP_EQUAL) { s_st = ST_HIT; A.read_slot[r0] = (u32)s_j; }
+                    else if (r == CMP_INCOMPLETE) { s_st = ST_NONE; atomicOr(&A.ctr->err, ERR_INTERNAL); }
                     else { s_j = (s_j + 1) & A.cap_mask; s_probes += 1; if (s_probes >= MAX_PROBE) { s_st = ST_FULL; A.requeue[atomicAdd(A.n_requeue, 1ull)] = h; } }
                 }
                 __syncthreads();
             }
         }
         __syncthreads();
-        if (s_st == ST_CREATED) {                           // publish: pairs (write-through) by everybody, then n1 by one
+        if (s_st == ST_CREATED) {                           // publish: pairs (write-through) by everybody, {n1, off} by one; no waiting
             Slot* sl = A.table + s_j;
             const bool dead = s_n1 == DEAD_KEY;
             if (!dead) for (u64 p = tid; p < cap2; p += TPB) {
@@ -1111,12 +1354,8 @@ __global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
                     store_wt64(reinterpret_cast<u64*>(dst), pack2(make_uint2(k - 1u, m)));
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
             if (tid == 0) {
-                store_wt32(&sl->off, s_off);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                store_wt32(&sl->n1, dead ? DEAD_KEY : np + 1u);
+                publish_key(sl, dead ? DEAD_KEY : np + 1u, s_off);
                 A.read_slot[r0] = (u32)s_j;
             }
         }
@@ -1318,25 +1557,27 @@ __global__ void k_adopt(const Entry* ent, u64 n, const uint2* pairs, Slot* table
 
 // The ordered merge of bam_utils.py:680-724, one thread per incoming EC: find its key in the table (exact compare) or
 // insert it; counts are added, first appearances minimised.
-struct ListCmp {                                   // incoming key = a sorted pair list; stored key = slot + arena
-    const uint2* inc; u32 n; uint2* arena; bool fresh;
-    __device__ __forceinline__ uint2 stored(const SlotView& v, u32 i) const {
-        if (i < INL) return v.p[i];
-        u64* src = reinterpret_cast<u64*>(arena + (u64)v.off + (i - INL));
-        return unpack2(fresh ? fresh64(src) : __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    }
-    __device__ __forceinline__ bool operator()(const SlotView& v) const {
-        if (v.n != n) return false;
-        bool same = true;                          // both sorted (keys that came from an export): element by element
-        for (u32 i = 0; i < n && same; ++i) { const uint2 a = stored(v, i), b = inc[i]; same = a.x == b.x && a.y == b.y; }
-        if (same) return true;
+struct ListCmp {                                   // incoming key = a sorted pair list; stored key = slot + arena, read fresh
+    const uint2* inc; u32 n; uint2* arena;
+    __device__ __forceinline__ int quick(const SlotView& v) const { return v.n != n ? CMP_DIFFERENT : CMP_UNSURE; }   // (keys are compared in full(): not a hot path)
+    __device__ __noinline__ int full(Slot* s, u32 sn, u32 off) const {
+        if (sn != n) return CMP_DIFFERENT;
+        bool same = true, inc_ = false;            // both sorted (keys that came from an export): element by element
+        for (u32 i = 0; i < n && same; ++i) {
+            const uint2 a = key_pair_fresh(s, arena, off, i), b = inc[i];
+            inc_ |= a.y == 0u;
+            same = a.x == b.x && a.y == b.y;
+        }
+        if (same) return CMP_EQUAL;
+        if (inc_) return CMP_INCOMPLETE;
         for (u32 i = 0; i < n; ++i) {              // the stored key may be one k_stream wrote, in no order: compare as sets
-            const uint2 a = stored(v, i);
+            const uint2 a = key_pair_fresh(s, arena, off, i);
+            if (a.y == 0u) return CMP_INCOMPLETE;
             bool found = false;
             for (u32 k = 0; k < n && !found; ++k) found = inc[k].x == a.x && inc[k].y == a.y;
-            if (!found) return false;
+            if (!found) return CMP_DIFFERENT;
         }
-        return true;
+        return CMP_EQUAL;
     }
 };
 constexpr u32 MERGE_PER_BLOCK = 16 * TPB;     // entries per workgroup (one EC-count atomic per workgroup, not per wave: ~18 ns each on one address)
@@ -1355,7 +1596,7 @@ __global__ __launch_bounds__(TPB) void k_merge(const Entry* ent, u64 n, const ui
         if (on) s = ent[e];
         const bool ok = on && (u64)s.off + s.n <= n_pairs && s.lo != 0ull;
         if (on && !ok) atomicOr(&ctr->err, ERR_CONTRACT);
-        ListCmp cmp{pairs + s.off, s.n, arena, false};
+        ListCmp cmp{pairs + s.off, s.n, arena};
         u64 j = s.lo & cap_mask;
         u32 probes = 0;
         int st = ST_NONE;
@@ -1378,24 +1619,19 @@ __global__ __launch_bounds__(TPB) void k_merge(const Entry* ent, u64 n, const ui
                 my_new += (u32)__popcll(cm);
                 if (cr) {
                     const bool dead = at == ~0ull;
-                    if (!dead) {
+                    if (!dead)
                         for (u32 t = 0; t < s.n; ++t) {
                             uint2* dst = t < INL ? &table[j].pair[t] : arena + (at + (t - INL));
                             store_wt64(reinterpret_cast<u64*>(dst), pack2(pairs[(u64)s.off + t]));
                         }
-                        store_wt32(&table[j].off, (u32)at);
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    store_wt32(&table[j].n1, dead ? DEAD_KEY : s.n + 1u);
+                    publish_key(table + j, dead ? DEAD_KEY : s.n + 1u, (u32)at);
                     st = ST_HIT; created = true;
                 }
             }
             if (!__ballot(st == ST_PENDING)) break;
             if (round >= 64u) { if (st == ST_PENDING) { atomicOr(&ctr->err, ERR_INTERNAL); st = ST_NONE; } break; }
             if (st == ST_PENDING) {
-                ListCmp fc = cmp;
-                fc.fresh = true;
-                const int r = table_settle(table + j, fc);
+                const int r = table_settle(table + j, cmp);
                 if (r == ST_HIT) st = ST_HIT;
                 else if (r == ST_STUCK) { atomicOr(&ctr->err, ERR_INTERNAL); st = ST_NONE; }
                 else { j = (j + 1) & cap_mask; ++probes; st = table_lookup(table, cap_mask, s.lo, j, probes, cmp); }
@@ -1886,13 +2122,14 @@ int plan_stream(ecb_handle* h, u64 n, StreamPlan* P) {
     waves = std::min<u64>(waves, (n + 2 * WT - 1) / (2 * WT));
     waves = std::max<u64>(waves, 1);
     u64 chunk = (n + waves - 1) / waves;
-    chunk = (chunk + 3) & ~(u64)3;
+    chunk = (chunk + WT - 1) / WT * WT;          // whole tiles: a tile never straddles two slices
     waves = (n + chunk - 1) / chunk;
     P->slices = waves; P->chunk = chunk;
     P->blocks = std::min<u64>((waves + NWAVE - 1) / NWAVE, resident_blocks);
     P->pwaves = P->blocks * NWAVE;               // waves of the launch
-    // a parked launch defers at most the reads of the tiles in flight
-    const u64 need_q = waves * (u64)(WMAXR + 1) + 16;
+    // deferred reads: a parked launch defers at most the reads of the tiles in flight (one tile per resident wave); a read
+    // with more than CMAX loci takes more than CMAX records
+    const u64 need_q = P->pwaves * (u64)(WT + 1) + n / CMAX + 16;
     if (h->queue_cap < need_q) {
         if (h->queue) hipFree(h->queue);
         h->queue = nullptr; h->queue_cap = 0;
@@ -2012,7 +2249,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     {
         u64 t[8];
         hipMemcpy(t, a.timing, sizeof(t), hipMemcpyDeviceToHost); hipFree(a.timing);
-        static const char* nm[8] = {"clear+filter+heads", "seg/geometry", "prefetch issue", "(b) LDS tables", "hash entries", "(c) lookup", "claim", "-"};
+        static const char* nm[8] = {"(a) filter+heads", "tile decisions", "prefetch issue+clear+geometry", "(b) LDS tables", "hash entries", "(c) lookup", "publish/settle/slot stores", "-"};
         u64 tot = 0; for (int i = 0; i < 7; ++i) tot += t[i];
         fprintf(stderr, "[ecb timing] %llu waves, clocks per wave:", (unsigned long long)waves);
         for (int i = 0; i < 7; ++i) fprintf(stderr, "  %s %.0f (%.1f%%)", nm[i], (double)t[i] / waves, 100.0 * t[i] / std::max<u64>(tot, 1));
