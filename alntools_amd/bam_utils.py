@@ -137,7 +137,7 @@ def convert(bam_filename, ec_filename, emase_filename, num_chunks=0, number_proc
             os.remove(emase_filename)
         except OSError:
             pass
-        emase_h5.save(emase_filename, m, title='bam2ec', incidence_only=True)     # bam_utils.py:861
+        emase_h5.save(emase_filename, m, title='bam2ec', incidence_only=True, count_2d=True)     # bam_utils.py:845, 861: count is a csc column
     if ec_filename:
         LOG.info("Saving to {}...".format(ec_filename))
         try:

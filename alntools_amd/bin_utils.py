@@ -110,18 +110,15 @@ def ecload(ec_filename):
     return ECMatrices(hname, lname, lengths, sname, A[0], A[1], A[2], N[0], N[1], N[2])
 
 
-def _need_hdf5():
-    raise RuntimeError("EMASE .h5 I/O needs PyTables or h5py, neither of which is installed here; "
-                       "the .bin (EC format 2) path is complete")
-
-
-def ec2emase(ec_file, emase_file):
-    """``.bin`` -> EMASE ``.h5`` (``bin_utils.py:979-995``)."""
+def ec2emase(ec_file, emase_file, **converters):
+    """``.bin`` -> EMASE ``.h5`` (``bin_utils.py:979-995``); the CSR -> per-haplotype CSC conversion runs on the GPU
+    (``emase_h5.device_hapcsc``; tests may pass ``hapcsc=`` their checker)."""
     from . import emase_h5
-    emase_h5.save(emase_file, ecload(ec_file), incidence_only=False)
+    emase_h5.save(emase_file, ecload(ec_file), title='Converted from {}'.format(ec_file), incidence_only=False, **converters)
 
 
-def emase2ec(emase_file, ec_file):
-    """EMASE ``.h5`` -> ``.bin`` (``bin_utils.py:998-1028``)."""
+def emase2ec(emase_file, ec_file, **converters):
+    """EMASE ``.h5`` -> ``.bin`` (``bin_utils.py:998-1028``); ``A = sum_h 2^h M_h`` is built on the GPU
+    (``emase_h5.device_csr``; tests may pass ``csr=`` their checker)."""
     from . import emase_h5
-    ecsave2(ec_file, emase_h5.load(emase_file))
+    ecsave2(ec_file, emase_h5.load(emase_file, **converters))

@@ -17,7 +17,8 @@ def _common(f):
     for opt in (click.option('-v', '--verbose', count=True, help='enables verbose mode'),
                 click.option('-t', '--targets', default=None, type=click.Path(exists=True, dir_okay=False), help='target file'),
                 click.option('--rangefile', default=None, type=click.Path(dir_okay=False), help='range file'),
-                click.option('-p', '--processes', default=-1, help='accepted for compatibility; ignored'),
+                click.option('-p', '--number-processes', '--processes', 'processes', default=-1,
+                             help='number of processes (accepted for compatibility: the work runs on the GPU)'),
                 click.option('--multisample', is_flag=True, help='BAM_FILE is a directory of per-sample BAM files'),
                 click.option('-m', '--mincount', default=None, type=int, help='minimum reads per cell (multisample)'),
                 click.option('-d', '--directory', default=None, type=click.Path(file_okay=False), help='accepted for compatibility; ignored'),
@@ -35,6 +36,9 @@ def bam2ec(bam_file, ec_file, chunks, directory, mincount, multisample, processe
     """Convert a BAM file (bam_file) to a binary file (ec_file)."""
     utils.configure_logging(verbose)
     if multisample:
+        if sample:                                                   # cli.py:60-63
+            print('-s, --sample should NOT be specified with --multisample')
+            return
         methods.bam2ec_multisample(bam_file, ec_file, chunks, 1000 if mincount is None else mincount, directory,
                                    processes, rangefile, targets)
     else:

@@ -33,11 +33,61 @@ def _backend():
     return "libhdf5"
 
 
-def save(h5file, m, title=None, incidence_only=True):
-    """Write :class:`alntools_amd.bin_utils.ECMatrices` ``m`` in the EMASE layout."""
+class _Csc(object):
+    """indptr / indices / data of one haplotype's E x T incidence matrix, as ``apm.data[h]`` holds them after ``finalize()``."""
+
+    def __init__(self, indptr, indices):
+        self.indptr, self.indices = indptr, indices
+        self.data = np.ones(len(indices), dtype=np.float64)
+
+
+def device_hapcsc(m):
+    """CSR(bitmask) A -> one CSC matrix per haplotype, on the GPU (``ecb_csr_to_hapcsc_device``: the sparse-format half of
+    ``bin_utils.ec2emase`` / ``Sparse3DMatrix.finalize``, ``bin_utils.py:979-995``, ``Sparse3DMatrix.py:189-193``).
+    No CPU path: without a GPU this raises, like the rest of the hot path."""
+    import torch
+    from . import ecb
+    if not torch.cuda.is_available():
+        raise RuntimeError("the CSR -> per-haplotype CSC conversion runs on the GPU (libecb); no HIP device is visible")
+    dev = torch.device("cuda", int(__import__("os").environ.get("ALNTOOLS_GPU", "0")))
+    ip, ix, da = (torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev) for a in (m.indptrA, m.indicesA, m.dataA))
+    cptr, cidx = ecb.csr_to_hapcsc(ip, ix, da, m.num_loci, m.num_haplotypes)
+    cptr, cidx = cptr.cpu().numpy(), cidx.cpu().numpy()
+    out, start = [], 0
+    for h in range(m.num_haplotypes):
+        n = int(cptr[h, -1])
+        out.append(_Csc(cptr[h], cidx[start:start + n]))
+        start += n
+    return out
+
+
+def device_csr(parts, n_ecs, n_loci):
+    """Per-haplotype CSC (indptr, indices) -> CSR(bitmask) A = sum_h 2^h M_h, on the GPU (``ecb_hapcsc_to_csr_device``:
+    ``bin_utils.emase2ec``, ``bin_utils.py:998-1028``)."""
+    import torch
+    from . import ecb
+    if not torch.cuda.is_available():
+        raise RuntimeError("the per-haplotype CSC -> CSR conversion runs on the GPU (libecb); no HIP device is visible")
+    dev = torch.device("cuda", int(__import__("os").environ.get("ALNTOOLS_GPU", "0")))
+    cptr = torch.from_numpy(np.stack([np.asarray(ip, dtype=np.int32) for ip, _ in parts])).to(dev)
+    cidx = torch.from_numpy(np.concatenate([np.asarray(ix, dtype=np.int32) for _, ix in parts])).to(dev)
+    ip, ix, da = ecb.hapcsc_to_csr(cptr, cidx, n_ecs)
+    return ip.cpu().numpy(), ix.cpu().numpy(), da.cpu().numpy()
+
+
+def save(h5file, m, title=None, incidence_only=True, count_2d=None, hapcsc=device_hapcsc):
+    """Write :class:`alntools_amd.bin_utils.ECMatrices` ``m`` in the EMASE layout.
+
+    ``count_2d``: ``/count`` as the group of a 2-D sparse matrix (uint32 indptr / indices / data) rather than a vector.
+    The reference writes the group whenever ``apm.count`` is 2-D -- always from ``bam2emase`` (``bam_utils.py:845``: a
+    ``csc_matrix`` column even for one sample) and for several samples -- and the float64 vector from ``ec2emase`` of a
+    one-sample ``.bin`` (``bin_utils.py:92-93`` flattens it).  Default: group iff more than one sample.
+    ``hapcsc``: the CSR -> per-haplotype CSC conversion; the device kernel unless a test passes its checker."""
     be = _backend()
     T, H, E = m.shape
-    mats = [m.haplotype_csc(h) for h in range(H)]
+    mats = hapcsc(m)
+    if count_2d is None:
+        count_2d = m.num_samples != 1
     if be == "tables":
         import tables
         fil = tables.Filters(complevel=1, complib='zlib')
@@ -52,7 +102,7 @@ def save(h5file, m, title=None, incidence_only=True):
                 if not incidence_only:
                     f.create_carray(g, 'data', obj=sp.data.astype(float), filters=fil)
             f.create_carray(f.root, 'lengths', obj=np.asarray(m.lengths), title='Transcript Lengths', filters=fil)
-            if m.num_samples == 1:
+            if not count_2d:
                 f.create_carray(f.root, 'count', obj=m.dataN.astype(np.float64), title='Equivalence Class Counts', filters=fil)
             else:
                 g = f.create_group(f.root, 'count', 'Sparse matrix components for N matrix')
@@ -78,7 +128,7 @@ def save(h5file, m, title=None, incidence_only=True):
                 if not incidence_only:
                     f.create_array('/h%d/data' % h, sp.data.astype(np.float64))
             f.create_array('/lengths', np.asarray(m.lengths))
-            if m.num_samples == 1:
+            if not count_2d:
                 f.create_array('/count', m.dataN.astype(np.float64))
             else:
                 f.create_group('/count')
@@ -102,7 +152,7 @@ def save(h5file, m, title=None, incidence_only=True):
             if not incidence_only:
                 g.create_dataset('data', data=sp.data.astype(float), compression='gzip', compression_opts=1)
         f.create_dataset('lengths', data=np.asarray(m.lengths))
-        if m.num_samples == 1:
+        if not count_2d:
             f.create_dataset('count', data=m.dataN.astype(np.float64))
         else:
             g = f.create_group('count')
@@ -115,9 +165,9 @@ def save(h5file, m, title=None, incidence_only=True):
         f.create_dataset('sname', data=np.array(m.sname, dtype='S'))
 
 
-def load(h5file):
-    """EMASE ``.h5`` -> :class:`ECMatrices` (the inverse of :func:`save`; ``A = sum_h 2^h * M_h``)."""
-    from scipy.sparse import csc_matrix
+def load(h5file, csr=device_csr):
+    """EMASE ``.h5`` -> :class:`ECMatrices` (the inverse of :func:`save`; ``A = sum_h 2^h * M_h``, on the GPU unless a
+    test passes its checker as ``csr``)."""
     from .bin_utils import ECMatrices
     be = _backend()
     if be == "tables":
@@ -161,11 +211,23 @@ def load(h5file):
                 N = (f['count/indptr'][()], f['count/indices'][()], f['count/data'][()])
             else:
                 N = (np.array([0, E]), np.arange(E), f['count'][()])
+    a_ptr, a_idx, a_dat = csr(parts, E, T)
+    return ECMatrices(hname, lname, lengths, sname, a_ptr, a_idx, np.asarray(a_dat).astype(np.int64),
+                      np.asarray(N[0]).astype(np.int64), np.asarray(N[1]).astype(np.int64), np.asarray(N[2]).astype(np.int64))
+
+
+def scipy_hapcsc(m):
+    """CHECKER for tests (scipy on the host): what :func:`device_hapcsc` must produce."""
+    return [m.haplotype_csc(h) for h in range(m.num_haplotypes)]
+
+
+def scipy_csr(parts, n_ecs, n_loci):
+    """CHECKER for tests (scipy on the host): what :func:`device_csr` must produce."""
+    from scipy.sparse import csc_matrix
     a = None
     for h, (ip, ix) in enumerate(parts):
-        mh = csc_matrix((np.full(len(ix), float(2 ** h)), ix.astype(int), ip.astype(int)), shape=(E, T))
+        mh = csc_matrix((np.full(len(ix), float(2 ** h)), np.asarray(ix).astype(int), np.asarray(ip).astype(int)), shape=(n_ecs, n_loci))
         a = mh if a is None else a + mh
     a = a.tocsr()
     a.sort_indices()
-    return ECMatrices(hname, lname, lengths, sname, a.indptr, a.indices, a.data.astype(np.int64),
-                      np.asarray(N[0]).astype(np.int64), np.asarray(N[1]).astype(np.int64), np.asarray(N[2]).astype(np.int64))
+    return a.indptr, a.indices, a.data.astype(np.int64)

@@ -90,18 +90,26 @@ class TupleEncoder(object):
         tid = np.asarray(tid, dtype=np.int64)
         valid = record_valid(flag, tid, np.asarray(next_tid, dtype=np.int64), np.asarray(next_pos, dtype=np.int64))
         vi = np.nonzero(valid)[0]
-        names = [trim_name(qnames[i]) if self.trim else qnames[i] for i in vi]
-        # a read starts at a valid record whose name differs from the previous valid record's
+        # a read starts at a valid record whose (trimmed) name differs from the previous valid record's (bam_utils.py:289-320).
+        # No Python loop over records: the names become one fixed-width code-point matrix, each row is blanked from its cut
+        # (first space at an index > 0, bam_utils.py:292-294) on, and consecutive rows are compared.
         head = np.zeros(len(vi), dtype=bool)
-        prev = self.last_name
-        for k, nm in enumerate(names):
-            if nm != prev:
-                head[k] = True
-                prev = nm
-        if names:
-            self.last_name = prev
-        if self.names_of_reads is not None:
-            self.names_of_reads.extend(qnames[vi[k]] for k in np.nonzero(head)[0])
+        if len(vi):
+            names = np.asarray(qnames, dtype=str)[vi] if not isinstance(qnames, np.ndarray) else qnames[vi].astype(str)
+            width = max(names.dtype.itemsize // 4, 1)
+            lens = np.char.str_len(names)
+            cut = lens
+            if self.trim:
+                sp = np.char.find(names, ' ')
+                cut = np.where(sp > 0, sp, lens)
+            code = np.ascontiguousarray(names).view(np.uint32).reshape(len(names), width)
+            code = np.where(np.arange(width)[None, :] < cut[:, None], code, 0)
+            head[1:] = (cut[1:] != cut[:-1]) | (code[1:] != code[:-1]).any(axis=1)
+            first = str(names[0][:cut[0]])
+            head[0] = first != self.last_name
+            self.last_name = str(names[-1][:cut[-1]])
+            if self.names_of_reads is not None:
+                self.names_of_reads.extend(str(x) for x in np.asarray(qnames, dtype=str)[vi[head]])
         starts = np.zeros(n, dtype=np.int64)
         starts[vi[head]] = 1
         rid = (np.cumsum(starts) + (np.int64(self.cur) if self.cur != 0xFFFFFFFF else -1))

@@ -62,24 +62,112 @@ def generate_shard(spec, r0, r1, device, chunk_reads=1 << 20):
     return rid, loc, hf, dict(records=n, reads=reads, valid=valid)
 
 
-def cpu_baseline(rid, loc, hf, n_haps, sample_reads):
-    """The oracle's C restatement (oracle/ec_oracle.c) on a bounded sample, on the host cores."""
+def _host_slice(rid, loc, hf, n_reads):
+    """The first ``n_reads`` reads of the device-resident stream as host uint32 arrays (whole reads)."""
     import numpy as np
     import torch
-    from oracle import c_oracle
-    cut = int(torch.searchsorted(rid, torch.tensor([sample_reads], dtype=torch.int32, device=rid.device))[0])
-    if cut == 0:
+    cut = int(torch.searchsorted(rid, torch.tensor([n_reads], dtype=torch.int32, device=rid.device))[0]) if n_reads else 0
+    if cut == 0 or n_reads >= int(rid[-1]) + 1:
         cut = rid.numel()
-    h = [t[:cut].cpu().numpy().view(np.uint32) for t in (rid, loc, hf)]
-    cores = min(os.cpu_count() or 1, 32)
+    return [t[:cut].cpu().numpy().view(np.uint32) for t in (rid, loc, hf)], cut
+
+
+def cpu_baseline(rid, loc, hf, n_haps, sample_reads):
+    """The oracle's C restatement (oracle/ec_oracle.c) on the host cores: all of them, contiguous read shards + ordered merge."""
+    from oracle import c_oracle
+    h, cut = _host_slice(rid, loc, hf, sample_reads)
+    cores = min(os.cpu_count() or 1, 64)
     c_oracle.load()
     t0 = time.perf_counter()
     r = c_oracle.ec_from_tuples(h[0], h[1], h[2], n_haps, threads=cores)
     dt = time.perf_counter() - t0
+    whole = cut == rid.numel()
     return dict(value=cut / dt, unit="alignments/s", cores=cores, kind="port",
-                sample="first %d reads (%d records) of the same stream, %d ECs; oracle/ec_oracle.c, "
-                       "%d threads over contiguous read shards + ordered merge; %.2f s"
-                       % (r["n_reads"], cut, len(r["count"]), cores, dt))
+                sample="%s (%d reads, %d records), %d ECs; oracle/ec_oracle.c, %d threads over contiguous read shards + "
+                       "ordered merge; %.2f s" % ("the whole workload" if whole else "first reads of the same stream",
+                                                   r["n_reads"], cut, len(r["count"]), cores, dt))
+
+
+def cpu_baseline_py(rid, loc, hf, n_haps, sample_reads):
+    """The reference's own algorithm in Python (oracle/py_baseline.py: per-alignment loop, string keys, ordered dicts, ordered
+    merge, per-EC incidence build) on a slice, P = os.cpu_count() worker processes; per-alignment cost is O(1), so the
+    full-workload time is the slice's time scaled by records."""
+    from oracle import py_baseline
+    h, cut = _host_slice(rid, loc, hf, sample_reads)
+    P = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    r = py_baseline.run(h[0], h[1], h[2], n_haps, P)
+    dt = time.perf_counter() - t0
+    return dict(value=cut / dt, unit="alignments/s", cores=P, kind="port (Python restatement of the reference's loops)",
+                sample="first %d reads (%d records) of the same stream, %d ECs; %d worker processes over contiguous read shards; "
+                       "scan %.2f s + ordered merge %.2f s + A build %.2f s; scales linearly in records (extrapolated whole-"
+                       "workload time: %.0f s)" % (sample_reads, cut, r["n_ecs"], P, r["seconds_scan"], r["seconds_merge"],
+                                                   r["seconds_build"], dt * rid.numel() / cut))
+
+
+def h2d_inclusive(b, rid, loc, hf, n_records):
+    """Records/s through the host-pointer entry point (ecb_push: staging, H2D copies, kernels), from pinned host memory."""
+    import numpy as np
+    import torch
+    m = min(n_records, rid.numel())
+    last = int(rid[m - 1])
+    cut = int(torch.searchsorted(rid, torch.tensor([last], dtype=torch.int32, device=rid.device))[0]) or m    # whole reads
+    host = [torch.empty(cut, dtype=torch.int32).pin_memory() for _ in range(3)]
+    for d, t in zip(host, (rid, loc, hf)):
+        d.copy_(t[:cut])
+    torch.cuda.synchronize()
+    arrs = [d.numpy().view(np.uint32) for d in host]
+    b.reset()
+    t0 = time.perf_counter()
+    b.push(*arrs)
+    b.finalize()
+    dt = time.perf_counter() - t0
+    return dict(value=cut / dt, unit="alignments/s", records=cut, seconds=dt,
+                note="pinned host arrays -> ecb_push (16 Mi-record staging batches, H2D copies, kernels) -> finalize; PCIe Gen5 x16 "
+                     "moves at most 63 GB/s = 5.2 G records/s of 12-byte tuples")
+
+
+def e2e_from_bam(spec_args, reads, tmpdir):
+    """BAM file -> .bin through the drop-in's convert() (host decode + tuple encoding + device + writer), decode time apart."""
+    from alntools_amd import bam_utils, bamio, synth
+    from alntools_amd.tuples import HeaderMaps, TupleEncoder
+    spec = synth.SynthSpec(*spec_args[:3], paired=spec_args[3])
+    bam, out = os.path.join(tmpdir, "e2e.bam"), os.path.join(tmpdir, "e2e.bin")
+    bamio.write_bam(bam, spec.references(), synth.raw_records(spec, 0, reads), level=1)
+    t0 = time.perf_counter()
+    sizes = bam_utils.convert(bam, out, None)
+    t_all = time.perf_counter() - t0
+    t0 = time.perf_counter()                          # the host side alone: decode + tuple encoding, nothing pushed
+    rd = bam_utils.open_bam(bam)
+    enc = TupleEncoder(HeaderMaps(rd.references, rd.lengths))
+    n = 0
+    while True:
+        q, flag, tid, pos, ntid, npos = rd.read_batch(bam_utils.BATCH_RECORDS)
+        if not len(q):
+            break
+        enc.encode(q, flag, tid, pos, ntid, npos)
+        n += len(q)
+    rd.close()
+    t_host = time.perf_counter() - t0
+    return dict(value=n / t_all, unit="alignments/s", records=n, reads=reads, seconds=t_all, host_decode_encode_seconds=t_host,
+                decoder=type(rd).__name__, ecs=sizes["n_ecs"],
+                note="convert(bam, bin): BAM decode on the host (%s), tuple encoding, ecb_push, finalize, .bin writer" % type(rd).__name__)
+
+
+def copy_peak(device, nbytes=4 << 30, reps=5):
+    """Device-to-device copy rate (read + write bytes per second) measured in this run: the bandwidth a kernel can get."""
+    import torch
+    a = torch.empty(nbytes // 4, dtype=torch.int32, device=device).fill_(1)
+    c = torch.empty_like(a)
+    c.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        c.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def main():
@@ -88,8 +176,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-sample-reads", type=int, default=6_000_000)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-reads", type=int, default=0, help="reads of the C baseline's sample (0 = the whole workload)")
+    ap.add_argument("--py-sample-reads", type=int, default=1_000_000, help="reads of the Python restatement's slice")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip every host-side measurement (C / Python baselines, H2D, BAM)")
+    ap.add_argument("--e2e-slice-reads", type=int, default=20_000, help="reads of the config-2 slice converted from a real BAM file")
     args = ap.parse_args()
 
     import torch
@@ -214,7 +304,7 @@ def main():
         b.reset()
         b.push_device(rid, loc, hf)
         bad, skipped = b.verify_device(rid, loc, hf)
-        exact = {"reads_differing_from_their_ec_key": bad, "reads_not_rechecked": skipped}
+        exact = {"reads_differing_from_their_ec_key": bad, "reads_on_the_long_read_path": skipped}
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -233,11 +323,17 @@ def main():
         k_ms_per_launch = k_ms / max(k_launches, 1)
         alg_bytes = 12.0 * st["records"] + 4.0 * st["reads"]
         achieved = alg_bytes / (k_ms / max(args.steps, 1) * 1e-3) / 1e9      # GB/s over the kernel's own time
-        traffic = None
+        # the whole step against SURVEY 8d's B_alg = 12 A + 4 R + 4 (E + 1) + 8 nnz(A): tuples -> CSR, everything in between
+        E, nnz = sizes.get("n_ecs") or 0, sizes.get("nnz_a") or 0
+        step_bytes = 12.0 * total_records + 4.0 * total_reads + 4.0 * (E + 1) + 8.0 * nnz
+        step_achieved = step_bytes / (ms_per_step * 1e-3) / 1e9
+        peak_copy = copy_peak(device) if not rehearsal else None
+        traffic, traffic_src = None, None
         tfile = os.path.join(ROOT, "profiles", "traffic_%s_n%d.json" % (args.workload, world))
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tfile))
+                traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "from_profiles: " + tj.get("source", "profiles/ (rocprofv3 --pmc, separate passes)")
             except Exception:
                 traffic = None
         out = {
@@ -257,13 +353,24 @@ def main():
                        "sharding": "contiguous reads over %d GPU(s)%s" % (world, ", per-rank EC tables cut into key ranges, exchanged point-to-point over RCCL, merged per range, gathered on rank 0" if world > 1 else ""),
                        "generate_s": round(t_gen, 2), "exactness_pass": exact},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_stream<false>", "kernel_ms_per_launch": k_ms_per_launch,
                          "launches_per_step": launches_per_step,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "step_achieved": step_achieved, "step_frac": step_achieved / HBM_PEAK_GBS,
+                         "step_algorithmic_bytes": step_bytes,
+                         "peak_measured_copy": peak_copy,
+                         "frac_of_measured_copy": (achieved / peak_copy) if peak_copy else None},
         }
         if not use_dist and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(rid, loc, hf, H, min(args.cpu_sample_reads, st["reads"]))
+            out["cpu_baseline"] = cpu_baseline(rid, loc, hf, H, args.cpu_sample_reads)
+            out["cpu_baseline_py"] = cpu_baseline_py(rid, loc, hf, H, min(args.py_sample_reads, st["reads"]))
+            out["h2d_inclusive"] = h2d_inclusive(b, rid, loc, hf, 400_000_000)
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                c1, c2 = WORKLOADS["c1"], WORKLOADS["c2"]
+                out["e2e_from_bam"] = {"config1": e2e_from_bam((c1[0], c1[1], c1[2], c1[3]), c1[0], td),
+                                       "config2_slice": e2e_from_bam((c2[0], c2[1], c2[2], c2[3]), args.e2e_slice_reads, td)}
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

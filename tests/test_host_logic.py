@@ -141,8 +141,8 @@ def test_emase_h5_round_trip_through_libhdf5(golden_dir, tmp_path):
     for name in ("g2_c1.bin", "g1_edge.bin", "g4_multi_min0.bin"):
         src = os.path.join(golden_dir, name)
         h5, back = str(tmp_path / (name + ".h5")), str(tmp_path / (name + ".back"))
-        bin_utils.ec2emase(src, h5)
-        bin_utils.emase2ec(h5, back)
+        bin_utils.ec2emase(src, h5, hapcsc=emase_h5.scipy_hapcsc)      # (no GPU here: the checker stands in for the device conversion)
+        bin_utils.emase2ec(h5, back, csr=emase_h5.scipy_csr)
         assert open(back, "rb").read() == open(src, "rb").read(), name
     if emase_h5._backend() == "libhdf5":
         from alntools_amd import h5lite
@@ -156,3 +156,59 @@ def test_emase_h5_round_trip_through_libhdf5(golden_dir, tmp_path):
                 assert np.array_equal(f.read_array('/h%d/indptr' % h), ref.indptr)
                 assert np.array_equal(f.read_array('/h%d/indices' % h), ref.indices)
             assert np.array_equal(f.read_array('/count'), m.dataN.astype(np.float64))
+
+
+def _h5dump_header(path):
+    import shutil
+    import subprocess
+    exe = shutil.which("h5dump") or "/opt/conda/bin/h5dump"
+    if not os.path.exists(exe):
+        pytest.skip("no h5dump in this environment")
+    out = subprocess.run([exe, "-H", "-A", path], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    return out.stdout
+
+
+def test_emase_h5_structure_matches_the_documented_layout(golden_dir, tmp_path):
+    """The groups, dataset types and attributes of the written .h5, read back by an independent tool (h5dump), against the
+    layout the reference writes (Sparse3DMatrix.py:325-342, AlignmentPropertyMatrix.py:507-532): root attrs incidence_only /
+    mtype / shape / hname, /h<i>/{indptr, indices} uint32 (+ data float64 unless incidence-only), /lengths, /lname, /rname,
+    /sname, and /count as a float64 vector (ec2emase of a one-sample .bin) or as the uint32 group of a 2-D matrix
+    (bam2emase: bam_utils.py:845 makes count a csc column; several samples)."""
+    import re
+    from alntools_amd import emase_h5
+    try:
+        emase_h5._backend()
+    except RuntimeError:
+        pytest.skip("no HDF5 library in this environment")
+    m = bin_utils.ecload(os.path.join(golden_dir, "g2_c1.bin"))
+    vec, grp = str(tmp_path / "vec.h5"), str(tmp_path / "grp.h5")
+    emase_h5.save(vec, m, title="t", incidence_only=False, hapcsc=emase_h5.scipy_hapcsc)                 # what ec2emase writes
+    emase_h5.save(grp, m, title="bam2ec", incidence_only=True, count_2d=True, hapcsc=emase_h5.scipy_hapcsc)   # what bam2emase writes
+
+    def datasets(txt):
+        out = {}
+        for mm in re.finditer(r'DATASET "([^"]+)" \{\s*DATATYPE\s+(\S+)', txt):
+            out[mm.group(1)] = mm.group(2)
+        return out
+
+    hv, hg = _h5dump_header(vec), _h5dump_header(grp)
+    for txt in (hv, hg):
+        for a in ("incidence_only", "mtype", "shape", "hname"):
+            assert 'ATTRIBUTE "%s"' % a in txt, a
+        for g in ["h%d" % h for h in range(m.num_haplotypes)]:
+            assert 'GROUP "%s"' % g in txt
+        assert txt.count('DATASET "indptr"') >= m.num_haplotypes and txt.count('DATASET "indices"') >= m.num_haplotypes
+        for name in ("lengths", "lname", "rname", "sname"):
+            assert 'DATASET "%s"' % name in txt, name
+    dv, dg = datasets(hv), datasets(hg)
+    assert dv["indptr"] == dv["indices"] == "H5T_STD_U32LE"                       # index_dtype='uint32' (Sparse3DMatrix.py:335-336)
+    assert dv["data"] == "H5T_IEEE_F64LE" and dv["count"] == "H5T_IEEE_F64LE"     # data_dtype=float; count vector
+    assert 'GROUP "count"' not in hv and 'GROUP "count"' in hg                    # vector vs 2-D count
+    assert "data" in dg and dg["data"] == "H5T_STD_U32LE"                         # the only "data" left is /count/data, uint32 (APM.py:521)
+    assert 'DATASET "count"' not in hg
+    # and the two files read back to the same matrices
+    for path in (vec, grp):
+        back = emase_h5.load(path, csr=emase_h5.scipy_csr)
+        assert np.array_equal(back.indptrA, m.indptrA) and np.array_equal(back.indicesA, m.indicesA) and np.array_equal(back.dataA, m.dataA)
+        assert np.array_equal(back.dataN, m.dataN) and back.sname == m.sname and back.lname == m.lname
