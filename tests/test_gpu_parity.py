@@ -359,6 +359,7 @@ def test_full_size_config3_properties():
     assert np.all(np.diff(whole["indptrA"]) > 0) and whole["indptrA"][-1] == s["nnz_a"]
     assert whole["indicesA"].min() >= 0 and whole["indicesA"].max() < T
     assert whole["dataA"].min() >= 1 and whole["dataA"].max() < (1 << H)
+    _assert_rows_distinct(whole, s["n_ecs"])
     rows = np.random.RandomState(1).randint(0, s["n_ecs"], 2000)
     for e in rows:
         r = whole["indicesA"][whole["indptrA"][e]:whole["indptrA"][e + 1]]
@@ -403,6 +404,138 @@ def test_full_size_config3_properties():
     for k in ("indptrA", "indicesA", "dataA", "dataN"):
         assert np.array_equal(whole[k], merged[k]), k
     root.b.close()
+
+
+def _mix64(x, seed):
+    with np.errstate(over="ignore"):
+        x = x + np.uint64(seed)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+
+
+def _assert_rows_distinct(out, n_ecs):
+    """No two ECs with the same key: two independent 64-bit hashes per CSR row -- the sum over the row of a splitmix64 of
+    (locus, mask, position); columns are ascending, so equal rows hash equal, and unequal rows do with probability ~2^-128."""
+    ip = out["indptrA"].astype(np.int64)
+    v = (out["indicesA"].astype(np.uint64) << np.uint64(32)) | out["dataA"].astype(np.uint64)
+    pos = np.arange(len(v), dtype=np.uint64) - np.repeat(ip[:-1], np.diff(ip)).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        h1 = np.add.reduceat(_mix64(v ^ _mix64(pos, 0x9E3779B97F4A7C15), 1), ip[:-1])
+        h2 = np.add.reduceat(_mix64(v + _mix64(pos, 0xD6E8FEB86659FD93), 0xC2B2AE3D27D4EB4F), ip[:-1])
+    both = np.stack([h1, h2, np.diff(ip).astype(np.uint64)], axis=1)
+    assert len(np.unique(both, axis=0)) == n_ecs, "two equivalence classes with the same target set"
+
+
+def test_full_size_config2_properties():
+    """BASELINE config 2 at full size (50 M single-end reads, 8 haplotypes x 40 k transcripts): totals against the generator's
+    own counts, the independent exactness pass over all 48 M reads, distinct EC keys, CSR invariants."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    import bench
+    R, T, H, paired, _ = bench.WORKLOADS["c2"]
+    spec = synth.SynthSpec(R, T, H, paired=paired)
+    dev = torch.device("cuda:0")
+    rid, loc, hf, st = bench.generate_shard(spec, 0, R, dev)
+    with ecb.EcBuilder(T, H, ec_capacity=1 << 22) as b:
+        b.push_device(rid, loc, hf)
+        assert b.verify_device(rid, loc, hf) == (0, 0)            # every read's target set == the key of its EC
+        s = b.finalize()
+        out = b.export()
+    assert s["all_alignments"] == st["records"] and s["valid_alignments"] == st["valid"] and s["n_reads"] == st["reads"]
+    assert int(out["dataN"].astype(np.int64).sum()) == st["reads"] and out["dataN"].min() >= 1
+    assert np.all(np.diff(out["indptrA"]) > 0) and out["indptrA"][-1] == s["nnz_a"]
+    assert out["indicesA"].min() >= 0 and out["indicesA"].max() < T and out["dataA"].min() >= 1 and out["dataA"].max() < (1 << H)
+    inner = np.ones(len(out["indicesA"]), dtype=bool)
+    inner[out["indptrA"][:-1]] = False
+    assert np.all(np.diff(out["indicesA"].astype(np.int64))[inner[1:]] > 0)          # columns ascending within every row
+    _assert_rows_distinct(out, s["n_ecs"])
+
+
+def test_full_size_config4_multisample_triples():
+    """BASELINE config 4 at full size on one GPU: 200 M paired-end reads, 5 000 cell barcodes, 64 files.  The EC of every read
+    is checked by the independent exactness pass (re-derived from the records, compared with the stored key: 0 of 192 M
+    differ), so the per-read EC ranks are a sound basis: the (EC, cell, file) triples, their counts and first reads must be
+    exactly the groups of (rank, meta) over the reads."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    import bench
+    R, T, H = 200_000_000, 80_000, 8
+    spec = synth.SynthSpec(R, T, H, paired=True)
+    dev = torch.device("cuda:0")
+    rid, loc, hf, st = bench.generate_shard(spec, 0, R, dev)
+    n_reads = st["reads"]
+    g = torch.arange(n_reads, dtype=torch.int64, device=dev)
+    x = ((g * 0x9E3779B97F4A7C15) >> 20) & 0x7FFFFFFFFFF
+    cell = x % 5000
+    cell = torch.where((x % 7) == 0, torch.full_like(cell, 17), cell)           # one big cell
+    fil = (g * 64) // n_reads                                                     # 64 files: contiguous read ranges, as a directory scan gives
+    meta = (cell | (fil << 22)).to(torch.int32)
+    with ecb.EcBuilder(T, H, multisample=True, ec_capacity=1 << 24) as b:
+        b.push_device(rid, loc, hf)
+        assert b.verify_device(rid, loc, hf) == (0, 0)
+        del loc, hf
+        b.push_cells(meta.cpu().numpy().view(np.uint32), 0)
+        s = b.finalize()
+        pr = b.export_pairs()
+        rec = torch.from_numpy(b.export_read_ec()).to(dev)
+    assert s["n_reads"] == n_reads and int(pr["count"].sum()) == n_reads
+    key = (rec.to(torch.int64) << 32) | (meta.to(torch.int64) & 0xFFFFFFFF)
+    order = torch.argsort(key, stable=True)
+    ks = key[order]
+    heads = torch.nonzero(torch.cat([torch.ones(1, dtype=torch.bool, device=dev), ks[1:] != ks[:-1]])).flatten()
+    exp_key = ks[heads].cpu().numpy()
+    exp_cnt = torch.diff(torch.cat([heads, torch.tensor([len(ks)], device=dev)])).cpu().numpy()
+    exp_first = order[heads].cpu().numpy()                                        # stable sort: a run starts with its smallest read
+    got_key = (pr["ec"] << 32) | (pr["cell"] | (pr["file"] << 22))
+    assert len(got_key) == len(exp_key) == s["nnz_n"]
+    assert np.array_equal(got_key, exp_key) and np.array_equal(pr["count"], exp_cnt) and np.array_equal(pr["first"], exp_first)
+
+
+def test_full_size_config5_round_trip_and_ranges():
+    """BASELINE config 5 on config 3's output: (i) CSR(bitmask) -> per-haplotype CSC -> CSR on the 12 M-nnz matrix of the
+    100 M-read stream gives the same arrays back, every set bit exactly once; (ii) the range reduction over all 3.3 G
+    records equals torch's own min / max per (locus, haplotype)."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    import bench
+    R, T, H, paired, _ = bench.WORKLOADS["c3"]
+    spec = synth.SynthSpec(R, T, H, paired=paired)
+    dev = torch.device("cuda:0")
+    rid, loc, hf, st = bench.generate_shard(spec, 0, R, dev)
+    n = rid.numel()
+    pos = ((torch.arange(n, dtype=torch.int64, device=dev) * 1103515245 + 12345) % 4999).to(torch.int32)
+    with ecb.EcBuilder(T, H, ec_capacity=1 << 24, track_ranges=True) as b:
+        b.push_device(rid, loc, hf, pos)
+        s = b.finalize()
+        out = b.export()
+        rng = b.export_ranges()
+    del rid
+    # (ii) ranges: max - min + 1 over the valid records of every (locus, haplotype), 0 where none
+    lo = torch.full((T * H,), 1 << 40, dtype=torch.int64, device=dev)
+    hi = torch.full((T * H,), -1, dtype=torch.int64, device=dev)
+    for c0 in range(0, n, 1 << 29):                                   # (in pieces: torch indexes with 32 bits)
+        c1 = min(c0 + (1 << 29), n)
+        f = hf[c0:c1].to(torch.int64) & 0xFFFFFFFF
+        valid = ((f & 4) == 0) & (((f & 1) == 0) | (((f ^ 2) & 0x3082) == 0))
+        slot = (loc[c0:c1].to(torch.int64) * H + ((f >> 16) & 0xFF))[valid]
+        pv = pos[c0:c1].to(torch.int64)[valid]
+        lo.scatter_reduce_(0, slot, pv, "amin")
+        hi.scatter_reduce_(0, slot, pv, "amax")
+    exp = torch.where(hi >= 0, hi - lo + 1, torch.zeros_like(hi)).cpu().numpy().reshape(T, H)
+    assert np.array_equal(rng, exp)
+    del f, valid, slot, pv, loc, hf, pos
+    # (i) the sparse-format round trip at full size
+    ip, ix, da = (torch.from_numpy(out[k]).to(dev) for k in ("indptrA", "indicesA", "dataA"))
+    cptr, cidx = ecb.csr_to_hapcsc(ip, ix, da, T, H)
+    bits = int(sum(int(((out["dataA"] >> h) & 1).sum()) for h in range(H)))
+    assert cidx.numel() == bits and int(cptr[:, -1].sum()) == bits
+    ip2, ix2, da2 = ecb.hapcsc_to_csr(cptr, cidx, s["n_ecs"])
+    assert torch.equal(ip2, ip) and torch.equal(ix2, ix) and torch.equal(da2, da)
+    _assert_rows_distinct(out, s["n_ecs"])
 
 
 def test_sparse_format_round_trip_on_device(golden_dir):
@@ -486,7 +619,7 @@ def _random_stream(seed, n_reads, n_loci, n_haps, max_len, p_invalid, loci_mode)
 @pytest.mark.parametrize("seed,n_loci,n_haps,max_len,p_inv,mode", [
     (1, 50, 1, 60, 0.1, "wide"),                 # one haplotype: every record a new locus, tables at their fullest
     (2, 1 << 20, 31, 40, 0.2, "strided"),        # 31 haplotypes (bit 30 set), loci congruent mod 64
-    (3, (1 << 27) - 1, 8, 200, 0.05, "wide"),    # the largest locus index the key packing allows; long reads
+    (3, (1 << 27) - 1, 8, 200, 0.05, "wide"),    # the largest locus index the key packing allows; long reads (carried over tiles, some via k_slow)
     (4, 300, 4, 12, 0.5, "near"),                # half the records invalid
     (5, 7, 2, 3, 0.0, "near"),                   # tiny reads: more than 64 reads per tile
 ])
