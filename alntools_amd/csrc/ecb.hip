@@ -32,8 +32,6 @@
 #include <string>
 #include <vector>
 
-#include <rocprim/rocprim.hpp>   // radix sort of the (EC, cell, file) keys of the multisample path only
-
 #include "../../include/ecb.h"
 
 namespace {
@@ -1828,7 +1826,7 @@ __global__ void k_ms_combine(const u64* keys, const u32* idx, const u32* flag, c
 
 // ---------------------------------------------------------------------------------------------
 // f-2: CSR(bitmask) <-> per-haplotype CSC (bin_utils.py:979-1028).  Expand to (key, value) pairs, stable radix sort
-// (rocprim), locate rows / columns by binary search on the sorted keys.
+// (the LSD sort above), locate rows / columns by binary search on the sorted keys.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ u64 lower_bound_u32(const u32* a, u64 n, u32 v) {
     u64 lo = 0, hi = n;
@@ -1845,19 +1843,19 @@ __global__ void k_cv_popc(const int* data, u64 nnz, u32* cnt) {
     if (i < nnz) cnt[i] = __popc((u32)data[i]);
 }
 __global__ void k_cv_expand(const int* indptr, u32 n_ecs, const int* indices, const int* data, u64 nnz, const u32* pos,
-                            u32 n_loci, u32* keys, u32* vals) {
+                            u32 n_loci, u64* keys, u32* vals) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= nnz) return;
     u32 lo = 0, hi = n_ecs;                                  // row of entry i: last e with indptr[e] <= i
     while (lo < hi) { const u32 m = (lo + hi + 1) >> 1; if ((u64)indptr[m] <= i) lo = m; else hi = m - 1; }
     u32 m = (u32)data[i], at = pos[i];
-    while (m) { const u32 h = __ffs(m) - 1; m &= m - 1; keys[at] = h * n_loci + (u32)indices[i]; vals[at] = lo; ++at; }
+    while (m) { const u32 h = __ffs(m) - 1; m &= m - 1; keys[at] = (u64)h * n_loci + (u32)indices[i]; vals[at] = lo; ++at; }
 }
-__global__ void k_cv_cscptr(const u32* keys, u64 total, u32 n_loci, u32 n_haps, int* cscptr) {
+__global__ void k_cv_cscptr(const u64* keys, u64 total, u32 n_loci, u32 n_haps, int* cscptr) {
     const u64 c = blockIdx.x * (u64)blockDim.x + threadIdx.x;          // c = h * (T + 1) + t
     if (c >= (u64)n_haps * (n_loci + 1)) return;
     const u32 h = (u32)(c / (n_loci + 1)), t = (u32)(c % (n_loci + 1));
-    cscptr[c] = (int)(lower_bound_u32(keys, total, h * n_loci + t) - lower_bound_u32(keys, total, h * n_loci));
+    cscptr[c] = (int)(lower_bound_u64(keys, total, (u64)h * n_loci + t) - lower_bound_u64(keys, total, (u64)h * n_loci));
 }
 __global__ void k_cv_back_expand(const int* cscptr, const int* cscidx, u64 total, u32 n_loci, u32 n_haps, const u64* hap_start,
                                  u64* keys, u32* vals) {
@@ -1903,6 +1901,88 @@ __global__ void k_range_len(const int* mn, const int* mx, u64 n, long long* out)
 __global__ void k_fill_i32(int* p, u64 n, int v) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LSD radix sort of (u64 key, u32 value) pairs, 8 bits per pass, stable: the sort behind the multisample triples
+// (bam_utils_multisample.py:503-576, 737-791) and the sparse-format conversions (bin_utils.py:979-1028).
+// A pass = k_rs_hist (LDS histogram per 4 096-key tile) -> exclusive scan over (digit, tile) -> k_rs_scatter.  The scatter
+// ranks keys WITHOUT reordering equal digits: every wave owns a contiguous quarter of the tile and walks it 64 keys at a
+// time; lanes with the same digit find each other with eight ballots (one per digit bit), the lowest of them bumps the
+// wave's LDS counter of that digit by the group's size, and a key's rank is that counter value plus the number of group
+// members in lower lanes.  Counters of the four waves are added up in wave order afterwards.
+// ---------------------------------------------------------------------------------------------
+constexpr int RS_TPB = 256, RS_ITEMS = 16, RS_TILE = RS_TPB * RS_ITEMS;
+__global__ __launch_bounds__(RS_TPB) void k_rs_hist(const u64* keys, u64 n, u32 shift, u32 nb, u32* hist) {
+    __shared__ u32 h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const u64 t0 = (u64)blockIdx.x * RS_TILE;
+#pragma unroll 4
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        const u64 i = t0 + (u64)k * RS_TPB + threadIdx.x;
+        if (i < n) atomicAdd(&h[(u32)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(u64)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+}
+__global__ __launch_bounds__(RS_TPB) void k_rs_scatter(const u64* kin, const u32* vin, u64 n, u32 shift, u32 nb, const u32* offs,
+                                                       u64* kout, u32* vout) {
+    __shared__ u32 cnt[RS_TPB / 64][256];
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    for (u32 q = tid; q < (RS_TPB / 64) * 256; q += RS_TPB) (&cnt[0][0])[q] = 0;
+    __syncthreads();
+    const u64 w0 = (u64)blockIdx.x * RS_TILE + (u64)w * (RS_TILE / (RS_TPB / 64));
+    const u64 lt = (1ull << lane) - 1ull;
+    u64 key[RS_ITEMS];
+    u32 val[RS_ITEMS], rk[RS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const u64 i = w0 + (u64)r * 64 + lane;
+        const bool have = i < n;
+        key[r] = have ? kin[i] : 0ull;
+        val[r] = have ? vin[i] : 0u;
+        const u32 d = (u32)(key[r] >> shift) & 255u;
+        u64 peers = __ballot(have);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const u64 m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const u32 below = (u32)__popcll(peers & lt);
+        u32 base = 0;
+        if (have && below == 0u) base = atomicAdd(&cnt[w][d], (u32)__popcll(peers));
+        base = __shfl(base, have ? __ffsll((long long)peers) - 1 : (int)lane);
+        rk[r] = base + below;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const u64 i = w0 + (u64)r * 64 + lane;
+        if (i < n) {
+            const u32 d = (u32)(key[r] >> shift) & 255u;
+            u32 pre = 0;
+            for (u32 k = 0; k < w; ++k) pre += cnt[k][d];
+            const u32 pos = offs[(u64)d * nb + blockIdx.x] + pre + rk[r];
+            kout[pos] = key[r];
+            vout[pos] = val[r];
+        }
+    }
+}
+__global__ __launch_bounds__(TPB) void k_or_reduce(const u64* keys, u64 n, u64* out) {
+    u64 v = 0;
+    for (u64 i = blockIdx.x * (u64)TPB + threadIdx.x; i < n; i += (u64)gridDim.x * TPB) v |= keys[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v |= __shfl_xor(v, d);
+    if ((threadIdx.x & 63u) == 0 && v) atomicOr(out, v);
+}
+__global__ void k_widen(const u32* in, u64 n, u64* out) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+__global__ void k_narrow(const u64* in, u64 n, u32* out) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (u32)in[i];
 }
 
 }  // namespace
@@ -1955,7 +2035,7 @@ struct ecb_handle {
     enum { P_RESUME, P_SUMS, P_HIST, P_OFFS, P_PAIRS, P_CNT, P_PARTS, P_STARTS, P_WORK, P_LIST, P_BITMAP, P_WPOP, P_WPREFIX, P_ROWLEN, P_ORDER,
            P_WCOUNTS, P_RANK, P_INDPTR, P_COUNTS, P_INDICES, P_DATA, P_MS_KEYS, P_MS_KEYS2, P_MS_VALS, P_MS_VALS2, P_MS_TMP,
            P_MS_FLAG, P_MS_POS, P_MS_OKEY, P_MS_OFIRST, P_MS_OSTART, P_MS_X, P_MS_OCOUNT, P_MS_GRANK, P_MS_CIN, P_MS_FIN, P_LISTFN,
-           P_REMAP, P_TOTALS, P_SLOW_LEN, P_SLOW_OFF, P_SLOW_NRE, P_SLOW_REQ, P_SLOW_REQ2, P_SLOW_KEY, P_SLOW_MASK, P_BIG, P_N };
+           P_REMAP, P_TOTALS, P_SLOW_LEN, P_SLOW_OFF, P_SLOW_NRE, P_SLOW_REQ, P_SLOW_REQ2, P_SLOW_KEY, P_SLOW_MASK, P_BIG, P_RS_HIST, P_RS_OFFS, P_RS_SUMS, P_N };
     void* pool[P_N] = {}; u64 pool_bytes[P_N] = {};
 
     // profiling
@@ -2333,6 +2413,49 @@ int excl_scan(ecb_handle* h, const u32* in, u64 n, u32* out, u64* total) {
     return ECB_OK;
 }
 
+// Stable LSD radix sort of n (key, value) pairs on `st`: only the digits some key has a bit in are sorted on (one OR-reduction
+// and one host wait up front).  k[0] / v[0] hold the input; the result lands in k[*where] / v[*where].  scratch: u32 hist and
+// offs of 256 * tiles each, u32 sums of tiles / 8 + 8, and 8 bytes at d_word.
+struct SortScratch { u32 *hist, *offs, *sums; u64* d_word; };
+inline u64 rs_tiles(u64 n) { return std::max<u64>(1, (n + RS_TILE - 1) / RS_TILE); }
+inline u64 rs_scan_blocks(u64 n) { return std::max<u64>(1, (256 * rs_tiles(n) + SCAN_BLOCK - 1) / SCAN_BLOCK); }
+hipError_t radix_sort_pairs64(hipStream_t st, u64* k[2], u32* v[2], u64 n, const SortScratch& sc, int* where, u64 bit_mask = ~0ull) {
+    *where = 0;
+    if (n < 2) return hipSuccess;
+    if (n >= (1ull << 32)) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(sc.d_word, 0, 8, st);
+    if (e != hipSuccess) return e;
+    k_or_reduce<<<(unsigned)std::min<u64>(1024, (n + TPB - 1) / TPB), TPB, 0, st>>>(k[0], n, sc.d_word);
+    u64 ormask = 0;
+    if ((e = hipMemcpyAsync(&ormask, sc.d_word, 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    ormask &= bit_mask;
+    const u32 nb = (u32)rs_tiles(n);
+    const u64 m = 256ull * nb, sb = rs_scan_blocks(n);
+    int cur = 0;
+    for (u32 shift = 0; shift < 64; shift += 8) {
+        if (!((ormask >> shift) & 255ull)) continue;            // every key has zero here: already in order
+        k_rs_hist<<<nb, RS_TPB, 0, st>>>(k[cur], n, shift, nb, sc.hist);
+        k_scan_sums<<<(unsigned)sb, TPB, 0, st>>>(sc.hist, m, sc.sums);
+        k_scan_top<<<1, TPB, 0, st>>>(sc.sums, sb, sc.d_word);
+        k_scan_apply<<<(unsigned)sb, TPB, 0, st>>>(sc.hist, m, sc.sums, sc.offs);
+        k_rs_scatter<<<nb, RS_TPB, 0, st>>>(k[cur], v[cur], n, shift, nb, sc.offs, k[cur ^ 1], v[cur ^ 1]);
+        cur ^= 1;
+    }
+    *where = cur;
+    return hipGetLastError();
+}
+int handle_sort(ecb_handle* h, u64* k[2], u32* v[2], u64 n, int* where) {
+    SortScratch sc{};
+    u64* tot = nullptr;
+    POOL(h, P_RS_HIST, sc.hist, 256 * rs_tiles(n)); POOL(h, P_RS_OFFS, sc.offs, 256 * rs_tiles(n));
+    POOL(h, P_RS_SUMS, sc.sums, rs_scan_blocks(n) + 8); POOL(h, P_TOTALS, tot, 8);
+    sc.d_word = tot + 6;
+    const hipError_t e = radix_sort_pairs64(h->stream, k, v, n, sc, where);
+    if (e != hipSuccess) return fail(h, ECB_ERR_HIP, "radix sort: %s", hipGetErrorString(e));
+    return ECB_OK;
+}
+
 // reads per EC / first appearance, from read_slot[0, n_reads) (once, when the stream is closed).  Only queues kernels:
 // the totals and the work list of k_count_bins stay on the device.
 int ensure_counts(ecb_handle* h) {
@@ -2407,13 +2530,13 @@ int ms_reduce(ecb_handle* h, const u32* ec_of_slot) {
     POOL(h, P_MS_KEYS, keys, R); POOL(h, P_MS_KEYS2, keys2, R); POOL(h, P_MS_VALS, vals, R); POOL(h, P_MS_VALS2, vals2, R);
     POOL(h, P_MS_FLAG, flag, R); POOL(h, P_MS_POS, pos, R);
     k_ms_keys<<<nblk(R, TPB), TPB, 0, h->stream>>>(h->read_slot, ec_of_slot, h->meta, R, keys, vals);
-    size_t tmp_bytes = 0;
-    if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, R, 0, 64, h->stream) != hipSuccess)
-        return fail(h, ECB_ERR_HIP, "rocprim::radix_sort_pairs (size query)");
-    char* tmp = nullptr;
-    POOL(h, P_MS_TMP, tmp, tmp_bytes);
-    if (rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, R, 0, 64, h->stream) != hipSuccess)
-        return fail(h, ECB_ERR_HIP, "rocprim::radix_sort_pairs");
+    {
+        u64* kk[2] = {keys, keys2}; u32* vv[2] = {vals, vals2};
+        int where = 0;
+        const int rc0 = handle_sort(h, kk, vv, R, &where);
+        if (rc0 != ECB_OK) return rc0;
+        keys2 = kk[where]; vals2 = vv[where];
+    }
     k_ms_heads<<<nblk(R, TPB), TPB, 0, h->stream>>>(keys2, R, flag);
     u64 nt = 0;
     int rc = excl_scan(h, flag, R, pos, &nt);
@@ -3002,13 +3125,13 @@ int ecb_ms_adopt_triples_device(ecb_handle* h, uint32_t n_tables, const void* co
     u64 nt = 0;
     if (tot) {
         k_iota<<<nblk(tot, TPB), TPB, 0, h->stream>>>((int*)vals, tot);
-        size_t tmp_bytes = 0;
-        if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, tot, 0, 64, h->stream) != hipSuccess)
-            return fail(h, ECB_ERR_HIP, "rocprim::radix_sort_pairs (size query)");
-        char* tmp = nullptr;
-        POOL(h, P_MS_TMP, tmp, tmp_bytes);
-        if (rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, tot, 0, 64, h->stream) != hipSuccess)
-            return fail(h, ECB_ERR_HIP, "rocprim::radix_sort_pairs");
+        {
+            u64* kk[2] = {keys, keys2}; u32* vv[2] = {vals, vals2};
+            int where = 0;
+            const int rc0 = handle_sort(h, kk, vv, tot, &where);
+            if (rc0 != ECB_OK) return rc0;
+            keys2 = kk[where]; vals2 = vv[where];
+        }
         k_ms_heads<<<nblk(tot, TPB), TPB, 0, h->stream>>>(keys2, tot, flag);
         int rc = excl_scan(h, flag, tot, pos, &nt);
         if (rc != ECB_OK) return rc;
@@ -3103,16 +3226,19 @@ extern "C" int ecb_csr_to_hapcsc_device(int device, uint32_t n_ecs, uint32_t n_l
     if (tot >= (1ull << 32)) return fail(nullptr, ECB_ERR_LIMIT, "more than 2^32-1 set haplotype bits");
     *total = tot;
     if (!d_cscidx || !d_cscptr) return ECB_OK;
-    u32 *keys = sc.get<u32>(tot), *vals = sc.get<u32>(tot), *keys2 = sc.get<u32>(tot);
-    if (!keys || !vals || !keys2) return fail(nullptr, ECB_ERR_HIP, "out of device memory");
+    u64 *keys = sc.get<u64>(tot), *keys2 = sc.get<u64>(tot);
+    u32* vals = sc.get<u32>(tot);
+    SortScratch ss{sc.get<u32>(256 * rs_tiles(tot)), sc.get<u32>(256 * rs_tiles(tot)), sc.get<u32>(rs_scan_blocks(tot) + 8), sc.get<u64>(1)};
+    if (!keys || !vals || !keys2 || !ss.hist || !ss.offs || !ss.sums || !ss.d_word) return fail(nullptr, ECB_ERR_HIP, "out of device memory");
     k_cv_expand<<<nblk(nnz, TPB), TPB, 0, st>>>((const int*)d_indptr, n_ecs, (const int*)d_indices, (const int*)d_data, nnz, pos,
                                                n_loci, keys, vals);
-    size_t tb = 0;
-    unsigned bits = 1; while ((1ull << bits) < (u64)n_haps * n_loci) ++bits;
-    rocprim::radix_sort_pairs(nullptr, tb, keys, keys2, vals, (u32*)d_cscidx, tot, 0, bits, st);
-    char* tmp = sc.get<char>(tb);
-    if (!tmp) return fail(nullptr, ECB_ERR_HIP, "out of device memory");
-    if (rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, (u32*)d_cscidx, tot, 0, bits, st) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "sort");
+    {   // stable sort by (haplotype, locus): rows stay ascending within a column, as scipy's tocsc() leaves them
+        u64* kk[2] = {keys, keys2}; u32* vv[2] = {vals, (u32*)d_cscidx};
+        int where = 0;
+        if (radix_sort_pairs64(st, kk, vv, tot, ss, &where) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "sort");
+        if (where == 0 && hipMemcpyAsync(d_cscidx, vals, tot * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "copy");
+        keys2 = kk[where];
+    }
     const u64 nc = (u64)n_haps * (n_loci + 1);
     k_cv_cscptr<<<nblk(nc, TPB), TPB, 0, st>>>(keys2, tot, n_loci, n_haps, (int*)d_cscptr);
     if (hipStreamSynchronize(st) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "csr -> csc");
@@ -3140,11 +3266,14 @@ extern "C" int ecb_hapcsc_to_csr_device(int device, uint32_t n_ecs, uint32_t n_l
     if (!d_hs || !keys || !keys2 || !vals || !vals2 || !flag || !pos) return fail(nullptr, ECB_ERR_HIP, "out of device memory");
     hipMemcpy(d_hs, hs.data(), (n_haps + 1) * 8, hipMemcpyHostToDevice);
     k_cv_back_expand<<<nblk(total, TPB), TPB, 0, st>>>((const int*)d_cscptr, (const int*)d_cscidx, total, n_loci, n_haps, d_hs, keys, vals);
-    size_t tb = 0;
-    rocprim::radix_sort_pairs(nullptr, tb, keys, keys2, vals, vals2, total, 0, 64, st);
-    char* tmp = sc.get<char>(tb);
-    if (!tmp) return fail(nullptr, ECB_ERR_HIP, "out of device memory");
-    if (rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, total, 0, 64, st) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "sort");
+    {
+        SortScratch ss{sc.get<u32>(256 * rs_tiles(total)), sc.get<u32>(256 * rs_tiles(total)), sc.get<u32>(rs_scan_blocks(total) + 8), sc.get<u64>(1)};
+        if (!ss.hist || !ss.offs || !ss.sums || !ss.d_word) return fail(nullptr, ECB_ERR_HIP, "out of device memory");
+        u64* kk[2] = {keys, keys2}; u32* vv[2] = {vals, vals2};
+        int where = 0;
+        if (radix_sort_pairs64(st, kk, vv, total, ss, &where) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "sort");
+        keys2 = kk[where]; vals2 = vv[where];
+    }
     k_ms_heads<<<nblk(total, TPB), TPB, 0, st>>>(keys2, total, flag);
     u64 nnz = 0;
     if (cv_scan(st, flag, total, pos, &nnz, sc) != ECB_OK) return fail(nullptr, ECB_ERR_HIP, "scan");
