@@ -8,8 +8,8 @@ Split of the work:
   name is the UNTRIMMED query name (``:292``), and the last read of every file is never counted (``:306-321``);
 * device (libecb) -- everything read-sized: filter, target sets, ECs in first-appearance order, A, and the reduction
   of reads to distinct (EC, cell, file) triples with counts and first read index (``ec[key][cell] += 1``, ``:288-290``);
-* host -- metadata-sized: cell order (``cr_totals`` insertion order, ``:513-546``), the minimum-count filter and EC
-  re-ranking (``:596-636``), N as CSC (``:737-791``), from the triples.
+* device too (``ecb_ms_filter``): cell order (``cr_totals`` insertion order, ``:513-546``), the minimum-count filter and EC
+  re-ranking (``:596-636``), N as CSC (``:737-791``), from the triples; the host only maps cell ids back to names.
 
 File order: the reference takes ``glob.glob`` order (``:379``), which is filesystem-dependent and changes sample
 order and EC order; ``convert`` here sorts the file names.  ``convert_files`` takes an explicit order.
@@ -25,7 +25,7 @@ import numpy as np
 from . import utils
 from .bam_utils import BATCH_RECORDS, open_bam, write_range_file
 from .bin_utils import ECMatrices, ecsave2
-from .ecb import FLAG_MATE_OTHER_REF, FLAG_NEXT_POS_NEG, HAP_SHIFT, EcBuilder
+from .ecb import FLAG_MATE_OTHER_REF, FLAG_NEXT_POS_NEG, HAP_SHIFT, EcBuilder, EcbError
 from .tuples import HeaderMaps, record_valid, trim_name
 
 LOG = utils.get_logger()
@@ -88,47 +88,6 @@ def _tuples(c, sel, maps, read_base):
             c["pos"][sel].astype(np.int32), valid)
 
 
-def reduce_triples(tr, n_ecs, n_cells, minimum_count):
-    """Triples -> (kept cell ids in sample order, EC keep mask, CSC N) -- ``bam_utils_multisample.py:503-636, 737-791``."""
-    ec, cell, fil, cnt, first = tr["ec"], tr["cell"], tr["file"], tr["count"], tr["first"]
-    # cr_totals insertion order: files in order; within a file ECs by first appearance; within an EC cells by first appearance
-    fe = fil * n_ecs + ec
-    _, inv = np.unique(fe, return_inverse=True)
-    fec = np.full(inv.max() + 1 if len(inv) else 0, np.iinfo(np.int64).max)
-    np.minimum.at(fec, inv, first)
-    order = np.lexsort((first, fec[inv], fil))
-    seq = cell[order]
-    _, idx = np.unique(seq, return_index=True)
-    cr_order = seq[np.sort(idx)]
-    totals = np.bincount(cell, weights=cnt, minlength=n_cells).astype(np.int64)
-    if minimum_count <= 0:
-        minimum_count = 1                                             # :596-597
-    kept_cells = [int(c) for c in cr_order if totals[c] >= minimum_count]
-    new_cell = np.full(n_cells, -1, dtype=np.int64)
-    new_cell[kept_cells] = np.arange(len(kept_cells))
-    sel = new_cell[cell] >= 0
-    ec_keep = np.zeros(n_ecs, dtype=bool)
-    ec_keep[ec[sel]] = True                                           # ECs left empty are dropped, the rest re-ranked (:616-636)
-    new_rank = np.cumsum(ec_keep) - 1
-    S = len(kept_cells)
-    key = new_cell[cell[sel]] * int(ec_keep.sum()) + new_rank[ec[sel]]          # column-major: CSC order
-    uk, kinv = np.unique(key, return_inverse=True)
-    data = np.bincount(kinv, weights=cnt[sel]).astype(np.int64)
-    E2 = int(ec_keep.sum())
-    cols, rows = uk // max(E2, 1), uk % max(E2, 1)
-    indptr = np.zeros(S + 1, dtype=np.int64)
-    np.add.at(indptr, cols + 1, 1)
-    indptr = np.cumsum(indptr)
-    return kept_cells, ec_keep, (indptr, rows, data)
-
-
-def select_rows(indptr, indices, data, keep):
-    lens = np.diff(indptr)
-    rowsel = np.repeat(keep, lens)
-    new_ptr = np.concatenate([[0], np.cumsum(lens[keep])])
-    return new_ptr, indices[rowsel], data[rowsel]
-
-
 def convert_files(bam_files, ec_filename, emase_filename, minimum_count=-1, range_filename=None, target_filename=None):
     """``bam_files`` in the given order -> ``.bin`` / ``.h5``; returns counters."""
     start_time = time.time()
@@ -174,29 +133,31 @@ def convert_files(bam_files, ec_filename, emase_filename, minimum_count=-1, rang
                 b.push_cells(np.asarray(ids, dtype=np.uint32) | np.uint32(fi << CELL_BITS), read_base)
             read_base += len(cells)
         sizes = b.finalize()
-        a = b.export()
-        tr = b.export_pairs()
+        names = list(cell_ids.keys())
+        LOG.info("Number of alignments: {:,}".format(n_valid))
+        LOG.info("Number of main targets: {:,}".format(maps.n_loci))
+        LOG.info("Number of haplotypes: {:,}".format(maps.n_haplotypes))
+        LOG.info("Number of ECs: {:,}".format(sizes["n_ecs"]))
+        LOG.info("Number of cells: {:,}".format(len(names)))
+        try:
+            f = b.ms_filter(len(names), minimum_count)                # cell order, filter, re-rank, N: on the device
+        except EcbError as e:
+            if e.code == -7:                                          # ECB_ERR_EMPTY
+                raise ValueError("no cell reaches the minimum count")
+            raise
         if track:
             mn, mx = b.export_range_minmax()
             mn, mx = np.minimum(mn.astype(np.int64), host_min), np.maximum(mx.astype(np.int64), host_max)
             write_range_file(range_filename, maps, np.where(mx >= mn, mx - mn + 1, 0))
-    names = list(cell_ids.keys())
-    LOG.info("Number of alignments: {:,}".format(n_valid))
-    LOG.info("Number of main targets: {:,}".format(maps.n_loci))
-    LOG.info("Number of haplotypes: {:,}".format(maps.n_haplotypes))
-    LOG.info("Number of ECs: {:,}".format(sizes["n_ecs"]))
-    LOG.info("Number of cells: {:,}".format(len(names)))
-    kept, ec_keep, (n_ptr, n_idx, n_dat) = reduce_triples(tr, sizes["n_ecs"], len(names), minimum_count)
-    LOG.info("Number of ECs after filtering : {:,}".format(int(ec_keep.sum())))
+    kept = [int(c) for c in f["kept_cells"]]
+    n_ecs_kept = len(f["indptrA"]) - 1
+    LOG.info("Number of ECs after filtering : {:,}".format(n_ecs_kept))
     LOG.info("Number of cells after filtering: {:,}".format(len(kept)))
-    if not kept:
-        raise ValueError("no cell reaches the minimum count")
-    a_ptr, a_idx, a_dat = select_rows(a["indptrA"], a["indicesA"], a["dataA"], ec_keep)
     m = ECMatrices(maps.haplotypes, maps.main_targets, maps.lengths, [names[c] for c in kept],
-                   a_ptr, a_idx, a_dat, n_ptr, n_idx, n_dat)
+                   f["indptrA"], f["indicesA"], f["dataA"], f["indptrN"], f["indicesN"], f["dataN"])
     if emase_filename:
         from . import emase_h5
-        emase_h5.save(emase_filename, m, title='Multisample APM', incidence_only=False)   # :806
+        emase_h5.save(emase_filename, m, title='Multisample APM', incidence_only=False, count_2d=True)   # :806; N is a csc matrix whatever S is (:783-791)
     if ec_filename:
         try:
             os.remove(ec_filename)
@@ -204,7 +165,7 @@ def convert_files(bam_files, ec_filename, emase_filename, minimum_count=-1, rang
             pass
         ecsave2(ec_filename, m)
     LOG.info("Done, total time: {}".format(utils.format_time(start_time, time.time())))
-    return dict(all_alignments=n_all, valid_alignments=n_valid, n_ecs=int(ec_keep.sum()), n_cells=len(kept),
+    return dict(all_alignments=n_all, valid_alignments=n_valid, n_ecs=n_ecs_kept, n_cells=len(kept),
                 n_ecs_before=sizes["n_ecs"], n_cells_before=len(names), samples=[names[c] for c in kept])
 
 

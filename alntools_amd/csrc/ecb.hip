@@ -1976,6 +1976,113 @@ __global__ __launch_bounds__(TPB) void k_or_reduce(const u64* keys, u64 n, u64* 
     for (int d = 32; d > 0; d >>= 1) v |= __shfl_xor(v, d);
     if ((threadIdx.x & 63u) == 0 && v) atomicOr(out, v);
 }
+// ---------------------------------------------------------------------------------------------
+// Multisample K4' / K5' (bam_utils_multisample.py:503-636, 737-791) from the (EC, cell, file) triples: cell order = insertion
+// order of the reference's cr_totals (files in order; within a file ECs by first appearance there; within an EC cells by
+// first appearance), per-cell totals, minimum-count filter, EC re-rank, CSC N, rows of A that survive.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_msf_keys_fe(const u32* ec, const u32* meta, u64 n, u64* key, u32* val) {          // (file, EC) of every triple
+    const u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (t < n) { key[t] = ((u64)(meta[t] >> ECB_CELL_BITS) << 32) | ec[t]; val[t] = (u32)t; }
+}
+__global__ void k_msf_runfix(const u32* flag, u32* runid, u64 n) {       // exclusive scan of head flags -> index of the run an element is in
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n && !flag[i]) runid[i] -= 1u;
+}
+__global__ void k_msf_runmin(const u32* val, const u32* runid, const u32* first, u64 n, u32* runmin) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n) atomicMin(&runmin[runid[i]], first[val[i]]);
+}
+__global__ void k_msf_spread(const u32* val, const u32* runid, const u32* runmin, u64 n, u32* fec) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n) fec[val[i]] = runmin[runid[i]];
+}
+__global__ void k_msf_keys_cell(const u32* meta, u64 n, u64* key, u32* val) {
+    const u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (t < n) { key[t] = meta[t] & ((1u << ECB_CELL_BITS) - 1u); val[t] = (u32)t; }
+}
+__global__ void k_msf_runstart(const u32* flag, const u32* runid, u64 n, u32* start, u32 n_runs) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) start[runid[i]] = (u32)i;
+    if (i == 0) start[n_runs] = (u32)n;
+}
+// one workgroup per cell: reads in it, and the earliest (file, first appearance of the EC in that file, first read) among its triples
+__global__ __launch_bounds__(TPB) void k_msf_cell(const u64* skey, const u32* sval, const u32* start, const u32* meta, const u32* cnt,
+                                                  const u32* fec, const u32* first, u32* cell_id, u64* total, u64* best_hi, u64* best_lo) {
+    const u32 c = blockIdx.x, a = start[c], b = start[c + 1];
+    u64 sum = 0, bh = ~0ull, bl = ~0ull;
+    for (u32 i = a + threadIdx.x; i < b; i += TPB) {
+        const u32 t = sval[i];
+        sum += cnt[t];
+        const u64 hi = meta[t] >> ECB_CELL_BITS, lo = ((u64)fec[t] << 32) | first[t];
+        if (hi < bh || (hi == bh && lo < bl)) { bh = hi; bl = lo; }
+    }
+    __shared__ u64 s_sum[TPB / 64], s_h[TPB / 64], s_l[TPB / 64];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        sum += __shfl_xor(sum, d);
+        const u64 oh = __shfl_xor(bh, d), ol = __shfl_xor(bl, d);
+        if (oh < bh || (oh == bh && ol < bl)) { bh = oh; bl = ol; }
+    }
+    if ((threadIdx.x & 63u) == 0) { s_sum[threadIdx.x >> 6] = sum; s_h[threadIdx.x >> 6] = bh; s_l[threadIdx.x >> 6] = bl; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < TPB / 64; ++w) {
+            sum += s_sum[w];
+            if (s_h[w] < bh || (s_h[w] == bh && s_l[w] < bl)) { bh = s_h[w]; bl = s_l[w]; }
+        }
+        cell_id[c] = (u32)skey[a]; total[c] = sum; best_hi[c] = bh; best_lo[c] = bl;
+    }
+}
+__global__ void k_msf_iota(u32* v, u64 n) { const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; if (i < n) v[i] = (u32)i; }
+__global__ void k_msf_gather64(const u64* src, const u32* idx, u64 n, u64* dst) { const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; if (i < n) dst[i] = src[idx[i]]; }
+__global__ void k_msf_keepflag(const u32* order, const u64* total, u64 n, u64 min_count, u32* flag) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = total[order[i]] >= min_count ? 1u : 0u;
+}
+__global__ void k_msf_newcell(const u32* order, const u32* flag, const u32* pos, const u32* cell_id, u64 n, u32* new_cell, u32* kept_cells) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) { const u32 c = cell_id[order[i]]; new_cell[c] = pos[i]; kept_cells[pos[i]] = c; }
+}
+__global__ void k_msf_mark(const u32* ec, const u32* meta, const u32* new_cell, u64 n, u32* keep_ec, u32* kt) {
+    const u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const bool k = new_cell[meta[t] & ((1u << ECB_CELL_BITS) - 1u)] != 0xFFFFFFFFu;
+    kt[t] = k ? 1u : 0u;
+    if (k) keep_ec[ec[t]] = 1u;
+}
+__global__ void k_msf_nkeys(const u32* ec, const u32* meta, const u32* cnt, const u32* kt, const u32* kpos, const u32* new_cell,
+                            const u32* new_rank, u64 n, u64* key, u32* val) {
+    const u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (t < n && kt[t]) {
+        key[kpos[t]] = ((u64)new_cell[meta[t] & ((1u << ECB_CELL_BITS) - 1u)] << 32) | new_rank[ec[t]];
+        val[kpos[t]] = cnt[t];
+    }
+}
+__global__ void k_msf_nemit(const u64* key, const u32* val, const u32* flag, const u32* pos, u64 n, int* indices, int* data) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 o = pos[i] - (flag[i] ? 0u : 1u);                      // pos = exclusive scan of the head flags
+    if (flag[i]) indices[o] = (int)(u32)key[i];
+    atomicAdd(&data[o], (int)val[i]);
+}
+__global__ void k_msf_nptr(const u64* key, const u32* pos, u64 n, u32 nnz, u32 n_cells, int* indptr) {
+    const u64 c = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (c > n_cells) return;
+    const u64 at = lower_bound_u64(key, n, (u64)c << 32);
+    indptr[c] = at < n ? (int)pos[at] : (int)nnz;                    // pos[] = index of the run that starts at or after `at`
+}
+__global__ void k_msf_rowlen(const u32* indptr, const u32* keep_ec, const u32* new_rank, u64 n_ecs, u32* rowlen2) {
+    const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (e < n_ecs && keep_ec[e]) rowlen2[new_rank[e]] = indptr[e + 1] - indptr[e];
+}
+__global__ void k_msf_rows(const u32* indptr, const int* indices, const int* data, const u32* keep_ec, const u32* new_rank,
+                           const u32* indptr2, u64 n_ecs, int* indices2, int* data2) {
+    const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (e >= n_ecs || !keep_ec[e]) return;
+    const u32 a = indptr[e], b = indptr[e + 1], o = indptr2[new_rank[e]];
+    for (u32 i = a; i < b; ++i) { indices2[o + (i - a)] = indices[i]; data2[o + (i - a)] = data[i]; }
+}
 __global__ void k_widen(const u32* in, u64 n, u64* out) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i < n) out[i] = in[i];
@@ -2012,6 +2119,9 @@ struct ecb_handle {
     u32* meta = nullptr; u64 meta_cap = 0, meta_hi = 0;   // multisample: cell | file << 22 per read
     u64 n_triples = 0; u64* ms_okey = nullptr; u32 *ms_ofirst = nullptr, *ms_ostart = nullptr, *ms_ocount = nullptr;
     bool ms_adopted = false;          // the triples came from ecb_ms_adopt_triples_device (multi-GPU)
+    // ecb_ms_filter's results (device): kept cells in sample order, rows of A of the kept ECs, CSC N
+    bool ms_filtered = false; ecb_ms_sizes msf{};
+    u32* f_cells = nullptr; int *f_ipa = nullptr, *f_ixa = nullptr, *f_daa = nullptr, *f_ipn = nullptr, *f_ixn = nullptr, *f_dan = nullptr;
     int *rng_min = nullptr, *rng_max = nullptr;
     u64* queue = nullptr; u64 queue_cap = 0;
     u64 n_ecs() const { return hctr.n_ecs; }
@@ -2035,7 +2145,8 @@ struct ecb_handle {
     enum { P_RESUME, P_SUMS, P_HIST, P_OFFS, P_PAIRS, P_CNT, P_PARTS, P_STARTS, P_WORK, P_LIST, P_BITMAP, P_WPOP, P_WPREFIX, P_ROWLEN, P_ORDER,
            P_WCOUNTS, P_RANK, P_INDPTR, P_COUNTS, P_INDICES, P_DATA, P_MS_KEYS, P_MS_KEYS2, P_MS_VALS, P_MS_VALS2, P_MS_TMP,
            P_MS_FLAG, P_MS_POS, P_MS_OKEY, P_MS_OFIRST, P_MS_OSTART, P_MS_X, P_MS_OCOUNT, P_MS_GRANK, P_MS_CIN, P_MS_FIN, P_LISTFN,
-           P_REMAP, P_TOTALS, P_SLOW_LEN, P_SLOW_OFF, P_SLOW_NRE, P_SLOW_REQ, P_SLOW_REQ2, P_SLOW_KEY, P_SLOW_MASK, P_BIG, P_RS_HIST, P_RS_OFFS, P_RS_SUMS, P_N };
+           P_REMAP, P_TOTALS, P_SLOW_LEN, P_SLOW_OFF, P_SLOW_NRE, P_SLOW_REQ, P_SLOW_REQ2, P_SLOW_KEY, P_SLOW_MASK, P_BIG, P_RS_HIST, P_RS_OFFS, P_RS_SUMS,
+           P_F_CELLS, P_F_IPA, P_F_IXA, P_F_DAA, P_F_IPN, P_F_IXN, P_F_DAN, P_N };
     void* pool[P_N] = {}; u64 pool_bytes[P_N] = {};
 
     // profiling
@@ -2072,6 +2183,11 @@ int pool_get(ecb_handle* h, int id, u64 count, T** out) {
     *out = reinterpret_cast<T*>(h->pool[id]);
     return ECB_OK;
 }
+struct Scratch {                       // frees what it allocated
+    std::vector<void*> p;
+    template <class T> T* get(u64 n) { void* q = nullptr; if (hipMalloc(&q, std::max<u64>(n, 1) * sizeof(T)) != hipSuccess) return nullptr; p.push_back(q); return (T*)q; }
+    ~Scratch() { for (void* q : p) hipFree(q); }
+};
 #define POOL(h, id, ptr, count) do { int rc_ = pool_get(h, ecb_handle::id, count, &(ptr)); if (rc_ != ECB_OK) return rc_; } while (0)
 
 // zero the device counters and point every arena region's cursor at its first pair
@@ -2666,7 +2782,7 @@ int ecb_reset(ecb_handle* h) {
     h->extra_all = h->extra_valid = h->extra_reads = 0;
     h->c_rid.clear(); h->c_loc.clear(); h->c_hf.clear(); h->c_pos.clear();
     h->finalized = false; h->counted = false; h->adopted = false; h->sizes = ecb_sizes{}; h->n_list = 0;
-    h->n_mismatch = 0;
+    h->n_mismatch = 0; h->ms_filtered = false;
     return ECB_OK;
 }
 
@@ -3150,6 +3266,121 @@ int ecb_ms_adopt_triples_device(ecb_handle* h, uint32_t n_tables, const void* co
     return ECB_OK;
 }
 
+int ecb_ms_filter(ecb_handle* h, uint32_t n_cells, int64_t minimum_count, ecb_ms_sizes* out) {
+    if (!h || !out) return ECB_ERR_ARG;
+    if (!h->finalized || !(h->cfg.flags & ECB_F_MULTISAMPLE)) return fail(h, ECB_ERR_STATE, "no multisample result");
+    if (h->adopted && !h->ms_adopted) return fail(h, ECB_ERR_STATE, "multisample across GPUs: no triples adopted yet (ecb_ms_adopt_triples_device)");
+    if (!n_cells || n_cells > (1u << ECB_CELL_BITS)) return fail(h, ECB_ERR_ARG, "n_cells out of range");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const u64 T = h->n_triples, E = h->sizes.n_ecs;
+    const u64 min_count = minimum_count <= 0 ? 1ull : (u64)minimum_count;          // bam_utils_multisample.py:596-597
+    if (!T) return fail(h, ECB_ERR_EMPTY, "no (EC, cell) counts: nothing to filter");
+    Scratch sc;
+    u32 *ec = sc.get<u32>(T), *meta = sc.get<u32>(T), *cnt = sc.get<u32>(T), *fec = sc.get<u32>(T);
+    u64 *k0 = sc.get<u64>(T), *k1 = sc.get<u64>(T);
+    u32 *v0 = sc.get<u32>(T), *v1 = sc.get<u32>(T), *flag = sc.get<u32>(T), *runid = sc.get<u32>(T), *runmin = sc.get<u32>(T + 1);
+    if (!ec || !meta || !cnt || !fec || !k0 || !k1 || !v0 || !v1 || !flag || !runid || !runmin) return fail(h, ECB_ERR_HIP, "out of device memory");
+    k_ms_split<<<nblk(T, TPB), TPB, 0, st>>>(h->ms_okey, h->ms_ostart, h->ms_ocount, T, ec, meta, cnt);
+    const u32* first = h->ms_ofirst;
+    int rc, where = 0;
+    u64 tot = 0;
+    // 1. first appearance of every EC in every file: group the triples by (file, EC), minimum of their first reads
+    k_msf_keys_fe<<<nblk(T, TPB), TPB, 0, st>>>(ec, meta, T, k0, v0);
+    { u64* kk[2] = {k0, k1}; u32* vv[2] = {v0, v1}; rc = handle_sort(h, kk, vv, T, &where); if (rc != ECB_OK) return rc;
+      k_ms_heads<<<nblk(T, TPB), TPB, 0, st>>>(kk[where], T, flag);
+      rc = excl_scan(h, flag, T, runid, &tot); if (rc != ECB_OK) return rc;
+      // runid[i] = heads before i; the run of i is that, minus one unless i is a head itself -- fold it in place
+      k_msf_runfix<<<nblk(T, TPB), TPB, 0, st>>>(flag, runid, T);
+      HIPCHK(h, hipMemsetAsync(runmin, 0xFF, (tot + 1) * 4, st));
+      k_msf_runmin<<<nblk(T, TPB), TPB, 0, st>>>(vv[where], runid, first, T, runmin);
+      k_msf_spread<<<nblk(T, TPB), TPB, 0, st>>>(vv[where], runid, runmin, T, fec); }
+    // 2. per cell: reads, and the earliest (file, EC's first appearance in the file, first read) -- its place in the cell order
+    k_msf_keys_cell<<<nblk(T, TPB), TPB, 0, st>>>(meta, T, k0, v0);
+    u64 n_runs = 0;
+    u64* skey = nullptr; u32* sval = nullptr;
+    { u64* kk[2] = {k0, k1}; u32* vv[2] = {v0, v1}; rc = handle_sort(h, kk, vv, T, &where); if (rc != ECB_OK) return rc;
+      skey = kk[where]; sval = vv[where];
+      k_ms_heads<<<nblk(T, TPB), TPB, 0, st>>>(skey, T, flag);
+      rc = excl_scan(h, flag, T, runid, &n_runs); if (rc != ECB_OK) return rc;
+      k_msf_runfix<<<nblk(T, TPB), TPB, 0, st>>>(flag, runid, T); }
+    const u64 C = n_runs;                                    // cells that have reads
+    u32 *cstart = sc.get<u32>(C + 1), *cell_id = sc.get<u32>(C), *corder = sc.get<u32>(C), *corder2 = sc.get<u32>(C), *cflag = sc.get<u32>(C), *cpos = sc.get<u32>(C);
+    u64 *ctotal = sc.get<u64>(C), *bhi = sc.get<u64>(C), *blo = sc.get<u64>(C), *ck0 = sc.get<u64>(C), *ck1 = sc.get<u64>(C);
+    u32* new_cell = sc.get<u32>(n_cells);
+    if (!cstart || !cell_id || !corder || !corder2 || !cflag || !cpos || !ctotal || !bhi || !blo || !ck0 || !ck1 || !new_cell) return fail(h, ECB_ERR_HIP, "out of device memory");
+    k_msf_runstart<<<nblk(T, TPB), TPB, 0, st>>>(flag, runid, T, cstart, (u32)C);
+    k_msf_cell<<<(unsigned)C, TPB, 0, st>>>(skey, sval, cstart, meta, cnt, fec, first, cell_id, ctotal, bhi, blo);
+    // 3. cell order: by (first appearance of the EC in the file, first read), then -- stable -- by file
+    k_msf_iota<<<nblk(C, TPB), TPB, 0, st>>>(corder, C);
+    HIPCHK(h, hipMemcpyAsync(ck0, blo, C * 8, hipMemcpyDeviceToDevice, st));
+    u32* ord = nullptr;
+    { u64* kk[2] = {ck0, ck1}; u32* vv[2] = {corder, corder2}; rc = handle_sort(h, kk, vv, C, &where); if (rc != ECB_OK) return rc;
+      u32* o1 = vv[where]; u32* o2 = vv[where ^ 1]; u64* ka = kk[where ^ 1]; u64* kb = kk[where];
+      k_msf_gather64<<<nblk(C, TPB), TPB, 0, st>>>(bhi, o1, C, ka);
+      u64* kk2[2] = {ka, kb}; u32* vv2[2] = {o1, o2}; rc = handle_sort(h, kk2, vv2, C, &where); if (rc != ECB_OK) return rc;
+      ord = vv2[where]; }
+    k_msf_keepflag<<<nblk(C, TPB), TPB, 0, st>>>(ord, ctotal, C, min_count, cflag);
+    u64 S = 0;
+    rc = excl_scan(h, cflag, C, cpos, &S); if (rc != ECB_OK) return rc;
+    if (!S) return fail(h, ECB_ERR_EMPTY, "no cell reaches the minimum count");
+    POOL(h, P_F_CELLS, h->f_cells, S);
+    HIPCHK(h, hipMemsetAsync(new_cell, 0xFF, (u64)n_cells * 4, st));
+    k_msf_newcell<<<nblk(C, TPB), TPB, 0, st>>>(ord, cflag, cpos, cell_id, C, new_cell, h->f_cells);
+    // 4. ECs that keep a cell, re-ranked (bam_utils_multisample.py:611-636)
+    u32 *keep_ec = sc.get<u32>(E), *new_rank = sc.get<u32>(E), *kt = flag, *kpos = runid;
+    if (!keep_ec || !new_rank) return fail(h, ECB_ERR_HIP, "out of device memory");
+    HIPCHK(h, hipMemsetAsync(keep_ec, 0, E * 4, st));
+    k_msf_mark<<<nblk(T, TPB), TPB, 0, st>>>(ec, meta, new_cell, T, keep_ec, kt);
+    u64 E2 = 0, K = 0;
+    rc = excl_scan(h, keep_ec, E, new_rank, &E2); if (rc != ECB_OK) return rc;
+    rc = excl_scan(h, kt, T, kpos, &K); if (rc != ECB_OK) return rc;
+    // 5. N as CSC over (kept EC, kept cell): the same cell's reads of one EC in several files add up (:737-791)
+    k_msf_nkeys<<<nblk(T, TPB), TPB, 0, st>>>(ec, meta, cnt, kt, kpos, new_cell, new_rank, T, k0, v0);
+    u64 nnz_n = 0;
+    { u64* kk[2] = {k0, k1}; u32* vv[2] = {v0, v1}; rc = handle_sort(h, kk, vv, K, &where); if (rc != ECB_OK) return rc;
+      u32* hflag = sc.get<u32>(K), *hpos = sc.get<u32>(K);
+      if (!hflag || !hpos) return fail(h, ECB_ERR_HIP, "out of device memory");
+      k_ms_heads<<<nblk(K, TPB), TPB, 0, st>>>(kk[where], K, hflag);
+      rc = excl_scan(h, hflag, K, hpos, &nnz_n); if (rc != ECB_OK) return rc;
+      if (nnz_n >= (1ull << 31)) return fail(h, ECB_ERR_LIMIT, "N has more than 2^31-1 non-zeros");
+      POOL(h, P_F_IPN, h->f_ipn, S + 1); POOL(h, P_F_IXN, h->f_ixn, nnz_n); POOL(h, P_F_DAN, h->f_dan, nnz_n);
+      HIPCHK(h, hipMemsetAsync(h->f_dan, 0, nnz_n * 4, st));
+      k_msf_nemit<<<nblk(K, TPB), TPB, 0, st>>>(kk[where], vv[where], hflag, hpos, K, h->f_ixn, h->f_dan);
+      k_msf_nptr<<<nblk(S + 1, TPB), TPB, 0, st>>>(kk[where], hpos, K, (u32)nnz_n, (u32)S, h->f_ipn); }
+    // 6. the rows of A of the ECs that are left
+    u32* rowlen2 = sc.get<u32>(E2 + 1);
+    if (!rowlen2) return fail(h, ECB_ERR_HIP, "out of device memory");
+    POOL(h, P_F_IPA, h->f_ipa, E2 + 1);
+    k_msf_rowlen<<<nblk(E, TPB), TPB, 0, st>>>(h->indptr, keep_ec, new_rank, E, rowlen2);
+    u64 nnz_a = 0;
+    rc = excl_scan(h, rowlen2, E2, reinterpret_cast<u32*>(h->f_ipa), &nnz_a); if (rc != ECB_OK) return rc;
+    { const u32 last = (u32)nnz_a; HIPCHK(h, hipMemcpyAsync(h->f_ipa + E2, &last, 4, hipMemcpyHostToDevice, st)); HIPCHK(h, hipStreamSynchronize(st)); }
+    POOL(h, P_F_IXA, h->f_ixa, nnz_a); POOL(h, P_F_DAA, h->f_daa, nnz_a);
+    k_msf_rows<<<nblk(E, TPB), TPB, 0, st>>>(h->indptr, h->indices, h->data, keep_ec, new_rank, reinterpret_cast<const u32*>(h->f_ipa), E, h->f_ixa, h->f_daa);
+    HIPCHK(h, hipStreamSynchronize(st));
+    h->msf.n_cells_seen = C; h->msf.n_cells_kept = S; h->msf.n_ecs_kept = E2; h->msf.nnz_a = nnz_a; h->msf.nnz_n = nnz_n;
+    h->ms_filtered = true;
+    *out = h->msf;
+    return ECB_OK;
+}
+
+int ecb_ms_export(ecb_handle* h, uint32_t* kept_cells, int32_t* ia, int32_t* ja, int32_t* da, int32_t* in_, int32_t* jn, int32_t* dn) {
+    if (!h) return ECB_ERR_ARG;
+    if (!h->ms_filtered) return fail(h, ECB_ERR_STATE, "ecb_ms_export before ecb_ms_filter");
+    HIPCHK(h, hipSetDevice(h->device));
+    const ecb_ms_sizes& m = h->msf;
+    if (kept_cells) HIPCHK(h, hipMemcpyAsync(kept_cells, h->f_cells, m.n_cells_kept * 4, hipMemcpyDeviceToHost, h->stream));
+    if (ia) HIPCHK(h, hipMemcpyAsync(ia, h->f_ipa, (m.n_ecs_kept + 1) * 4, hipMemcpyDeviceToHost, h->stream));
+    if (ja) HIPCHK(h, hipMemcpyAsync(ja, h->f_ixa, m.nnz_a * 4, hipMemcpyDeviceToHost, h->stream));
+    if (da) HIPCHK(h, hipMemcpyAsync(da, h->f_daa, m.nnz_a * 4, hipMemcpyDeviceToHost, h->stream));
+    if (in_) HIPCHK(h, hipMemcpyAsync(in_, h->f_ipn, (m.n_cells_kept + 1) * 4, hipMemcpyDeviceToHost, h->stream));
+    if (jn) HIPCHK(h, hipMemcpyAsync(jn, h->f_ixn, m.nnz_n * 4, hipMemcpyDeviceToHost, h->stream));
+    if (dn) HIPCHK(h, hipMemcpyAsync(dn, h->f_dan, m.nnz_n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ECB_OK;
+}
+
 int ecb_counters(ecb_handle* h, uint64_t* all_alignments, uint64_t* valid_alignments, uint64_t* n_reads) {
     if (!h) return ECB_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
@@ -3189,11 +3420,6 @@ int ecb_profile_read(ecb_handle* h, double* ms, uint64_t* launches, uint64_t* re
 
 // ---- f-2 conversions (stateless; scratch is allocated per call: this is not the hot path) ------------------------
 namespace {
-struct Scratch {                       // frees what it allocated
-    std::vector<void*> p;
-    template <class T> T* get(u64 n) { void* q = nullptr; if (hipMalloc(&q, std::max<u64>(n, 1) * sizeof(T)) != hipSuccess) return nullptr; p.push_back(q); return (T*)q; }
-    ~Scratch() { for (void* q : p) hipFree(q); }
-};
 int cv_scan(hipStream_t st, const u32* in, u64 n, u32* out, u64* total, Scratch& sc) {
     const u64 nb = std::max<u64>(1, (n + SCAN_BLOCK - 1) / SCAN_BLOCK);
     u32* sums = sc.get<u32>(nb + 4);

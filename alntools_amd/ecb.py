@@ -26,7 +26,8 @@ FLAG_NEXT_POS_NEG = 0x2000
 #: every symbol include/ecb.h declares
 SYMBOLS = ("ecb_abi_version", "ecb_device_count", "ecb_create", "ecb_destroy", "ecb_reset", "ecb_last_error",
            "ecb_push", "ecb_push_device", "ecb_push_cells", "ecb_verify_device", "ecb_finalize", "ecb_export",
-           "ecb_export_device", "ecb_export_ranges", "ecb_export_range_minmax", "ecb_export_pairs", "ecb_export_read_ec", "ecb_table_sizes",
+           "ecb_export_device", "ecb_export_ranges", "ecb_export_range_minmax", "ecb_export_pairs", "ecb_ms_filter", "ecb_ms_export",
+           "ecb_export_read_ec", "ecb_table_sizes",
            "ecb_table_export_device", "ecb_table_merge_device", "ecb_table_export_parts_device",
            "ecb_table_adopt_device", "ecb_table_merge_batch_device", "ecb_table_adopt_batch_device",
            "ecb_export_ec_keys_device", "ecb_ms_local_triples_device", "ecb_ms_adopt_triples_device", "ecb_counters", "ecb_add_counters", "ecb_profile",
@@ -50,6 +51,11 @@ class Sizes(C.Structure):
     _fields_ = [("n_ecs", C.c_uint64), ("nnz_a", C.c_uint64), ("n_samples", C.c_uint64),
                 ("nnz_n", C.c_uint64), ("all_alignments", C.c_uint64), ("valid_alignments", C.c_uint64),
                 ("n_reads", C.c_uint64)]
+
+
+class MsSizes(C.Structure):
+    _fields_ = [("n_cells_seen", C.c_uint64), ("n_cells_kept", C.c_uint64), ("n_ecs_kept", C.c_uint64),
+                ("nnz_a", C.c_uint64), ("nnz_n", C.c_uint64)]
 
 
 _lib = None
@@ -91,6 +97,8 @@ def load():
     lib.ecb_export_read_ec.argtypes = [vp, vp]
     lib.ecb_export_pairs.argtypes = [vp, vp, vp, vp, vp]
     lib.ecb_export_range_minmax.argtypes = [vp, vp, vp]
+    lib.ecb_ms_filter.argtypes = [vp, C.c_uint32, C.c_int64, C.POINTER(MsSizes)]
+    lib.ecb_ms_export.argtypes = [vp] + [vp] * 7
     lib.ecb_table_sizes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     lib.ecb_table_export_device.argtypes = [vp, vp, vp, u64]
     lib.ecb_table_merge_device.argtypes = [vp, vp, u64, vp, u64]
@@ -261,6 +269,21 @@ class EcBuilder(object):
         self._chk(self._lib.ecb_export_pairs(self._h, _ptr(ec), _ptr(meta), _ptr(cnt), _ptr(first)))
         return dict(ec=ec.astype(np.int64), cell=(meta & ((1 << 22) - 1)).astype(np.int64), file=(meta >> 22).astype(np.int64),
                     count=cnt.astype(np.int64), first=first.astype(np.int64))
+
+    def ms_filter(self, n_cells, minimum_count):
+        """Multisample, after finalize: cell order, minimum-count filter, EC re-rank, CSC N and the surviving rows of A, on
+        the device (``bam_utils_multisample.py:596-636, 737-791``) -> dict(kept_cells [cell ids in sample order], indptrA,
+        indicesA, dataA, indptrN, indicesN, dataN, n_cells_seen)."""
+        m = MsSizes()
+        self._chk(self._lib.ecb_ms_filter(self._h, n_cells, minimum_count, C.byref(m)))
+        S, E2, nnza, nnzn = int(m.n_cells_kept), int(m.n_ecs_kept), int(m.nnz_a), int(m.nnz_n)
+        out = dict(kept_cells=np.empty(S, np.uint32), indptrA=np.empty(E2 + 1, np.int32), indicesA=np.empty(nnza, np.int32),
+                   dataA=np.empty(nnza, np.int32), indptrN=np.empty(S + 1, np.int32), indicesN=np.empty(nnzn, np.int32),
+                   dataN=np.empty(nnzn, np.int32))
+        self._chk(self._lib.ecb_ms_export(self._h, *[_ptr(out[k]) for k in
+                                                     ("kept_cells", "indptrA", "indicesA", "dataA", "indptrN", "indicesN", "dataN")]))
+        out["n_cells_seen"] = int(m.n_cells_seen)
+        return out
 
     def export_ranges(self):
         out = np.empty((self.n_loci, self.n_haplotypes), np.int64)

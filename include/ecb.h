@@ -136,6 +136,23 @@ int ecb_export_range_minmax(ecb_handle* h, int32_t* range_min, int32_t* range_ma
  * ec[key][cell] per worker (bam_utils_multisample.py:288-290, 503-576).  Cell order, the minimum-count filter
  * and the CSC N matrix (:596-636, 737-791) are metadata-sized work done by the host from these. */
 int ecb_export_pairs(ecb_handle* h, uint32_t* ec, uint32_t* meta, uint32_t* count, uint32_t* first_read);
+/* Multisample, after ecb_finalize: what the reference does with its merged ec[key][cell] dicts (bam_utils_multisample.py:
+ * 596-636, 737-791), on the device, from those triples: cells in the insertion order of the reference's cr_totals (files in
+ * order; within a file ECs by first appearance there; within an EC cells by first appearance), cells with fewer than
+ * minimum_count reads (<= 0 means 1) dropped, ECs left without a cell dropped and the rest re-ranked, N as CSC over
+ * (kept EC, kept cell), and the rows of A of the kept ECs.  n_cells = number of cell ids the host handed out.
+ * ecb_ms_export fills caller buffers of the sizes ecb_ms_filter reported: kept_cells[n_cells_kept] = cell ids in sample
+ * order; A as CSR (n_ecs_kept + 1, nnz_a, nnz_a); N as CSC (n_cells_kept + 1, nnz_n, nnz_n).  Any pointer may be NULL. */
+typedef struct ecb_ms_sizes {
+    uint64_t n_cells_seen;       /* cells with at least one read */
+    uint64_t n_cells_kept;       /* S */
+    uint64_t n_ecs_kept;         /* E after the filter */
+    uint64_t nnz_a;
+    uint64_t nnz_n;
+} ecb_ms_sizes;
+int ecb_ms_filter(ecb_handle* h, uint32_t n_cells, int64_t minimum_count, ecb_ms_sizes* out);
+int ecb_ms_export(ecb_handle* h, uint32_t* kept_cells, int32_t* indptr_a, int32_t* indices_a, int32_t* data_a,
+                  int32_t* indptr_n, int32_t* indices_n, int32_t* data_n);
 /* EC index of every read, in read order (n_reads values). */
 int ecb_export_read_ec(ecb_handle* h, int32_t* ec_of_read);
 

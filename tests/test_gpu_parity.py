@@ -673,6 +673,51 @@ def test_multisample_triples_at_scale():
     assert np.array_equal(pr["first"], exp_first)
 
 
+@pytest.mark.parametrize("mincount", [-1, "median", "p90", 10**7])
+def test_multisample_filter_on_device_matches_the_numpy_checker(mincount):
+    """K4' / K5' (bam_utils_multisample.py:596-636, 737-791) on the device -- cell order, minimum-count filter, EC re-rank,
+    CSC N, surviving rows of A -- against the numpy restatement of the same reduction (tests/ms_checker.py) on the triples
+    the handle exports: 6 M reads, 1 500 cells whose reads are spread over 3 files, thresholds that keep all, most, few and
+    none of the cells."""
+    import torch
+    from ms_checker import reduce_triples, select_rows
+    R, T, H = 6_000_000, 20_000, 8
+    spec = synth.SynthSpec(R, T, H, paired=True)
+    dev = torch.device("cuda:0")
+    t = synth.generate(spec, 0, R, device=dev)
+    n_reads = t["n_reads"]
+    x = (np.arange(n_reads, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(20)
+    cell = ((x % np.uint64(1500)) * (x % np.uint64(1500)) // np.uint64(1500)).astype(np.uint32)      # skewed cell sizes
+    fil = (np.arange(n_reads, dtype=np.uint64) * np.uint64(3) // np.uint64(n_reads)).astype(np.uint32)   # 3 files, contiguous
+    # cell ids are handed out in order of first appearance, as convert_files does
+    _, first_idx, inv = np.unique(cell, return_index=True, return_inverse=True)
+    rank = np.empty(len(first_idx), dtype=np.uint32)
+    rank[np.argsort(first_idx)] = np.arange(len(first_idx), dtype=np.uint32)
+    cell = rank[inv]
+    n_cells = int(cell.max()) + 1
+    if isinstance(mincount, str):                                    # a threshold that keeps half / a tenth of the cells
+        mincount = int(np.quantile(np.bincount(cell), 0.5 if mincount == "median" else 0.9)) + 1
+    with ecb.EcBuilder(T, H, multisample=True, ec_capacity=1 << 21) as b:
+        b.push_device(t["read_id"], t["locus"], t["hapflag"])
+        b.push_cells(cell | (fil << np.uint32(22)), 0)
+        s = b.finalize()
+        a = b.export()
+        tr = b.export_pairs()
+        if mincount == 10**7:
+            with pytest.raises(ecb.EcbError) as e:
+                b.ms_filter(n_cells, mincount)
+            assert e.value.code == -7
+            return
+        f = b.ms_filter(n_cells, mincount)
+    kept, ec_keep, (n_ptr, n_idx, n_dat) = reduce_triples(tr, s["n_ecs"], n_cells, mincount)
+    a_ptr, a_idx, a_dat = select_rows(a["indptrA"], a["indicesA"], a["dataA"], ec_keep)
+    assert f["kept_cells"].tolist() == kept and 0 < len(kept) <= n_cells
+    if mincount > 0:
+        assert len(kept) < n_cells
+    for k, exp in (("indptrA", a_ptr), ("indicesA", a_idx), ("dataA", a_dat), ("indptrN", n_ptr), ("indicesN", n_idx), ("dataN", n_dat)):
+        assert np.array_equal(f[k], exp), k
+
+
 def test_multisample_over_shards_equals_one_handle():
     """Multisample across GPUs, device side on one card: three contiguous read shards (every cell has reads in all of them),
     ECs merged by key range and adopted by a multisample root, the root's EC keys looked up by every shard
