@@ -87,47 +87,9 @@ def stream_bam_to_builder(bam_filename, builder, maps=None, target_filename=None
             reader.close()
 
 
-def convert(bam_filename, ec_filename, emase_filename, num_chunks=0, number_processes=-1, temp_dir=None,
-            range_filename=None, sample=None, target_filename=None):
-    """BAM -> EC ``.bin`` and/or EMASE ``.h5`` (same arguments and outputs as ``bam_utils.convert``)."""
-    start_time = time.time()
-    if sample is None:
-        sample = os.path.basename(bam_filename)                      # bam_utils.py:552-554
-        LOG.info("Sample not supplied, using filename: {}".format(sample))
-    elif isinstance(sample, bytes):
-        sample = sample.decode('ascii', 'ignore')
-    LOG.info("Parsing file information ...")
-    reader = open_bam(bam_filename)
-    targets = None
-    if target_filename:
-        targets = list(utils.parse_targets(target_filename).keys())
-        if len(targets) == 0:
-            raise ValueError("Unable to parse target file")
-    maps = HeaderMaps(reader.references, reader.lengths, targets)
-    device = int(os.environ.get("ALNTOOLS_GPU", "0"))
-    temp_time = time.time()
-    with EcBuilder(maps.n_loci, maps.n_haplotypes, device=device, track_ranges=range_filename is not None) as b:
-        enc = TupleEncoder(maps)
-        while True:
-            q, flag, tid, pos, ntid, npos = reader.read_batch(BATCH_RECORDS)
-            if not q:
-                break
-            t = enc.encode(q, flag, tid, pos, ntid, npos)
-            b.push(t["read_id"], t["locus"], t["hapflag"], t["pos"] if range_filename else None)
-        reader.close()
-        sizes = b.finalize()
-        out = b.export()
-        LOG.info("All results combined in {}, total time: {}".format(utils.format_time(temp_time, time.time()),
-                                                                     utils.format_time(start_time, time.time())))
-        LOG.info("# Valid Alignments: {:,}".format(sizes["valid_alignments"]))
-        LOG.info("# Main Targets: {:,}".format(maps.n_loci))
-        LOG.info("# Haplotypes: {:,}".format(maps.n_haplotypes))
-        LOG.info("# Equivalence Classes: {:,}".format(sizes["n_ecs"]))
-        # the reference logs the number of distinct tracked names, which misses a trailing one-alignment
-        # read (bam_utils.py:296-306); this is the number of reads actually counted
-        LOG.info("# Unique Reads: {:,}".format(sizes["n_reads"]))
-        if range_filename:
-            write_range_file(range_filename, maps, b.export_ranges())
+def _write_outputs(maps, sample, sizes, out, range_len, ec_filename, emase_filename, range_filename):
+    if range_filename:
+        write_range_file(range_filename, maps, range_len)
     m = ECMatrices(maps.haplotypes, maps.main_targets, maps.lengths, [sample], out["indptrA"], out["indicesA"],
                    out["dataA"], out["indptrN"], out["indicesN"], out["dataN"])
     if emase_filename:
@@ -145,5 +107,149 @@ def convert(bam_filename, ec_filename, emase_filename, num_chunks=0, number_proc
         except OSError:
             pass
         ecsave2(ec_filename, m)
+
+
+def _log_summary(maps, sizes):
+    LOG.info("# Valid Alignments: {:,}".format(sizes["valid_alignments"]))
+    LOG.info("# Main Targets: {:,}".format(maps.n_loci))
+    LOG.info("# Haplotypes: {:,}".format(maps.n_haplotypes))
+    LOG.info("# Equivalence Classes: {:,}".format(sizes["n_ecs"]))
+    # the reference logs the number of distinct tracked names, which misses a trailing one-alignment
+    # read (bam_utils.py:296-306); this is the number of reads actually counted
+    LOG.info("# Unique Reads: {:,}".format(sizes["n_reads"]))
+
+
+def _rank_convert(rank, world, port, backend, devices, bam_filename, ec_filename, emase_filename, range_filename, sample,
+                  target_filename, result_path):
+    """One process per GPU (the reference: one process per contiguous chunk range, ``bam_utils.py:646-680``): every rank
+    decodes the BAM, takes the contiguous read range ``[rank R / world, (rank + 1) R / world)``, builds its EC table on its
+    GPU; the tables are merged by key range over RCCL (``dist.exchange_and_merge``: the ordered merge of ``:680-724``) and
+    rank 0 finalizes and writes.  The decode is not shared: every rank reads the file (twice: reads are counted first)."""
+    import json
+    import torch
+    import torch.distributed as tdist
+    from . import dist as ecdist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev_index = devices[rank]
+    device = torch.device("cuda", dev_index)
+    torch.cuda.set_device(device)
+    if backend == "nccl":
+        tdist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    else:
+        tdist.init_process_group(backend, rank=rank, world_size=world)
+    targets = list(utils.parse_targets(target_filename).keys()) if target_filename else None
+    # pass 1: how many reads there are (name runs among valid records: only the host can tell)
+    reader = open_bam(bam_filename)
+    maps = HeaderMaps(reader.references, reader.lengths, targets)
+    enc = TupleEncoder(maps)
+    while True:
+        q, flag, tid, pos, ntid, npos = reader.read_batch(BATCH_RECORDS)
+        if not len(q):
+            break
+        enc.encode(q, flag, tid, pos, ntid, npos)
+    reader.close()
+    R = 0 if enc.cur == 0xFFFFFFFF else enc.cur + 1
+    r0, r1 = rank * R // world, (rank + 1) * R // world
+    wrap = lambda e: e if backend == "nccl" else ecdist.HostStagedEngine(e)
+    track = range_filename is not None
+    b = EcBuilder(maps.n_loci, maps.n_haplotypes, device=dev_index, track_ranges=track)
+    # pass 2: my reads.  A record belongs to the read whose id it carries (records before the first read: to rank 0).
+    reader = open_bam(bam_filename)
+    enc = TupleEncoder(maps)
+    while True:
+        q, flag, tid, pos, ntid, npos = reader.read_batch(BATCH_RECORDS)
+        if not len(q):
+            break
+        t = enc.encode(q, flag, tid, pos, ntid, npos)
+        rid = t["read_id"].astype(np.int64)
+        rid[rid == 0xFFFFFFFF] = -1
+        mine = (rid >= r0) & (rid < r1) if rank else (rid < r1)
+        if mine.any():
+            local = np.where(rid[mine] < 0, 0xFFFFFFFF, rid[mine] - r0).astype(np.uint32)
+            b.push(local, t["locus"][mine], t["hapflag"][mine], t["pos"][mine] if track else None)
+    reader.close()
+    eng = wrap(ecdist.GpuEngine(b, device))
+    fresh = lambda: wrap(ecdist.GpuEngine(EcBuilder(maps.n_loci, maps.n_haplotypes, device=dev_index, track_ranges=False), device))
+    merged = ecdist.exchange_and_merge(eng, fresh, fresh, root=0)
+    range_len = None
+    if track:
+        mn, mx = b.export_range_minmax()
+        range_len = ecdist.reduce_ranges(mn, mx, device=device if backend == "nccl" else None)
+    if rank == 0:
+        mb = merged.b
+        sizes = mb.finalize()
+        out = mb.export()
+        _log_summary(maps, sizes)
+        _write_outputs(maps, sample, sizes, out, range_len, ec_filename, emase_filename, range_filename)
+        with open(result_path, "w") as f:
+            json.dump(sizes, f)
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+def _convert_multi(n_gpus, bam_filename, ec_filename, emase_filename, range_filename, sample, target_filename):
+    """``ALNTOOLS_GPUS=N``: N processes, one per GPU, RCCL merge (``ALNTOOLS_DIST_BACKEND=gloo`` + ``ALNTOOLS_GPU_LIST=0,0``
+    rehearses the same protocol with several ranks on one GPU, tables staged through host memory)."""
+    import json
+    import socket
+    import tempfile
+    import torch.multiprocessing as mp
+    backend = os.environ.get("ALNTOOLS_DIST_BACKEND", "nccl")
+    devices = [int(x) for x in os.environ.get("ALNTOOLS_GPU_LIST", ",".join(str(i) for i in range(n_gpus))).split(",")]
+    if len(devices) != n_gpus:
+        raise ValueError("ALNTOOLS_GPU_LIST names %d devices for ALNTOOLS_GPUS=%d" % (len(devices), n_gpus))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    with tempfile.TemporaryDirectory() as td:
+        result = os.path.join(td, "sizes.json")
+        mp.spawn(_rank_convert, args=(n_gpus, port, backend, devices, bam_filename, ec_filename, emase_filename, range_filename,
+                                      sample, target_filename, result), nprocs=n_gpus, join=True)
+        return json.load(open(result))
+
+
+def convert(bam_filename, ec_filename, emase_filename, num_chunks=0, number_processes=-1, temp_dir=None,
+            range_filename=None, sample=None, target_filename=None):
+    """BAM -> EC ``.bin`` and/or EMASE ``.h5`` (same arguments and outputs as ``bam_utils.convert``)."""
+    start_time = time.time()
+    if sample is None:
+        sample = os.path.basename(bam_filename)                      # bam_utils.py:552-554
+        LOG.info("Sample not supplied, using filename: {}".format(sample))
+    elif isinstance(sample, bytes):
+        sample = sample.decode('ascii', 'ignore')
+    n_gpus = int(os.environ.get("ALNTOOLS_GPUS", "1"))
+    if n_gpus > 1:
+        sizes = _convert_multi(n_gpus, bam_filename, ec_filename, emase_filename, range_filename, sample, target_filename)
+        LOG.info("Done, total time: {}".format(utils.format_time(start_time, time.time())))
+        return sizes
+    LOG.info("Parsing file information ...")
+    reader = open_bam(bam_filename)
+    targets = None
+    if target_filename:
+        targets = list(utils.parse_targets(target_filename).keys())
+        if len(targets) == 0:
+            raise ValueError("Unable to parse target file")
+    maps = HeaderMaps(reader.references, reader.lengths, targets)
+    device = int(os.environ.get("ALNTOOLS_GPU", "0"))
+    temp_time = time.time()
+    with EcBuilder(maps.n_loci, maps.n_haplotypes, device=device, track_ranges=range_filename is not None,
+                   verify=bool(int(os.environ.get("ALNTOOLS_VERIFY", "0")))) as b:
+        enc = TupleEncoder(maps)
+        while True:
+            q, flag, tid, pos, ntid, npos = reader.read_batch(BATCH_RECORDS)
+            if not len(q):
+                break
+            t = enc.encode(q, flag, tid, pos, ntid, npos)
+            b.push(t["read_id"], t["locus"], t["hapflag"], t["pos"] if range_filename else None)
+        reader.close()
+        sizes = b.finalize()
+        out = b.export()
+        LOG.info("All results combined in {}, total time: {}".format(utils.format_time(temp_time, time.time()),
+                                                                     utils.format_time(start_time, time.time())))
+        _log_summary(maps, sizes)
+        range_len = b.export_ranges() if range_filename else None
+    _write_outputs(maps, sample, sizes, out, range_len, ec_filename, emase_filename, range_filename)
     LOG.info("Done, total time: {}".format(utils.format_time(start_time, time.time())))
     return sizes
