@@ -32,5 +32,21 @@ def build(force=False, verbose=False):
     return OUT
 
 
+def build_sanitized(out=None, verbose=False):
+    """Host side of libecb under AddressSanitizer + UndefinedBehaviorSanitizer (the device code is compiled as usual:
+    GPU sanitizers are not available): ``libecb_asan.so``, for the no-GPU argument / state checking tests.  The C++ half of
+    the library is ~1.5 kLoC of manual hipMalloc / hipFree pairs and early returns."""
+    out = out or os.path.join(HERE, "libecb_asan.so")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-shared", "-fPIC", "-fsanitize=address,undefined",
+           "-fno-gpu-sanitize", "-shared-libsan", "-Wno-unused-value", "-o", out, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--asan" in sys.argv:
+        print(build_sanitized(verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -130,6 +130,29 @@ def test_plain_c_program_links_against_the_abi(tmp_path):
     assert "abi ok" in out.stdout
 
 
+def test_sanitized_host_build_passes_the_argument_checks(tmp_path):
+    """libecb's host half under ASAN + UBSAN (python -m alntools_amd.build --asan): the plain-C ABI program -- bad struct size,
+    too many haplotypes, create without a device (here) or a tiny run (on a GPU box) -- must come through without a report."""
+    import subprocess
+    from alntools_amd import build as b
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.join(here, "..")
+    so = b.build_sanitized(out=str(tmp_path / "libecb_asan.so"))
+    clang = os.path.join(os.path.dirname(os.path.realpath(b.HIPCC)), "..", "lib", "llvm", "bin", "clang")
+    if not os.path.exists(clang):
+        clang = "/opt/rocm/lib/llvm/bin/clang"
+    rt = os.path.dirname(subprocess.check_output([clang, "-print-file-name=libclang_rt.asan-x86_64.so"], text=True).strip())
+    exe = str(tmp_path / "abi_asan")
+    subprocess.check_call([clang, "-fsanitize=address,undefined", "-shared-libsan", "-std=c11", "-I", os.path.join(root, "include"),
+                           os.path.join(here, "abi_smoke.c"), "-o", exe, "-L", str(tmp_path), "-l:libecb_asan.so",
+                           "-Wl,-rpath," + str(tmp_path), "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath," + rt])
+    import torch
+    leaks = "0" if torch.cuda.is_available() else "1"      # (with a device the HIP runtime's own allocations outlive the program)
+    out = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=%s:halt_on_error=1" % leaks,
+                                                                      UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1"))
+    assert out.returncode == 0 and "abi ok" in out.stdout and "ERROR" not in out.stderr and "runtime error" not in out.stderr, (out.returncode, out.stdout, out.stderr[-2000:])
+
+
 def test_emase_h5_round_trip_through_libhdf5(golden_dir, tmp_path):
     """ec2emase / emase2ec (bin_utils.py:979-1028): .bin -> .h5 -> .bin is byte-identical; the .h5 holds the per-haplotype
     CSC matrices the reference stores (checked against scipy).  Needs only libhdf5 (ctypes)."""
