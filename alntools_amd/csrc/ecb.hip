@@ -299,22 +299,27 @@ __device__ __forceinline__ u32 unslot(u32 t) {                                  
     const u32 m = (t * 205u) >> 10; return 4u * m + (t - 5u * m);
 }
 
+// What k_stream needs once in a while sits behind ONE pointer (scalar registers are what this kernel runs out of: every
+// kernel argument occupies a pair for the whole launch, and what does not fit is shuffled through vector lanes).
+struct StreamCold {
+    uint2* arena; u64 arena_cap;
+    u64* queue; u64 queue_cap;       // head record index of deferred reads
+    u64* resume;                     // per slice {where a relaunch takes it up, records counted up to}
+    u32* wave_counts;                // per wave {records offered, records valid, ECs created}: summed by k_sum_counts
+    u64* wave_arena;                 // per wave {start, pairs left} of its arena reservation, kept from launch to launch
+    u64* timing;                     // profiling only (-DECB_TIMING): clocks per phase, summed over waves
+    u64 chunk;                       // records per slice (a multiple of WT)
+    u32 prev_rid;                    // read_id of the record before this batch (0xFFFFFFFF at stream start)
+};
 struct StreamArgs {
     const u32* rid; const u32* loc; const u32* hf;
-    u64 n, chunk;
-    u32 prev_rid;                    // read_id of the record before this batch (0xFFFFFFFF at stream start)
-    u32 n_loci, n_haps;
+    u64 n;
     Slot* table; u64 cap_mask;
-    uint2* arena; u64 arena_cap;
     Counters* ctr;
     u32* read_slot;                  // slot of every read (indexed by read_id)
     u64 reads_hi;                    // read_slot holds [0, reads_hi): a read index beyond it is a broken run counter
-    u64* queue; u64 queue_cap;       // head record index of deferred reads
-    u64* resume;                     // per wave {next record to process, records counted up to}
-    u32* wave_counts;                // per wave {records offered, records valid, ECs created}: summed by k_sum_counts
-    u64* wave_arena;                 // per wave {start, pairs left} of its arena reservation, kept from launch to launch
-    u32 ablate;                      // profiling only (env ECB_ABLATE): 1 = stop after (a), 2 = after (b), 4 = no EC table
-    u64* timing;                     // profiling only (-DECB_TIMING): clocks per phase, summed over waves
+    const StreamCold* cold;
+    u32 ablate;                      // profiling only (env ECB_ABLATE): 1 = stop after (a), 2 = after (b), 4 = no EC table, 8 / 16 / 32 see table_lookup
 };
 
 __device__ __forceinline__ void wave_sync() {   // orders this wave's LDS traffic (lanes run in lockstep)
@@ -349,7 +354,7 @@ struct TileRegs { u32 rr[RPL], ll[RPL], hh[RPL]; };
 struct LdsSetCmp {
     const WaveLds* L;
     u32 s2, e2, pm, np;
-    uint2* arena;
+    const StreamCold* cold;          // (the key arena, for keys longer than a slot: looked up when one turns up)
     __device__ __forceinline__ int quick(const SlotView& v) const {
         if (v.n != np) return CMP_DIFFERENT;
         uint2 t[INL];                                    // the INL first probes are issued together: one LDS round trip for the lot
@@ -368,7 +373,7 @@ struct LdsSetCmp {
             return CMP_UNSURE;                           // another locus of mine sits at the first probe: full() walks on
         }
         for (u32 i = INL; i < v.n; ++i) {                // the rest of a long key, from the arena
-            const uint2 pr = unpack2(__hip_atomic_load(reinterpret_cast<u64*>(arena + (u64)v.off + (i - INL)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const uint2 pr = unpack2(__hip_atomic_load(reinterpret_cast<u64*>(cold->arena + (u64)v.off + (i - INL)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             if (pr.y == 0u) return CMP_INCOMPLETE;
             const uint2 tt = tab_get(*L, s2 + ((pr.x + 1u) & pm));
             if (tt.x == pr.x + 1u && tt.y == pr.y) continue;
@@ -379,7 +384,7 @@ struct LdsSetCmp {
     __device__ __forceinline__ int full(Slot* s, u32 n, u32 off) const {
         if (n != np) return CMP_DIFFERENT;
         for (u32 i = 0; i < n; ++i) {
-            const uint2 pr = key_pair_fresh(s, arena, off, i);
+            const uint2 pr = key_pair_fresh(s, cold->arena, off, i);
             if (pr.y == 0u) return CMP_INCOMPLETE;
             const u32 key = pr.x + 1u;
             u32 q = s2 + (key & pm);
@@ -455,11 +460,13 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
     // unclaimed slice of the stream when it has finished one.  (Slices bound to workgroups at launch left a SIMD slot
     // idle until the slowest of a workgroup's four waves was done, and the last round ragged: a fifth of the kernel.)
     const u64 pw = (u64)blockIdx.x * NWAVE + w;   // this wave
+    const StreamCold* const C = A.cold;
+    static_assert(WT == 512, "tile index = record index >> 9");
     u32 s_all = 0, my_valid = 0, my_new = 0;      // wave total / per lane; a wave sees far fewer than 2^32 records
     u32 bad = 0;
     // this wave's current reservation in the key arena: what the last launch left of it is used first (a stream pushed in
     // many small batches would otherwise leave the tail of a 512-pair chunk behind per wave and launch)
-    if (!VERIFY && lane == 0) { const u64 ca = A.wave_arena[2 * pw]; L.ws[2] = (u32)ca; L.ws[3] = (u32)(ca >> 32); L.ws[4] = (u32)A.wave_arena[2 * pw + 1]; }
+    if (!VERIFY && lane == 0) { const u64* wa = C->wave_arena; const u64 ca = wa[2 * pw]; L.ws[2] = (u32)ca; L.ws[3] = (u32)(ca >> 32); L.ws[4] = (u32)wa[2 * pw + 1]; }
 #ifdef ECB_TIMING
     u64 tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
 #endif
@@ -467,22 +474,28 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
     u32 wid = 0;                                  // the slice (fewer than 2^32 of them: a slice is at least a tile)
     if (lane == 0) wid = (u32)atomicAdd(&A.ctr->next_slice, 1ull);
     wid = (u32)__builtin_amdgcn_readfirstlane((int)wid);
-    const u64 c0 = (u64)wid * A.chunk;            // (a multiple of WT)
+    const u64 chunk = C->chunk;
+    const u64 c0 = (u64)wid * chunk;              // (a multiple of WT)
     if (c0 >= A.n) break;
-    const u64 c1 = min(c0 + A.chunk, A.n);
+    const u64 c1 = min(c0 + chunk, A.n);
     // resume point: the first record not yet consumed by a finished read (a fresh slice: c0; after a park: the head of the
     // read that was open, or the tile that was next), and how far the slice's records have been counted
-    const u64 p = A.resume[2 * (u64)wid], counted0 = A.resume[2 * (u64)wid + 1];
+    const u64 p = C->resume[2 * (u64)wid], counted0 = C->resume[2 * (u64)wid + 1];
     if (p >= A.n || p == ~0ull) continue;         // finished before a relaunch
-    u64 t0 = p & ~(u64)(WT - 1);                  // tile start
-    int p_rel = (int)(p - t0);                    // (only matters in the first tile after a park)
+    // The loop below thinks in tiles (32-bit indices: scalar registers are scarce): tile t covers records [512 t, 512 t + 512)
+    u32 tix = (u32)(p >> 9);                      // the tile to work on
+    const u32 c1t = (u32)((c1 + (u64)(WT - 1)) >> 9);             // my slice ends before this tile
+    const u32 last_t = (u32)((A.n - 1) >> 9);                     // the stream's last tile ...
+    const u32 last_rel = (u32)(A.n - ((u64)last_t << 9));         // ... and how many records it holds
+    const u32 counted_t = (u32)((counted0 + (u64)(WT - 1)) >> 9); // tiles before this one have been counted (after a park)
+    int p_rel = (int)(p - ((u64)tix << 9));       // (only matters in the first tile after a park)
     // read index of the first head at or after p; records before it that are not heads belong to the read before
-    u32 base = (p == 0 ? A.prev_rid : A.rid[p - 1]) + 1u;
+    u32 base = (p == 0 ? C->prev_rid : A.rid[p - 1]) + 1u;
     bool open = false;                            // a read of mine is still open at the start of the tile (its index is `base`)
                                                   // (the record index of its head: L.ws[0..1])
     u32 carry_n = 0;                              // its entries so far, in L.carry
     TileRegs R;
-    load_tile(A, t0, min(t0 + (u64)WT, A.n), lane, R);
+    load_tile(A, (u64)tix << 9, min(((u64)tix << 9) + (u64)WT, A.n), lane, R);
     u32 parked = __hip_atomic_load(&A.ctr->full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("" : "+v"(parked));          // (settled before the loop: otherwise the loop header carries an s_waitcnt vmcnt(0) that every tile pays)
     bool slice_done = false;
@@ -495,15 +508,14 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
         u32 ln = lane;
         asm volatile("" : "+v"(ln));
         r_lo = (u32)__builtin_amdgcn_readfirstlane((int)r_lo);
-        t0 = ((u64)(u32)__builtin_amdgcn_readfirstlane((u32)(t0 >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((u32)t0);   // (the builtin returns int: no sign extension)
+        tix = (u32)__builtin_amdgcn_readfirstlane((int)tix);
         base = (u32)__builtin_amdgcn_readfirstlane(base);
-        const u64 te = min(t0 + (u64)WT, A.n);
-        const bool own = t0 < c1;                 // heads in this tile start reads of my slice (tiles do not straddle c1)
-        // tile-relative bounds (all below 2^31)
-        const int te_rel = (int)(te - t0);
+        const bool ends = tix == last_t;           // batches end on a read boundary
+        const bool own = tix < c1t;               // heads in this tile start reads of my slice (tiles do not straddle its end)
+        const int te_rel = ends ? (int)last_rel : WT;
         // records offered / valid are counted tile by tile: every tile of my slice once (after a park the tiles before the
         // one that was next have been counted: `counted0` is a tile boundary)
-        const bool count_tile = own && t0 >= counted0 && r_lo == 0u;
+        const bool count_tile = own && tix >= counted_t && r_lo == 0u;
         const bool plain = p_rel == 0 && te_rel == WT;      // a whole tile, nothing masked: all but the first after a park / the last of the stream
         // ---- (a) filter, heads -------------------------------------------------------------------
         // Written with integer bit arithmetic throughout: every instruction costs an issue slot, and
@@ -574,18 +586,17 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
         // last one is too if the stream ends with the tile.  In a tile past my slice only the open read is mine, and it
         // is complete as soon as a head shows up.
         const u32 n_in = (open ? 1u : 0u) + nheads;
-        const bool ends = te == A.n;               // batches end on a read boundary
         const u32 n_done = own ? (ends ? n_in : (n_in ? n_in - 1u : 0u)) : ((open && (nheads || ends)) ? 1u : 0u);
         const u32 n_build = own ? n_in : (open ? 1u : 0u);     // reads whose tables are built: the unfinished one too (it is carried on)
         const bool carry_out = own ? (!ends && n_in != 0u) : (open && !nheads && !ends);
-        const bool more = !ends && (t0 + (u64)WT < c1 || carry_out);
+        const bool more = !ends && (tix + 1u < c1t || carry_out);
         const bool again = r_lo + (u32)WMAXR < n_build;     // another pass over this tile follows
         TICK(1);
         // ---- prefetch the next tile while this one is hashed and looked up --------------------------
         TileRegs N;
         u32 parked_next = 0;
         if (more || again) {
-            const u64 nt = again ? t0 : t0 + (u64)WT;
+            const u64 nt = (u64)(again ? tix : tix + 1u) << 9;
             load_tile(A, nt, min(nt + (u64)WT, A.n), ln, N);
             parked_next = __hip_atomic_load(&A.ctr->full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -781,7 +792,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
             const bool on = ln < nproc && !(A.ablate & 3u);
             const u32 rd = base + r_lo + ln;
             LdsSetCmp cmp;
-            cmp.L = &L; cmp.arena = A.arena; cmp.s2 = cmp.e2 = cmp.pm = cmp.np = 0;
+            cmp.L = &L; cmp.cold = C; cmp.s2 = cmp.e2 = cmp.pm = cmp.np = 0;
             if (on) {
                 const u32 sg = L.seg[ln + 1];
                 cmp.s2 = sg & SMASK; cmp.e2 = (sg >> SBITS) & SMASK; cmp.pm = sg >> (2 * SBITS);
@@ -842,7 +853,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                             if (total > chunk_left) {                       // reserve another stretch of the key arena
                                 const u32 take = max(total, ARENA_CHUNK);
                                 u64 at = 0;
-                                if (ln == 0) at = arena_alloc(A.ctr, A.arena_cap, take, (u32)pw);
+                                if (ln == 0) at = arena_alloc(A.ctr, C->arena_cap, take, (u32)pw);
                                 chunk_at = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(at >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)at);
                                 chunk_left = take;
                                 if (chunk_at == ~0ull) { bad |= ERR_ARENA; chunk_left = 0; }
@@ -859,6 +870,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                         // order: rows are sorted when they are emitted), not by the founding ln walking its read's table:
                         // that serial walk with 1-3 lanes alive was ~400 issue slots per tile, a quarter of the kernel.
                         const u32 j32 = (u32)j;
+                        uint2* const arena = C->arena;
                         if (!dead) for (u32 e0 = 0; e0 < n_ent; e0 += 64) {
                             const u32 e = e0 + ln;
                             const u32 en = e < n_ent ? L.ent[e] : 0u, qq = en & SMASK, rl = en >> SBITS;
@@ -866,7 +878,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                             if (e < n_ent && (cmask >> rl & 1ull) && !(A.ablate & 32u)) {    // (32: profiling, no key stores)
                                 const u32 was = atomicSub(reinterpret_cast<u32*>(&L.npair[rl & ~1u]), (rl & 1u) ? 0x10000u : 1u);
                                 const u32 pos = ((rl & 1u) ? was >> 16 : was & 0xFFFFu) - 1u;   // a place of its own among the read's pairs
-                                uint2* dst = pos < INL ? &A.table[jj].pair[pos] : A.arena + ((u64)o + (pos - INL));
+                                uint2* dst = pos < INL ? &A.table[jj].pair[pos] : arena + ((u64)o + (pos - INL));
                                 const uint2 en2 = tab_get(L, qq);
                                 store_wt64(reinterpret_cast<u64*>(dst), pack2(make_uint2(en2.x - 1u, en2.y)));
                             }
@@ -886,8 +898,8 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                 if (st == ST_FULL) {                                    // table too full here: defer the read, park
                     atomicExch(&A.ctr->full, 1u);
                     const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
-                    const u64 head = (open && r_lo == 0u && ln == 0u) ? ws_get64(L, 0) : t0 + unslot((L.seg[ln + 1] & SMASK) - (u32)CPAD);
-                    if (qi < A.queue_cap) A.queue[qi] = head; else atomicOr(&A.ctr->err, ERR_QUEUE);
+                    const u64 head = (open && r_lo == 0u && ln == 0u) ? ws_get64(L, 0) : ((u64)tix << 9) + unslot((L.seg[ln + 1] & SMASK) - (u32)CPAD);
+                    if (qi < C->queue_cap) C->queue[qi] = head; else atomicOr(&A.ctr->err, ERR_QUEUE);
                 } else if (st == ST_HIT) {
                     A.read_slot[rd] = (u32)j;
                 }
@@ -907,28 +919,28 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
         r_lo = 0; p_rel = 0;
         // state for the next tile
         if (carry_out && !giant) {
-            if (last_pos != 0xFFFFFFFFu) ws_put64(L, 0, t0 + last_pos, ln);   // (else: the open read stays the open read)
+            if (last_pos != 0xFFFFFFFFu) ws_put64(L, 0, ((u64)tix << 9) + last_pos, ln);   // (else: the open read stays the open read)
             open = true; carry_n = new_carry; base = last_rid;
         } else {
             if (carry_out && giant) {                                // more entries than a tile's pad takes: one workgroup for this read (k_slow)
-                const u64 head = last_pos != 0xFFFFFFFFu ? t0 + last_pos : ws_get64(L, 0);
+                const u64 head = last_pos != 0xFFFFFFFFu ? ((u64)tix << 9) + last_pos : ws_get64(L, 0);
                 if (ln == 0) {
                     const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
-                    if (qi < A.queue_cap) A.queue[qi] = head; else atomicOr(&A.ctr->err, ERR_QUEUE);
+                    if (qi < C->queue_cap) C->queue[qi] = head; else atomicOr(&A.ctr->err, ERR_QUEUE);
                 }
             }
             open = false; carry_n = 0; base = last_rid + 1u;          // (the rest of a giant read is skipped: not a head, not open)
         }
         slice_done = !more;
-        t0 += (u64)WT;
+        tix += 1u;
     }
     // where a relaunch takes this slice up: at the head of the read that is open, else at the tile that comes next
-    u64 p_out = open ? ws_get64(L, 0) : t0;
-    const u64 counted = max(counted0, min(r_lo ? t0 + (u64)WT : t0, c1));   // (every tile before t0 has been counted; t0 itself once its first pass is through)
+    u64 p_out = open ? ws_get64(L, 0) : (u64)tix << 9;
+    const u64 counted = max(counted0, min((u64)(r_lo ? tix + 1u : tix) << 9, c1));   // (every tile before tix has been counted; tix itself once its first pass is through)
     const bool stop = __ballot(bad != 0u) || parked;
     if (__ballot(bad != 0u)) { if (bad) atomicOr(&A.ctr->err, bad); p_out = ~0ull; }
     else if (slice_done) p_out = ~0ull;
-    if (lane == 0) { A.resume[2 * (u64)wid] = p_out; A.resume[2 * (u64)wid + 1] = counted; }
+    if (lane == 0) { u64* rs = C->resume; rs[2 * (u64)wid] = p_out; rs[2 * (u64)wid + 1] = counted; }
     if (stop) break;
   }
     // records offered / valid: one atomic pair per wave
@@ -936,10 +948,10 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
     // per-wave totals go to their own words: thousands of waves adding to three shared counters serialise (~50 ns each)
     const u32 wn = VERIFY ? wave_sum(my_new) : my_new;
 #ifdef ECB_TIMING
-    if (lane == 0 && A.timing) for (int i = 0; i < 8; ++i) atomicAdd(A.timing + i, tacc[i]);
+    if (lane == 0 && C->timing) for (int i = 0; i < 8; ++i) atomicAdd(C->timing + i, tacc[i]);
 #endif
-    if (lane == 0) { A.wave_counts[3 * pw] = wa; A.wave_counts[3 * pw + 1] = wv; A.wave_counts[3 * pw + 2] = wn; }
-    if (!VERIFY && lane == 0) { A.wave_arena[2 * pw] = ((u64)L.ws[3] << 32) | L.ws[2]; A.wave_arena[2 * pw + 1] = L.ws[4]; }
+    if (lane == 0) { u32* wc = C->wave_counts; wc[3 * pw] = wa; wc[3 * pw + 1] = wv; wc[3 * pw + 2] = wn; }
+    if (!VERIFY && lane == 0) { u64* wav = C->wave_arena; wav[2 * pw] = ((u64)L.ws[3] << 32) | L.ws[2]; wav[2 * pw + 1] = L.ws[4]; }
 }
 
 // resume points of a fresh batch: slice b starts (and has counted its records up to) record b * chunk
@@ -2115,6 +2127,7 @@ struct ecb_handle {
     Counters* ctr = nullptr;
     Counters hctr{};                  // last read-back
     Counters* pin_ctr = nullptr;      // pinned staging for clear_counters
+    StreamCold *d_cold = nullptr, *pin_cold = nullptr;   // k_stream's rarely used arguments (device copy, pinned staging)
     u32* read_slot = nullptr; u64 read_slot_cap = 0;
     u32* meta = nullptr; u64 meta_cap = 0, meta_hi = 0;   // multisample: cell | file << 22 per read
     u64 n_triples = 0; u64* ms_okey = nullptr; u32 *ms_ofirst = nullptr, *ms_ostart = nullptr, *ms_ocount = nullptr;
@@ -2351,9 +2364,9 @@ int verify_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d
     HIPCHK(h, hipMemsetAsync(&h->ctr->full, 0, sizeof(u32), h->stream));
     HIPCHK(h, hipMemsetAsync(&h->ctr->next_slice, 0, sizeof(u64), h->stream));
     HIPCHK(h, hipMemsetAsync(&h->ctr->n_mismatch, 0, sizeof(u64), h->stream));
-    StreamArgs a{d_rid, d_loc, d_hf, n, P.chunk, prev_rid, h->cfg.n_loci, h->cfg.n_haplotypes,
-                 h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr, h->read_slot, h->reads_hi, h->queue, h->queue_cap, d_resume, d_wcounts, nullptr,
-                 0u, nullptr};
+    *h->pin_cold = StreamCold{h->arena, h->arena_cap, h->queue, h->queue_cap, d_resume, d_wcounts, nullptr, nullptr, P.chunk, prev_rid};
+    HIPCHK(h, hipMemcpyAsync(h->d_cold, h->pin_cold, sizeof(StreamCold), hipMemcpyHostToDevice, h->stream));
+    StreamArgs a{d_rid, d_loc, d_hf, n, h->table, h->cap - 1, h->ctr, h->read_slot, h->reads_hi, h->d_cold, 0u};
     k_stream<true><<<(unsigned)P.blocks, TPB, 0, h->stream>>>(a);
     k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, P.pwaves, h->ctr, 1u);
     HIPCHK(h, hipGetLastError());
@@ -2407,13 +2420,15 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
         }
         h->wave_arena = wa; h->wave_arena_n = pwaves;
     }
-    StreamArgs a{d_rid, d_loc, d_hf, n, chunk, h->prev_rid, h->cfg.n_loci, h->cfg.n_haplotypes,
-                 h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr, h->read_slot, h->reads_hi, h->queue, h->queue_cap, d_resume, d_wcounts, h->wave_arena,
-                 getenv("ECB_ABLATE") ? (u32)atoi(getenv("ECB_ABLATE")) : 0u, nullptr};
+    StreamCold cold{h->arena, h->arena_cap, h->queue, h->queue_cap, d_resume, d_wcounts, h->wave_arena, nullptr, chunk, h->prev_rid};
 #ifdef ECB_TIMING
-    HIPCHK(h, hipMalloc(&a.timing, 8 * sizeof(u64)));
-    HIPCHK(h, hipMemset(a.timing, 0, 8 * sizeof(u64)));
+    HIPCHK(h, hipMalloc(&cold.timing, 8 * sizeof(u64)));
+    HIPCHK(h, hipMemset(cold.timing, 0, 8 * sizeof(u64)));
 #endif
+    *h->pin_cold = cold;      // (pinned: rewritten by the next batch, which starts after this one's host wait)
+    HIPCHK(h, hipMemcpyAsync(h->d_cold, h->pin_cold, sizeof(StreamCold), hipMemcpyHostToDevice, h->stream));
+    StreamArgs a{d_rid, d_loc, d_hf, n, h->table, h->cap - 1, h->ctr, h->read_slot, h->reads_hi, h->d_cold,
+                 getenv("ECB_ABLATE") ? (u32)atoi(getenv("ECB_ABLATE")) : 0u};
     h->ctr_synced = false;
     for (;;) {
         HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));   // per launch
@@ -2444,7 +2459,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
 #ifdef ECB_TIMING
     {
         u64 t[8];
-        hipMemcpy(t, a.timing, sizeof(t), hipMemcpyDeviceToHost); hipFree(a.timing);
+        hipMemcpy(t, cold.timing, sizeof(t), hipMemcpyDeviceToHost); hipFree(cold.timing);
         static const char* nm[8] = {"(a) filter+heads", "tile decisions", "prefetch issue+clear+geometry", "(b) LDS tables", "hash entries", "(c) lookup", "publish/settle/slot stores", "-"};
         u64 tot = 0; for (int i = 0; i < 7; ++i) tot += t[i];
         fprintf(stderr, "[ecb timing] %llu waves, clocks per wave:", (unsigned long long)waves);
@@ -2705,6 +2720,8 @@ int ecb_create(const ecb_config* cfg, ecb_handle** out) {
     if ((e = hipMalloc(&h->arena, h->arena_cap * sizeof(uint2))) != hipSuccess) return bail(ECB_ERR_HIP, "hipMalloc(arena)", e);
     if ((e = hipMalloc(&h->ctr, sizeof(Counters))) != hipSuccess) return bail(ECB_ERR_HIP, "hipMalloc(counters)", e);
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->pin_ctr), sizeof(Counters), hipHostMallocDefault)) != hipSuccess) return bail(ECB_ERR_HIP, "hipHostMalloc", e);
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->pin_cold), sizeof(StreamCold), hipHostMallocDefault)) != hipSuccess) return bail(ECB_ERR_HIP, "hipHostMalloc", e);
+    if ((e = hipMalloc(&h->d_cold, sizeof(StreamCold))) != hipSuccess) return bail(ECB_ERR_HIP, "hipMalloc(args)", e);
     hipMemsetAsync(h->table, 0, h->cap * sizeof(Slot), h->stream);
     hipMemsetAsync(h->arena, 0, h->arena_cap * sizeof(uint2), h->stream);     // stale arena bytes must never look like a key (see ecb_reset)
     clear_counters(h);
@@ -2729,6 +2746,8 @@ void ecb_destroy(ecb_handle* h) {
     hipFree(h->table); hipFree(h->arena); hipFree(h->ctr); hipFree(h->read_slot); hipFree(h->meta);
     hipFree(h->rng_min); hipFree(h->rng_max); hipFree(h->queue); hipFree(h->wave_arena);
     if (h->pin_ctr) hipHostFree(h->pin_ctr);
+    if (h->pin_cold) hipHostFree(h->pin_cold);
+    hipFree(h->d_cold);
     for (int i = 0; i < ecb_handle::P_N; ++i) hipFree(h->pool[i]);
     hipFree(h->st_rid); hipFree(h->st_loc); hipFree(h->st_hf); hipFree(h->st_pos);
     if (h->ev0) hipEventDestroy(h->ev0);
