@@ -194,10 +194,11 @@ __device__ __forceinline__ SlotView make_view(uint4 a, uint4 b, uint4 c, uint4 d
     return v;
 }
 template <class Cmp>
-__device__ __forceinline__ int table_lookup(Slot* table, u64 cap_mask, u64 lo, u64& j, u32& probes, const Cmp& cmp, u32 abl = 0u) {
+__device__ __forceinline__ int table_lookup(Slot* table, u64 cap_mask, u64 lo, u64& j, u32& probes, const Cmp& cmp, u32 abl = 0u, u32* first_inv_seen = nullptr) {
     for (; probes < MAX_PROBE; ++probes, j = (j + 1) & cap_mask) {
         Slot* s = table + j;
         const uint4* q = reinterpret_cast<const uint4*>(s);
+        if (first_inv_seen) *first_inv_seen = 0u;
         uint4 a = q[0], b = a, c = a, d = a;                      // lo, n1, off | count, first_inv, pair 0 | pairs 1, 2 | pairs 3, 4
         if (!(abl & 16u)) { b = q[1]; c = q[2]; d = q[3]; }       // (profiling only: 16 = first 16 bytes only, 8 = no key compare)
         u64 clo = ((u64)a.y << 32) | a.x;
@@ -210,6 +211,7 @@ __device__ __forceinline__ int table_lookup(Slot* table, u64 cap_mask, u64 lo, u
         if (clo != lo) continue;
         if (a.z == 0u) return ST_PENDING;
         if (a.z == DEAD_KEY) continue;
+        if (first_inv_seen) *first_inv_seen = b.y;                 // (what this line -- possibly an old copy -- shows of the EC's first read)
         if (abl & 8u) return ST_HIT;
         const int r = cmp.quick(make_view(a, b, c, d));
         if (r == CMP_EQUAL) return ST_HIT;
@@ -787,7 +789,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
             TICK(4);
             // ---- (c) one ln per read: EC lookup with exact key compare; a new EC gets its key from the read's LDS table ---------
             u64 j = 0;
-            u32 st = ST_NONE, probes = 0, np = 0;
+            u32 st = ST_NONE, probes = 0, np = 0, fseen = 0;       // fseen: ~(first read) as the slot's line showed it (0 = nothing yet)
             u64 lo = 0;
             const bool on = ln < nproc && !(A.ablate & 3u);
             const u32 rd = base + r_lo + ln;
@@ -825,7 +827,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                 for (u32 round = 0;; ++round) {
                     if (st == ST_LOOK) {
                         if (A.ablate & 4u) st = ST_HIT;
-                        else st = table_lookup(A.table, A.cap_mask, lo, j, probes, cmp, A.ablate);
+                        else st = table_lookup(A.table, A.cap_mask, lo, j, probes, cmp, A.ablate, &fseen);
                     }
                     if (round == 0u) {
                         TICK(5);
@@ -902,6 +904,9 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                     if (qi < C->queue_cap) C->queue[qi] = head; else atomicOr(&A.ctr->err, ERR_QUEUE);
                 } else if (st == ST_HIT) {
                     A.read_slot[rd] = (u32)j;
+                    // First appearance of the EC (bam_utils.py:682-698: rank = first-seen order), kept current here: an old copy
+                    // of the line can only show a LATER first read, so the comparison errs on the side of one more atomic.
+                    if (~rd > fseen) atomicMax(&A.table[j].first_inv, ~rd);
                 }
             }
             wave_sync();
@@ -1020,7 +1025,7 @@ __global__ __launch_bounds__(TPB_PART) void k_part_hist(const u32* read_slot, u6
 }
 
 __global__ __launch_bounds__(TPB_PART) void k_part_scatter(const u32* read_slot, u64 n_reads, u32 n_buckets, const u32* offs,
-                                                      uint2* pairs) {
+                                                      u32* pairs) {
     extern __shared__ u32 sh[];
     const u64 G = gridDim.x, g = blockIdx.x, per = (n_reads + G - 1) / G;
     const u64 r0 = g * per, r1 = min(r0 + per, n_reads);
@@ -1038,20 +1043,22 @@ __global__ __launch_bounds__(TPB_PART) void k_part_scatter(const u32* read_slot,
 #pragma unroll
         for (int k = 0; k < 4; ++k) if (s[k] != PENDING) pos[k] = atomicAdd(&sh[s[k] >> BIN_BITS], 1u);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) if (s[k] != PENDING) pairs[pos[k]] = make_uint2(s[k], (u32)r[k]);
+        for (int k = 0; k < 4; ++k) if (s[k] != PENDING) pairs[pos[k]] = s[k];
     }
 }
 
+// (Elements are slot ids alone: the first read of an EC is kept current by k_stream itself -- the lookup has the slot's line in
+//  hand and adds an atomicMax only when its read is earlier than what the line shows -- so nothing but counts is left here.)
 // The scatter with its elements sorted by range in LDS first: a workgroup takes STAGE reads at a time, ranks them within their
 // range (LDS counters), lays them out range by range in LDS and writes them from there -- elements of one range leave in
 // runs of consecutive addresses (STAGE / n_buckets of them on average) instead of one 8-byte store per lane and range.
-constexpr u32 STAGE = 8 * TPB_PART;            // 8 192 elements = 64 KB of LDS
+constexpr u32 STAGE = 8 * TPB_PART;            // 8 192 elements = 32 KB of LDS
 constexpr u32 STAGE_MAX_BUCKETS = 4096;        // 3 x 16 KB of counters / starts / cursors beside the stage
 __global__ __launch_bounds__(TPB_PART) void k_part_scatter_staged(const u32* read_slot, u64 n_reads, u32 n_buckets, const u32* offs,
-                                                             uint2* pairs) {
-    extern __shared__ u32 sh[];                   // cnt[nb] | start[nb] | gcur[nb] | stage[STAGE] (uint2)
+                                                             u32* pairs) {
+    extern __shared__ u32 sh[];                   // cnt[nb] | start[nb] | gcur[nb] | stage[STAGE]
     u32 *cnt = sh, *start = sh + n_buckets, *gcur = sh + 2 * n_buckets;
-    uint2* stage = reinterpret_cast<uint2*>(sh + ((3 * n_buckets + 1) & ~1u));      // (8-byte aligned)
+    u32* stage = sh + 3 * n_buckets;
     __shared__ u32 s_wave[TPB_PART / 64];
     const u64 G = gridDim.x, g = blockIdx.x, per = (n_reads + G - 1) / G;
     const u64 r0 = g * per, r1 = min(r0 + per, n_reads);
@@ -1082,13 +1089,13 @@ __global__ __launch_bounds__(TPB_PART) void k_part_scatter_staged(const u32* rea
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-            if (s[k] != PENDING) stage[start[s[k] >> BIN_BITS] + lr[k]] = make_uint2(s[k], (u32)(rb + (u64)k * TPB_PART + tid));
+            if (s[k] != PENDING) stage[start[s[k] >> BIN_BITS] + lr[k]] = s[k];
         __syncthreads();
         u32 n_here = 0;
         for (u32 k = 0; k < TPB_PART / 64; ++k) n_here += s_wave[k];
         for (u32 i = tid; i < n_here; i += TPB_PART) {
-            const uint2 e = stage[i];
-            const u32 b = e.x >> BIN_BITS;
+            const u32 e = stage[i];
+            const u32 b = e >> BIN_BITS;
             pairs[gcur[b] + (i - start[b])] = e;
         }
         __syncthreads();
@@ -1134,25 +1141,25 @@ __global__ __launch_bounds__(1024) void k_build_work(const u32* starts, u32 n_bu
     }
     if (tid == 0) *n_work = min(s_carry, max_work);
 }
-__global__ __launch_bounds__(TPB_COUNT) void k_count_bins(const uint2* pairs, const CountWork* work, const u32* n_work, Slot* table) {
-    __shared__ u32 cnt[N_BINS], fst[N_BINS];
+__global__ __launch_bounds__(TPB_COUNT) void k_count_bins(const u32* pairs, const CountWork* work, const u32* n_work, Slot* table) {
+    __shared__ u32 cnt[N_BINS];
     if (blockIdx.x >= *n_work) return;                     // (the grid is the list's upper bound: its length never visits the host)
     const CountWork wk = work[blockIdx.x];
     const u32 b = wk.bucket, lane = threadIdx.x & 63u;
     const u32 start = wk.start, end = wk.end;
-    for (u32 q = threadIdx.x; q < N_BINS; q += TPB_COUNT) { cnt[q] = 0; fst[q] = 0xFFFFFFFFu; }
+    for (u32 q = threadIdx.x; q < N_BINS; q += TPB_COUNT) cnt[q] = 0;
     __syncthreads();
     for (u32 i0 = start; i0 < end; i0 += 4 * TPB_COUNT) {
-        uint2 pr[4];
+        u32 pr[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                       // four independent loads in flight per thread
             const u32 i = i0 + k * TPB_COUNT + threadIdx.x;
-            pr[k] = i < end ? pairs[i] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+            pr[k] = i < end ? pairs[i] : 0xFFFFFFFFu;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const bool have = pr[k].x != 0xFFFFFFFFu;
-            const u32 bin = pr[k].x & (N_BINS - 1);
+            const bool have = pr[k] != 0xFFFFFFFFu;
+            const u32 bin = pr[k] & (N_BINS - 1);
             const u64 hm = __ballot(have);
             if (!hm) continue;
             // a hot EC fills most lanes of a wave: add it once per wave, the rest go one by one
@@ -1160,13 +1167,10 @@ __global__ __launch_bounds__(TPB_COUNT) void k_count_bins(const uint2* pairs, co
             const bool same = have && bin == v;
             const u64 m = __ballot(same);
             if (__popcll(m) >= 8) {
-                u32 mn = same ? pr[k].y : 0xFFFFFFFFu;
-#pragma unroll
-                for (int d = 32; d > 0; d >>= 1) mn = min(mn, (u32)__shfl_xor(mn, d));
-                if (lane == (u32)(__ffsll((long long)m) - 1)) { atomicAdd(&cnt[v], (u32)__popcll(m)); atomicMin(&fst[v], mn); }
-                if (have && !same) { atomicAdd(&cnt[bin], 1u); atomicMin(&fst[bin], pr[k].y); }
+                if (lane == (u32)(__ffsll((long long)m) - 1)) atomicAdd(&cnt[v], (u32)__popcll(m));
+                if (have && !same) atomicAdd(&cnt[bin], 1u);
             } else if (have) {
-                atomicAdd(&cnt[bin], 1u); atomicMin(&fst[bin], pr[k].y);
+                atomicAdd(&cnt[bin], 1u);
             }
         }
     }
@@ -1175,8 +1179,8 @@ __global__ __launch_bounds__(TPB_COUNT) void k_count_bins(const uint2* pairs, co
         const u32 c = cnt[q];
         if (c) {
             Slot* s = table + (((u64)b << BIN_BITS) | q);
-            if (wk.shared) { atomicAdd(&s->count, c); atomicMax(&s->first_inv, ~fst[q]); }
-            else { s->count += c; s->first_inv = max(s->first_inv, ~fst[q]); }      // the only writer of its slots
+            if (wk.shared) atomicAdd(&s->count, c);
+            else s->count += c;                             // the only writer of its slots
         }
     }
 }
@@ -1344,7 +1348,7 @@ __global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
                 const int r = same_key();
                 __syncthreads();
                 if (tid == 0) {
-                    if (r == CMP_EQUAL) { s_st = ST_HIT; A.read_slot[r0] = (u32)s_j; }
+                    if (r == CMP_EQUAL) { s_st = ST_HIT; A.read_slot[r0] = (u32)s_j; atomicMax(&A.table[s_j].first_inv, ~r0); }
                     else if (r == CMP_INCOMPLETE) { s_st = ST_NONE; atomicOr(&A.ctr->err, ERR_INTERNAL); }
                     else { s_j = (s_j + 1) & A.cap_mask; s_probes += 1; if (s_probes >= MAX_PROBE) { s_st = ST_FULL; A.requeue[atomicAdd(A.n_requeue, 1ull)] = h; } }
                 }
@@ -1367,6 +1371,7 @@ __global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
             if (tid == 0) {
                 publish_key(sl, dead ? DEAD_KEY : np + 1u, s_off);
                 A.read_slot[r0] = (u32)s_j;
+                atomicMax(&sl->first_inv, ~r0);
             }
         }
     }
@@ -2597,7 +2602,7 @@ int ensure_counts(ecb_handle* h) {
         if (nb > MAX_BUCKETS) return fail(h, ECB_ERR_LIMIT, "EC table larger than 2^26 slots is not supported yet");
         const u32 G = (u32)std::min<u64>(PART_G, (R + 4095) / 4096);
         u32 *hist = nullptr, *offs = nullptr;
-        uint2* pairs = nullptr;
+        u32* pairs = nullptr;
         u64* d_tot = nullptr;
         POOL(h, P_HIST, hist, (u64)nb * G); POOL(h, P_OFFS, offs, (u64)nb * G);
         POOL(h, P_PAIRS, pairs, R);
@@ -2608,10 +2613,10 @@ int ensure_counts(ecb_handle* h) {
         if (nb <= STAGE_MAX_BUCKETS) {
             if (!h->scatter_attr_set) {             // (per handle = per device: more than 64 KB of dynamic LDS has to be asked for)
                 HIPCHK(h, hipFuncSetAttribute((const void*)k_part_scatter_staged, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              3 * STAGE_MAX_BUCKETS * 4 + 8 + STAGE * 8));
+                                              3 * STAGE_MAX_BUCKETS * 4 + STAGE * 4));
                 h->scatter_attr_set = true;
             }
-            k_part_scatter_staged<<<G, TPB_PART, 3 * nb * 4 + 8 + STAGE * 8, h->stream>>>(h->read_slot, R, nb, offs, pairs);
+            k_part_scatter_staged<<<G, TPB_PART, 3 * nb * 4 + STAGE * 4, h->stream>>>(h->read_slot, R, nb, offs, pairs);
         } else                                     // (tables beyond 2^25 slots: the counters would crowd the stage out of LDS)
             k_part_scatter<<<G, TPB_PART, nb * 4, h->stream>>>(h->read_slot, R, nb, offs, pairs);
         // work list of k_count_bins: ranges far above the average are cut into pieces (see CountWork)
