@@ -504,7 +504,9 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
     u32 r_lo = 0;                                 // first read of the tile this pass works on (tiles of short reads take several passes)
 
     while (!slice_done) {
-        if (parked) break;            // the EC table filled up somewhere: the host grows it and relaunches
+        if (__builtin_amdgcn_readfirstlane((int)parked)) break;   // the EC table filled up somewhere: the host grows it and relaunches
+                                      // (readfirstlane: every lane loaded the same word; said so, the loop is uniform to the compiler --
+                                      //  as a per-lane condition it dragged exec-mask bookkeeping through every block of the tile)
         // (opaque per tile: the LDS addresses and constants derived from the lane index are cheap to recompute; hoisted out of
         //  the loop they sat in registers the tile needs, and what did not fit was spilled and re-loaded BEHIND the prefetch)
         u32 ln = lane;
@@ -942,7 +944,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
     // where a relaunch takes this slice up: at the head of the read that is open, else at the tile that comes next
     u64 p_out = open ? ws_get64(L, 0) : (u64)tix << 9;
     const u64 counted = max(counted0, min((u64)(r_lo ? tix + 1u : tix) << 9, c1));   // (every tile before tix has been counted; tix itself once its first pass is through)
-    const bool stop = __ballot(bad != 0u) || parked;
+    const bool stop = __ballot(bad != 0u) || __builtin_amdgcn_readfirstlane((int)parked);
     if (__ballot(bad != 0u)) { if (bad) atomicOr(&A.ctr->err, bad); p_out = ~0ull; }
     else if (slice_done) p_out = ~0ull;
     if (lane == 0) { u64* rs = C->resume; rs[2 * (u64)wid] = p_out; rs[2 * (u64)wid + 1] = counted; }
