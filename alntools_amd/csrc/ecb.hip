@@ -44,7 +44,9 @@ constexpr u32 MAX_PROBE = 256;       // EC-table probes before a read is deferre
 constexpr u32 PENDING = 0xFFFFFFFFu;
 constexpr u32 ARENA_CHUNK = 512;     // pairs a wave reserves from the key arena per global atomic
 constexpr u32 ARENA_REGIONS = 64;    // the key arena has this many allocation cursors (see arena_alloc)
-constexpr u32 MAX_LOCI = 1u << 27;   // (locus << 5 | hap) + 1 must fit 32 bits
+constexpr u32 KBITS = 26;           // k_stream's LDS keys: locus + 1 in the low KBITS bits, the read's index within the pass above them
+constexpr u32 KMASK = (1u << KBITS) - 1u;
+constexpr u32 MAX_LOCI = KMASK - 1u;
 constexpr u32 INL = 5;               // (locus, mask) pairs of an EC's key held in its table slot; longer keys continue in the arena
 constexpr u32 DEAD_KEY = 0xFFFFFFFFu;   // Slot::n1 of a slot whose key could not be stored (arena exhausted: the run fails)
 constexpr u32 SPIN_MAX = 1u << 16;   // polls of a claimed slot's n1 before giving up (ERR_INTERNAL: the launch winds down; never seen)
@@ -249,22 +251,23 @@ constexpr int NG = RPL / 4;          // groups; group g of lane l holds records 
 constexpr int WT = 64 * RPL;         // records per wave tile
 constexpr int WMAXR = 64;            // reads finished per wave tile (one lane each in phase (c))
 constexpr int NWAVE = TPB / 64;
-#ifndef ECB_SLOT_SHIFT
-#define ECB_SLOT_SHIFT 1
-#endif
 #ifndef ECB_WAVES_PER_SIMD
 #define ECB_WAVES_PER_SIMD 4
 #endif
-constexpr int SLOT_SHIFT = ECB_SLOT_SHIFT;           // table slots per record = 1 + 2^-SLOT_SHIFT (1: 1.5, 2: 1.25)
-constexpr int CPAD = 128;                             // table slots in front of the tile's own: room for the entries a read carries in
-constexpr int CMAX = 80;                              // (locus, mask) entries an unfinished read may carry into the next tile (1.5 slots each <= CPAD)
-constexpr int TSLOTS = CPAD + WT + (WT >> SLOT_SHIFT);   // LDS table slots per wave tile
-static_assert(CMAX + (CMAX >> SLOT_SHIFT) <= CPAD && (TSLOTS * 8) % (16 * 64) == 0, "carry pad / clear loop");
-constexpr u32 SBITS = (TSLOTS <= 1024) ? 10 : 11;   // bits of a table-slot index
+constexpr int CMAX = 80;                              // (locus, mask) entries an unfinished read may carry into the next tile
+constexpr int TSLOTS = 896;                           // LDS table slots per wave and pass (at most WT + CMAX = 592 entries)
+static_assert(TSLOTS >= 512 * 7 / 4 && WT + CMAX < TSLOTS && (TSLOTS * 8) % (16 * 64) == 0, "home regions / a free slot / clear loop");
+constexpr u32 SBITS = 10;                             // bits of a table-slot index
 constexpr u32 SMASK = (1u << SBITS) - 1u;
+static_assert(TSLOTS <= (1 << SBITS), "ent[] packs slot | read << SBITS into 16 bits");
 struct alignas(16) WaveLds {
-    // per-read {locus -> mask} tables, 1.5 slots per record of the read: key = locus + 1, mask = OR of haplotype bits.  Two
-    // arrays, not one of pairs: at an 8-byte stride the compare-and-swaps of a wave land on the even banks only.
+    // ONE {(read, locus) -> haplotype mask} table for the reads of a pass: key = locus + 1 | read index << KBITS, mask = OR of
+    // haplotype bits.  Read r of nb probes from r * G' + (key & (G - 1)), G = 512 >> ceil(log2 nb), G' = 1.75 G: the loci of a
+    // read are mostly consecutive target ids, which the low bits never collide on, the reads' home regions are disjoint, and a
+    // read with more loci than its region simply probes on into its neighbour's (the keys say whose an entry is).  The geometry
+    // is two wave-uniform numbers; per-read extents (a scatter of head positions through LDS, a repack, a gather per record) were
+    // a fifth of the kernel's instructions.
+    // Two arrays, not one of pairs: at an 8-byte stride the compare-and-swaps of a wave land on the even banks only.
 #ifdef ECB_TAB_INTERLEAVED
     uint2 tab[TSLOTS];
 #else
@@ -273,9 +276,8 @@ struct alignas(16) WaveLds {
 #endif
     u64 acc[WMAXR];                  // per read: set-hash sum
     uint2 carry[CMAX];               // the entries of the read that is still open at the end of a tile (x = locus + 1, y = mask)
-    unsigned short ent[WT + CMAX];   // table entries created in this pass: slot | read << 10 (SBITS = 10 at 8 records per lane)
+    unsigned short ent[WT + CMAX];   // table entries created in this pass: slot | read << SBITS
     unsigned short npair[WMAXR];     // per read: number of (locus, mask) pairs
-    u32 seg[WMAXR + 3];              // seg[rl + 1]: first table slot of read rl | end slot << 16; repacked for finished reads
     u32 ws[5];                       // wave scalars that are touched once in a while (scalar registers are scarcer than the few LDS reads):
 };                                   //   [0,1] head record of the open read   [2,3] key-arena reservation: next pair   [4] ... pairs left
 static_assert(sizeof(WaveLds) * NWAVE * ECB_WAVES_PER_SIMD <= 160 * 1024, "four workgroups per CU");
@@ -295,12 +297,6 @@ __device__ __forceinline__ u32* tab_mask(WaveLds& L, u32 q) { return &L.tmask[q]
 __device__ __forceinline__ uint2 tab_get(const WaveLds& L, u32 q) { return make_uint2(L.tkey[q], L.tmask[q]); }
 __device__ __forceinline__ uint4* tab_base(WaveLds& L) { return reinterpret_cast<uint4*>(L.tkey); }
 #endif
-__device__ __forceinline__ u32 tslot(u32 rec) { return rec + (rec >> SLOT_SHIFT); }   // first table slot of a read starting at `rec`
-__device__ __forceinline__ u32 unslot(u32 t) {                                          // inverse, t < 1024
-    if (SLOT_SHIFT == 1) { const u32 m = (t * 683u) >> 11; return 2u * m + (t - 3u * m); }
-    const u32 m = (t * 205u) >> 10; return 4u * m + (t - 5u * m);
-}
-
 // What k_stream needs once in a while sits behind ONE pointer (scalar registers are what this kernel runs out of: every
 // kernel argument occupies a pair for the whole launch, and what does not fit is shuffled through vector lanes).
 struct StreamCold {
@@ -350,36 +346,36 @@ __device__ __forceinline__ u32 group_mask(int lo, int hi) {
 
 struct TileRegs { u32 rr[RPL], ll[RPL], hh[RPL]; };
 
-// "is the key of this slot the target set of my read?" -- the read's set is its {locus -> mask} table in LDS, region
-// [s2, e2) probed from s2 + (key & pm) exactly as phase (b) inserted it.  Both sides hold distinct loci, so equal sizes
-// and every stored pair found with the same mask means the sets are equal.
+// "is the key of this slot the target set of my read?" -- the read's set is what the pass's LDS table holds under its tag,
+// probed from home + (key & pm) exactly as phase (b) inserted it.  Both sides hold distinct loci, so equal sizes and every
+// stored pair found with the same mask means the sets are equal.
 struct LdsSetCmp {
     const WaveLds* L;
-    u32 s2, e2, pm, np;
+    u32 home, pm, tag, np;           // first slot of the read's home region, G - 1, read index << KBITS, number of pairs
     const StreamCold* cold;          // (the key arena, for keys longer than a slot: looked up when one turns up)
     __device__ __forceinline__ int quick(const SlotView& v) const {
         if (v.n != np) return CMP_DIFFERENT;
         uint2 t[INL];                                    // the INL first probes are issued together: one LDS round trip for the lot
 #pragma unroll
-        for (u32 i = 0; i < INL; ++i) t[i] = tab_get(*L, i < v.n ? s2 + ((v.p[i].x + 1u) & pm) : s2);
+        for (u32 i = 0; i < INL; ++i) t[i] = tab_get(*L, i < v.n ? home + ((v.p[i].x + 1u) & pm) : home);
         bool eq = true;
 #pragma unroll
-        for (u32 i = 0; i < INL; ++i) eq &= i >= v.n || (t[i].x == v.p[i].x + 1u && t[i].y == v.p[i].y);
+        for (u32 i = 0; i < INL; ++i) eq &= i >= v.n || (t[i].x == (tag | (v.p[i].x + 1u)) && t[i].y == v.p[i].y);
         if (eq && v.n <= INL) return CMP_EQUAL;          // (the common end: every stored pair sits where its locus probes first, same mask)
         if (!eq) {                                       // rare: a mask not written yet, a locus that probed on, or another key altogether
 #pragma unroll
             for (u32 i = 0; i < INL; ++i) if (i < v.n && v.p[i].y == 0u) return CMP_INCOMPLETE;
 #pragma unroll
             for (u32 i = 0; i < INL; ++i)
-                if (i < v.n && (t[i].x == 0u || (t[i].x == v.p[i].x + 1u && t[i].y != v.p[i].y))) return CMP_DIFFERENT;   // certainly not in my set
-            return CMP_UNSURE;                           // another locus of mine sits at the first probe: full() walks on
+                if (i < v.n && (t[i].x == 0u || (t[i].x == (tag | (v.p[i].x + 1u)) && t[i].y != v.p[i].y))) return CMP_DIFFERENT;   // certainly not in my set
+            return CMP_UNSURE;                           // something else sits at the first probe: full() walks on
         }
         for (u32 i = INL; i < v.n; ++i) {                // the rest of a long key, from the arena
             const uint2 pr = unpack2(__hip_atomic_load(reinterpret_cast<u64*>(cold->arena + (u64)v.off + (i - INL)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             if (pr.y == 0u) return CMP_INCOMPLETE;
-            const uint2 tt = tab_get(*L, s2 + ((pr.x + 1u) & pm));
-            if (tt.x == pr.x + 1u && tt.y == pr.y) continue;
-            return (tt.x == 0u || tt.x == pr.x + 1u) ? CMP_DIFFERENT : CMP_UNSURE;
+            const uint2 tt = tab_get(*L, home + ((pr.x + 1u) & pm));
+            if (tt.x == (tag | (pr.x + 1u)) && tt.y == pr.y) continue;
+            return (tt.x == 0u || tt.x == (tag | (pr.x + 1u))) ? CMP_DIFFERENT : CMP_UNSURE;
         }
         return CMP_EQUAL;
     }
@@ -388,14 +384,15 @@ struct LdsSetCmp {
         for (u32 i = 0; i < n; ++i) {
             const uint2 pr = key_pair_fresh(s, cold->arena, off, i);
             if (pr.y == 0u) return CMP_INCOMPLETE;
-            const u32 key = pr.x + 1u;
-            u32 q = s2 + (key & pm);
+            if (pr.x >= KMASK) return CMP_DIFFERENT;     // (no read of this kernel holds such a locus)
+            const u32 key = tag | (pr.x + 1u);
+            u32 q = home + ((pr.x + 1u) & pm);
             bool found = false;
-            for (u32 n = s2; n < e2; ++n) {              // (bounded by the region: a read's table always has a free slot)
+            for (u32 it = 0; it < (u32)TSLOTS; ++it) {   // (the table always has a free slot)
                 const uint2 t = tab_get(*L, q);
                 if (t.x == key) { found = t.y == pr.y; break; }
                 if (t.x == 0u) break;
-                if (++q == e2) q = s2;
+                if (++q == (u32)TSLOTS) q = 0;
             }
             if (!found) return CMP_DIFFERENT;
         }
@@ -411,6 +408,12 @@ struct LdsSetCmp {
 #define TICK(i) do { } while (0)
 #endif
 
+// First record of read `rd` among records [b, e) -- the run counter never decreases, and it steps ON a read's first record
+// (the rare paths that hand a read to k_slow ask; nothing on the way of an ordinary tile keeps head positions)
+__device__ __forceinline__ u64 tile_head(const u32* rid, u64 b, u64 e, u32 rd) {
+    while (b < e) { const u64 m = b + ((e - b) >> 1); if ((int)(rid[m] - rd) < 0) b = m + 1; else e = m; }
+    return b;
+}
 __device__ __forceinline__ void load_tile(const StreamArgs& A, u64 tb, u64 te, u32 lane, TileRegs& R) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     tb = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(tb >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)tb);   // (wave-uniform: say so)
@@ -563,7 +566,9 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                             const u32 step = R.rr[k] - (j == 0 ? prev0 : R.rr[k > 0 ? k - 1 : 0]);
                             r_rh[k] = min(R.rr[k] - base, 1023u) | (((f >> ECB_HAP_SHIFT) & 31u) << 10);
                             r_key[k] = R.ll[k] + 1u;
-                            hap_or |= f & (0u - ((ok4 >> j) & 1u));          // (a haplotype index of 32 or more would alias a low bit above)
+                            // (a haplotype index of 32 or more would alias a low bit above, a locus of KMASK or more the read tag of the
+                            //  LDS keys: both show in the bits from 21 up)
+                            hap_or |= ((r_key[k] & ~KMASK) | f) & (0u - ((ok4 >> j) & 1u));
                             head4 |= (step & 1u) << j;
                         }
                     } else {
@@ -622,42 +627,17 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                 for (int t = 0; t < (TSLOTS * 8) / (16 * 64); ++t) z[t * 64 + ln] = zv;
                 *reinterpret_cast<uint2*>(&L.acc[ln]) = make_uint2(zz, zz); L.npair[ln] = (unsigned short)zz;
             }
-            {   // a head at record x starts its read and ends the one before it; stored as table-slot offsets
-                unsigned short* sh = reinterpret_cast<unsigned short*>(L.seg);
-                u32 lx = (u32)CPAD + (4u + (4u >> SLOT_SHIFT)) * ln;
-                asm volatile("" : "+v"(lx));      // (opaque per pass: hoisted out of the loop, the eight sums below lived in registers and were spilled)
-#pragma unroll
-                for (int k = 0; k < RPL; ++k) {
-                    const u32 rel = (r_rh[k] & 1023u) - r_lo;
-                    if ((m_head >> k & 1u) && rel <= (u32)WMAXR) {
-                        // tslot(4*ln + c) = 6*ln + tslot(c) for even-multiple-of-4 offsets: one add per record
-                        const unsigned short x = (unsigned short)(lx + tslot((k & 3) + (k >> 2) * 256));
-                        sh[2 * rel + 2] = x;                           // start of read rel   (seg is indexed rel + 1)
-                        sh[2 * rel + 1] = x;                           // end of read rel - 1 (lands in the unused seg[0] for rel = 0)
-                    }
+            // The table's geometry (see WaveLds): two wave-uniform numbers
+            const u32 lg = nb > 1u ? 32u - (u32)__builtin_clz(nb - 1u) : 0u;       // ceil(log2 nb)
+            const u32 pm = (512u >> lg) - 1u, gp = (512u >> lg) + (256u >> lg) + (128u >> lg);
+            if (r_lo + nb == n_build) {                                 // head of the tile's last read (kept if it stays open): the tile's last head
+                const u64 h1 = __ballot((m_head >> 4) != 0u), h0 = __ballot((m_head & 15u) != 0u);
+                if (h1 | h0) {
+                    const u32 l = 63u - (u32)__builtin_clzll(h1 ? h1 : h0);
+                    const u32 bits = (u32)__builtin_amdgcn_readlane((int)m_head, (int)l);
+                    const u32 k = 31u - (u32)__builtin_clz(h1 ? bits & 0xF0u : bits & 0xFu);
+                    last_pos = (k & 3u) + (k >> 2) * 256u + 4u * l;
                 }
-                if (ln == 0) {
-                    if (open && r_lo == 0u) sh[2] = 0;                 // the open read's table starts with the pad its carried entries go to
-                    if (n_in - r_lo <= (u32)WMAXR) {                   // the tile's last read ends with the tile
-                        const unsigned short x = (unsigned short)((u32)CPAD + tslot((u32)te_rel));
-                        sh[2 * (n_in - r_lo) + 1] = x;
-                    }
-                }
-            }
-            wave_sync();
-            // Every read of the pass gets its table geometry packed once: first slot (SBITS bits) | end slot (SBITS) | mask of
-            // the largest power of two within the range (10 bits).  Probing starts at first + (locus & mask): the loci of a read are
-            // mostly consecutive target ids, which low bits never collide on -- cheaper than a multiplicative hash and the
-            // collision path below becomes rare.
-            u32 my_start = 0;
-            if (ln < nb) {
-                const u32 sg = L.seg[ln + 1], s2 = sg & 0xFFFFu, e2 = sg >> 16;
-                my_start = s2;
-                L.seg[ln + 1] = s2 | (e2 << SBITS) | (min((1u << (31 - __clz((int)(e2 - s2)))) - 1u, 0x3FFu) << (2 * SBITS));
-            }
-            if (r_lo + nb == n_build && n_build != 0u) {             // head of the tile's last read (kept if it stays open)
-                const u32 st_last = (u32)__builtin_amdgcn_readlane((int)my_start, (int)(nb - 1u));
-                if (!(open && n_in == 1u)) last_pos = unslot(st_last - (u32)CPAD);
             }
             wave_sync();
 
@@ -677,9 +657,10 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                 u32 c_key = 0, c_bit = 0;
                 if (cin && ln < carry_n) { const uint2 cv = L.carry[ln]; c_key = cv.x; c_bit = cv.y; act |= 1u << RPL; }
 #pragma unroll
-                for (int k = 0; k < RPL; ++k) {
+                for (int k = 0; k < RPL; ++k) {                      // records of this pass's reads; their keys get the read's tag
                     const u32 rel = (r_rh[k] & 1023u) - r_lo;
                     act |= ((m_ok >> k) & (u32)(rel < nb) & 1u) << k;
+                    r_key[k] |= rel << KBITS;                        // (records of no read of the pass: whatever -- they swap nothing)
                 }
                 // Two rounds: the even record positions (and the carried entry), then the odd ones -- nine compare-and-swap
                 // results in flight at once are more registers than the kernel has, and in a paired-end stream the odd (or the
@@ -689,16 +670,13 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                     const u32 hmask = h ? 0x0AAu : 0x155u;           // positions of this round (bit RPL: the carried entry)
                     if (__ballot((act & hmask) != 0u) == 0ull) continue;
 #pragma unroll
-                    for (int k = h; k <= RPL; k += 2)
-                        q[k] = L.seg[k < RPL ? ((act >> k & 1u) ? (r_rh[k < RPL ? k : 0] & 1023u) - r_lo + 1u : 0u) : 1u];
-#pragma unroll
-                    for (int k = h; k <= RPL; k += 2) {  // (all geometry reads are in flight before the first is used, and none hides in a lane branch)
-                        asm volatile("" : "+v"(q[k]));
-                        const u32 sg = q[k];
-                        q[k] = (act >> k & 1u) ? (sg & SMASK) + ((k < RPL ? r_key[k < RPL ? k : 0] : c_key) & (sg >> (2 * SBITS))) : ln;
+                    for (int k = h; k <= RPL; k += 2) {  // (lanes without a record here swap nothing: they expect a value no slot ever holds, at a slot of their own)
+                        const u32 key = k < RPL ? r_key[k < RPL ? k : 0] : c_key;
+                        const u32 rel = k < RPL ? (r_rh[k < RPL ? k : 0] & 1023u) - r_lo : 0u;
+                        q[k] = (act >> k & 1u) ? rel * gp + (key & pm) : ln;
                     }
 #pragma unroll
-                    for (int k = h; k <= RPL; k += 2)    // (lanes without a record here swap nothing: they expect a value no slot ever holds, at a slot of their own)
+                    for (int k = h; k <= RPL; k += 2)
                         old[k] = atomicCAS(tab_key(L, q[k]), (act >> k & 1u) ? 0u : 0xFFFFFFFFu, k < RPL ? r_key[k < RPL ? k : 0] : c_key);
 #pragma unroll
                     for (int k = h; k <= RPL; k += 2) {
@@ -715,7 +693,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                         n_ent += (u32)__popcll(mm);
                     }
                 }
-                if (__ballot(coll != 0u) || (cin && carry_n > 64u)) {    // slot taken by another locus of the read: probe on (rare)
+                if (__ballot(coll != 0u) || (cin && carry_n > 64u)) {    // slot taken by another (read, locus): probe on (rare)
 #pragma unroll
                     for (int k = 0; k <= RPL; ++k) {
                         const u32 key = k < RPL ? r_key[k] : c_key, bit = k < RPL ? 1u << (r_rh[k < RPL ? k : 0] >> 10) : c_bit;
@@ -723,17 +701,13 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                         const bool go = coll >> k & 1u;
                         bool made = false;
                         if (go) {
-                            const u32 sg = L.seg[rel + 1u];
-                            const u32 s2 = sg & SMASK, e2 = (sg >> SBITS) & SMASK;
-                            u32 o;
-                            bool lapped = false, stuck = false;  // (a read's range always has a free slot: the second lap only keeps a
-                            do {                                 //  corrupted geometry from spinning a wave for ever)
-                                if (++q[k] >= e2) { q[k] = s2; stuck = lapped; lapped = true; }
+                            u32 o, it = 0;                       // (the table always has a free slot: the bound only keeps corrupted
+                            do {                                 //  state from spinning a wave for ever)
+                                if (++q[k] >= (u32)TSLOTS) q[k] = 0;
                                 o = atomicCAS(tab_key(L, q[k]), 0u, key);
-                            } while (o != 0u && o != key && !stuck);
-                            if (stuck) bad |= ERR_CONTRACT;
-                            made = (o == 0u);
-                            atomicOr(tab_mask(L, q[k]), bit);
+                            } while (o != 0u && o != key && ++it < (u32)TSLOTS);
+                            if (o != 0u && o != key) bad |= ERR_INTERNAL;
+                            else { made = (o == 0u); atomicOr(tab_mask(L, q[k]), bit); }
                         }
                         const u64 mm = __ballot(made);
                         if (made) L.ent[n_ent + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u))] =
@@ -743,19 +717,16 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                     if (cin && carry_n > 64u) {                          // carried entries 64 .. CMAX - 1: a (rare) round of their own
                         const bool go = ln + 64u < carry_n;
                         const uint2 cv = L.carry[go ? ln + 64u : 0u];
-                        const u32 sg = L.seg[1], s2 = sg & SMASK, e2 = (sg >> SBITS) & SMASK;
-                        u32 qq = s2 + (cv.x & (sg >> (2 * SBITS)));
+                        u32 qq = cv.x & pm;
                         bool made = false;
                         if (go) {
-                            u32 o = atomicCAS(tab_key(L, qq), 0u, cv.x);
-                            bool lapped = false, stuck = false;
-                            while (o != 0u && o != cv.x && !stuck) {
-                                if (++qq >= e2) { qq = s2; stuck = lapped; lapped = true; }
+                            u32 o = atomicCAS(tab_key(L, qq), 0u, cv.x), it = 0;
+                            while (o != 0u && o != cv.x && ++it < (u32)TSLOTS) {
+                                if (++qq >= (u32)TSLOTS) qq = 0;
                                 o = atomicCAS(tab_key(L, qq), 0u, cv.x);
                             }
-                            if (stuck) bad |= ERR_CONTRACT;
-                            made = (o == 0u);
-                            atomicOr(tab_mask(L, qq), cv.y);
+                            if (o != 0u && o != cv.x) bad |= ERR_INTERNAL;
+                            else { made = (o == 0u); atomicOr(tab_mask(L, qq), cv.y); }
                         }
                         const u64 mm = __ballot(made);
                         if (made) L.ent[n_ent + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u))] = (unsigned short)qq;
@@ -775,13 +746,13 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                 const uint2 en2 = tab_get(L, qq);
                 const bool kept = have && keep && rl == rl_last;
                 if (have && !kept) {
-                    atomicAdd(&L.acc[rl], pair_hash64(en2.x - 1u, en2.y));
+                    atomicAdd(&L.acc[rl], pair_hash64((en2.x & KMASK) - 1u, en2.y));
                     atomicAdd(reinterpret_cast<u32*>(&L.npair[rl & ~1u]), (rl & 1u) ? 0x10000u : 1u);   // two 16-bit counters per word
                 }
                 if (keep) {
                     const u64 mm = __ballot(kept);
                     const u32 at = cn + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u));
-                    if (kept && at < (u32)CMAX) L.carry[at] = en2;
+                    if (kept && at < (u32)CMAX) L.carry[at] = make_uint2(en2.x & KMASK, en2.y);
                     cn += (u32)__popcll(mm);
                 }
             }
@@ -796,10 +767,8 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
             const bool on = ln < nproc && !(A.ablate & 3u);
             const u32 rd = base + r_lo + ln;
             LdsSetCmp cmp;
-            cmp.L = &L; cmp.cold = C; cmp.s2 = cmp.e2 = cmp.pm = cmp.np = 0;
+            cmp.L = &L; cmp.cold = C; cmp.home = ln * gp; cmp.pm = pm; cmp.tag = ln << KBITS; cmp.np = 0;
             if (on) {
-                const u32 sg = L.seg[ln + 1];
-                cmp.s2 = sg & SMASK; cmp.e2 = (sg >> SBITS) & SMASK; cmp.pm = sg >> (2 * SBITS);
                 np = L.npair[ln];
                 cmp.np = np;
                 lo = finish_hash(L.acc[ln], np);
@@ -884,7 +853,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                                 const u32 pos = ((rl & 1u) ? was >> 16 : was & 0xFFFFu) - 1u;   // a place of its own among the read's pairs
                                 uint2* dst = pos < INL ? &A.table[jj].pair[pos] : arena + ((u64)o + (pos - INL));
                                 const uint2 en2 = tab_get(L, qq);
-                                store_wt64(reinterpret_cast<u64*>(dst), pack2(make_uint2(en2.x - 1u, en2.y)));
+                                store_wt64(reinterpret_cast<u64*>(dst), pack2(make_uint2((en2.x & KMASK) - 1u, en2.y)));
                             }
                         }
                         if (cr) { publish_key(A.table + j, dead ? DEAD_KEY : np + 1u, off); st = ST_HIT; }   // (no wait: readers tell a whole key from its masks)
@@ -902,7 +871,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                 if (st == ST_FULL) {                                    // table too full here: defer the read, park
                     atomicExch(&A.ctr->full, 1u);
                     const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
-                    const u64 head = (open && r_lo == 0u && ln == 0u) ? ws_get64(L, 0) : ((u64)tix << 9) + unslot((L.seg[ln + 1] & SMASK) - (u32)CPAD);
+                    const u64 head = (open && r_lo == 0u && ln == 0u) ? ws_get64(L, 0) : tile_head(A.rid, (u64)tix << 9, min(((u64)tix << 9) + (u64)WT, A.n), rd);
                     if (qi < C->queue_cap) C->queue[qi] = head; else atomicOr(&A.ctr->err, ERR_QUEUE);
                 } else if (st == ST_HIT) {
                     A.read_slot[rd] = (u32)j;
@@ -984,18 +953,32 @@ __global__ __launch_bounds__(1024) void k_sum_counts(const u32* wave_counts, u64
 }
 
 // reference_start ranges per target (bam_utils.py:282-286): a separate pass, only with ECB_F_RANGES
+// Four records per lane and load (16 B/lane, like k_stream); the 2 x n_loci x n_haps bounds stay in L2, and a record only
+// issues an atomic when it moves a bound, which almost none do after the first few thousand.
+__device__ __forceinline__ void range_one(u32 lc, u32 f, int ps, u32 n_loci, u32 n_haps, int* rng_min, int* rng_max) {
+    if (!rec_valid(f)) return;
+    const u32 hap = (f >> ECB_HAP_SHIFT) & 0xFFu;
+    if (lc >= n_loci || hap >= n_haps) return;                // k_stream reports these
+    const u32 sl = lc * n_haps + hap;
+    if (ps < rng_min[sl]) atomicMin(rng_min + sl, ps);
+    if (ps > rng_max[sl]) atomicMax(rng_max + sl, ps);
+}
 __global__ __launch_bounds__(TPB) void k_ranges(const u32* loc, const u32* hf, const int* pos, u64 n, u32 n_loci, u32 n_haps,
                                                 int* rng_min, int* rng_max) {
-    for (u64 i = (u64)blockIdx.x * TPB + threadIdx.x; i < n; i += (u64)gridDim.x * TPB) {
-        const u32 f = hf[i];
-        if (!rec_valid(f)) continue;
-        const u32 lc = loc[i], hap = (f >> ECB_HAP_SHIFT) & 0xFFu;
-        if (lc >= n_loci || hap >= n_haps) continue;          // k_stream reports these
-        const u64 sl = (u64)lc * n_haps + hap;
-        const int ps = pos[i];
-        if (ps < rng_min[sl]) atomicMin(rng_min + sl, ps);
-        if (ps > rng_max[sl]) atomicMax(rng_max + sl, ps);
+    const u64 n4 = n / 4, step = (u64)gridDim.x * TPB;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4* l4 = (const u32x4*)loc; const u32x4* f4 = (const u32x4*)hf; const u32x4* p4 = (const u32x4*)pos;
+    for (u64 i = (u64)blockIdx.x * TPB + threadIdx.x; i < n4; i += step) {
+        const u32x4 l = __builtin_nontemporal_load(l4 + i), f = __builtin_nontemporal_load(f4 + i);
+        const u32x4 q = __builtin_nontemporal_load(p4 + i);
+        const int4 p = make_int4((int)q.x, (int)q.y, (int)q.z, (int)q.w);
+        range_one(l.x, f.x, p.x, n_loci, n_haps, rng_min, rng_max);
+        range_one(l.y, f.y, p.y, n_loci, n_haps, rng_min, rng_max);
+        range_one(l.z, f.z, p.z, n_loci, n_haps, rng_min, rng_max);
+        range_one(l.w, f.w, p.w, n_loci, n_haps, rng_min, rng_max);
     }
+    const u64 t = n4 * 4 + (u64)blockIdx.x * TPB + threadIdx.x;
+    if (t < n) range_one(loc[t], hf[t], pos[t], n_loci, n_haps, rng_min, rng_max);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2412,7 +2395,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     POOL(h, P_RESUME, d_resume, 2 * waves);
     k_init_resume<<<nblk(waves, TPB), TPB, 0, h->stream>>>(d_resume, waves, chunk);
     if (h->rng_min)
-        k_ranges<<<(unsigned)std::min<u64>(4096, (n + TPB - 1) / TPB), TPB, 0, h->stream>>>(
+        k_ranges<<<(unsigned)std::min<u64>(8192, (n / 4 + TPB) / TPB), TPB, 0, h->stream>>>(
             d_loc, d_hf, d_pos, n, h->cfg.n_loci, h->cfg.n_haplotypes, h->rng_min, h->rng_max);
     u32* d_wcounts = nullptr;
     POOL(h, P_WCOUNTS, d_wcounts, 3 * pwaves);
@@ -2702,7 +2685,7 @@ const char* ecb_last_error(const ecb_handle* h) { return h ? h->err.c_str() : g_
 
 int ecb_create(const ecb_config* cfg, ecb_handle** out) {
     if (!cfg || !out || cfg->struct_size != sizeof(ecb_config)) return fail(nullptr, ECB_ERR_ARG, "bad ecb_config (struct_size)");
-    if (cfg->n_loci == 0 || cfg->n_loci >= MAX_LOCI) return fail(nullptr, ECB_ERR_ARG, "n_loci out of range (1 .. 2^27-1)");
+    if (cfg->n_loci == 0 || cfg->n_loci >= MAX_LOCI) return fail(nullptr, ECB_ERR_ARG, "n_loci out of range (1 .. 2^26-3)");
     if (cfg->n_haplotypes == 0 || cfg->n_haplotypes > 31) return fail(nullptr, ECB_ERR_ARG, "n_haplotypes must be 1..31 (A stores a bitmask in int32)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, ECB_ERR_NO_DEVICE, "no HIP device: libecb has no CPU path");
@@ -2818,7 +2801,7 @@ int ecb_push_device(ecb_handle* h, const void* d_read_id, const void* d_locus, c
     if (h->finalized || h->counted) return fail(h, ECB_ERR_STATE, "push after finalize / table export");
     if (n && (!d_read_id || !d_locus || !d_hapflag)) return fail(h, ECB_ERR_ARG, "null tuple stream");
     if ((h->cfg.flags & ECB_F_RANGES) && n && !d_pos) return fail(h, ECB_ERR_ARG, "ECB_F_RANGES needs pos");
-    if (((uintptr_t)d_read_id | (uintptr_t)d_locus | (uintptr_t)d_hapflag) & 15) return fail(h, ECB_ERR_ARG, "device streams must be 16-byte aligned");
+    if (((uintptr_t)d_read_id | (uintptr_t)d_locus | (uintptr_t)d_hapflag | (uintptr_t)d_pos) & 15) return fail(h, ECB_ERR_ARG, "device streams must be 16-byte aligned");
     if (!h->c_rid.empty()) return fail(h, ECB_ERR_STATE, "ecb_push_device while a host push has an open read");
     HIPCHK(h, hipSetDevice(h->device));
     return process_batch(h, (const u32*)d_read_id, (const u32*)d_locus, (const u32*)d_hapflag, (const int*)d_pos, n);
