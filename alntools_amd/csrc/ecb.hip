@@ -527,10 +527,13 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
         // ---- (a) filter, heads -------------------------------------------------------------------
         // Written with integer bit arithmetic throughout: every instruction costs an issue slot, and
         // compare -> mask -> select chains were a third of this kernel's instruction count.
-        // locus + 1; read index within the tile (10 bits, 1023 = before the tile's first read) | haplotype index << 10 -- one
-        // register for the two: phase (b) holds nine compare-and-swap results on top of these
-        u32 r_key[RPL], r_rh[RPL];
-        u32 m_ok = 0, m_head = 0;                  // bit k: valid & in range / head
+        // Per record: its LDS key (locus + 1 | index of its read within the pass << KBITS) and its haplotype bit -- all that
+        // phase (b) needs of it; which records phase (b) takes at all (valid, of a read of this pass) is settled here too:
+        // the reads of a tile of mine are numbered base ..., so "one of the pass's WMAXR reads" is one unsigned comparison.
+        u32 r_key[RPL], r_bit[RPL];
+        u32 m_act = 0, m_head = 0;                 // bit k: valid record of a read of this pass / head
+        const u32 base_lo = base + r_lo;
+        const u32 lim = own ? (u32)WMAXR : ((open && r_lo == 0u) ? 1u : 0u);   // (past my slice only the open read is mine)
         {
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                     in4 = te4 & ~((1u << clamp04(p_rel - i0, 0, 4)) - 1u);
                 }
                 const u32 prev0 = ln == 0 ? wrap : up;
-                u32 ok4 = 0, head4 = 0, hap_or = 0;
+                u32 ok4 = 0, head4 = 0, hap_or = 0, mine4 = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const u32 f = R.hh[4 * g + j], nf = ~f;
@@ -564,16 +567,21 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                             const int k = 4 * g + j;
                             const u32 f = R.hh[k];
                             const u32 step = R.rr[k] - (j == 0 ? prev0 : R.rr[k > 0 ? k - 1 : 0]);
-                            r_rh[k] = min(R.rr[k] - base, 1023u) | (((f >> ECB_HAP_SHIFT) & 31u) << 10);
-                            r_key[k] = R.ll[k] + 1u;
-                            // (a haplotype index of 32 or more would alias a low bit above, a locus of KMASK or more the read tag of the
+                            const u32 relx = R.rr[k] - base_lo;              // (records before the pass's first read: huge)
+                            const u32 t = R.ll[k] + 1u;
+                            r_key[k] = t | (relx << KBITS);
+                            r_bit[k] = 1u << ((f >> ECB_HAP_SHIFT) & 31u);
+                            // (a haplotype index of 32 or more would alias a low one, a locus of KMASK or more the read tag of the
                             //  LDS keys: both show in the bits from 21 up)
-                            hap_or |= ((r_key[k] & ~KMASK) | f) & (0u - ((ok4 >> j) & 1u));
+                            hap_or |= ((t & ~KMASK) | f) & (u32)((int)(ok4 << (31 - j)) >> 31);
                             head4 |= (step & 1u) << j;
+                            mine4 |= (relx < lim ? 1u : 0u) << j;
                         }
                     } else {
 #pragma unroll
-                        for (int j = par; j < 4; j += 2) { r_rh[4 * g + j] = 1023u; r_key[4 * g + j] = 0u; }
+                        for (int j = par; j < 4; j += 2) {   // (no lane has a record at these positions: any value will do, none is used)
+                            asm volatile("" : "=v"(r_key[4 * g + j])); asm volatile("" : "=v"(r_bit[4 * g + j]));
+                        }
                     }
                 }
                 // the run counter may only step by 0 or 1, and only on a valid record: then, and only then, the steps seen at the
@@ -583,7 +591,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                 ok4 &= in4; head4 &= in4;
                 bad |= ((p_rel == 0 ? big : 0u) | (head4 & ~ok4)) ? ERR_CONTRACT : 0u;   // (the tile a park resumes in was checked before the park)
                 bad |= (hap_or >> (ECB_HAP_SHIFT + 5)) ? ERR_RANGE : 0u;      // (indices below 32 are checked against n_haplotypes per EC, at emit)
-                m_ok |= ok4 << (4 * g); m_head |= head4 << (4 * g);
+                m_act |= (ok4 & mine4) << (4 * g); m_head |= head4 << (4 * g);
             }
         }
         if (count_tile) s_all += (u32)te_rel;                      // records offered (bam_utils.py:261)
@@ -653,15 +661,10 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                 // round (a chain of LDS round trips of its own cost a fifth of the tile): entry c of the carry list is lane c's
                 // ninth "record" -- its haplotype "bit" is the whole mask so far.  (More than 64 of them: a second such round.)
                 const bool cin = open && r_lo == 0u && carry_n != 0u;
-                u32 q[RPL + 1], old[RPL + 1], act = 0, coll = 0;
+                u32 q[RPL + 1], old[RPL + 1], act = m_act;
+                bool anyc = false;                                   // some lane found its first slot taken by another (read, locus)
                 u32 c_key = 0, c_bit = 0;
                 if (cin && ln < carry_n) { const uint2 cv = L.carry[ln]; c_key = cv.x; c_bit = cv.y; act |= 1u << RPL; }
-#pragma unroll
-                for (int k = 0; k < RPL; ++k) {                      // records of this pass's reads; their keys get the read's tag
-                    const u32 rel = (r_rh[k] & 1023u) - r_lo;
-                    act |= ((m_ok >> k) & (u32)(rel < nb) & 1u) << k;
-                    r_key[k] |= rel << KBITS;                        // (records of no read of the pass: whatever -- they swap nothing)
-                }
                 // Two rounds: the even record positions (and the carried entry), then the odd ones -- nine compare-and-swap
                 // results in flight at once are more registers than the kernel has, and in a paired-end stream the odd (or the
                 // even) positions are the mate records, which the filter drops: a round no lane has a record in is skipped.
@@ -672,47 +675,49 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
 #pragma unroll
                     for (int k = h; k <= RPL; k += 2) {  // (lanes without a record here swap nothing: they expect a value no slot ever holds, at a slot of their own)
                         const u32 key = k < RPL ? r_key[k < RPL ? k : 0] : c_key;
-                        const u32 rel = k < RPL ? (r_rh[k < RPL ? k : 0] & 1023u) - r_lo : 0u;
-                        q[k] = (act >> k & 1u) ? rel * gp + (key & pm) : ln;
+                        q[k] = (act >> k & 1u) ? (key >> KBITS) * gp + (key & pm) : ln;
                     }
 #pragma unroll
                     for (int k = h; k <= RPL; k += 2)
                         old[k] = atomicCAS(tab_key(L, q[k]), (act >> k & 1u) ? 0u : 0xFFFFFFFFu, k < RPL ? r_key[k < RPL ? k : 0] : c_key);
 #pragma unroll
                     for (int k = h; k <= RPL; k += 2) {
-                        const u32 key = k < RPL ? r_key[k < RPL ? k : 0] : c_key, bit = k < RPL ? 1u << (r_rh[k < RPL ? k : 0] >> 10) : c_bit;
-                        const u32 rel = k < RPL ? (r_rh[k < RPL ? k : 0] & 1023u) - r_lo : 0u;
+                        const u32 key = k < RPL ? r_key[k < RPL ? k : 0] : c_key, bit = k < RPL ? r_bit[k < RPL ? k : 0] : c_bit;
                         const bool on = act >> k & 1u;
                         const bool made = on && old[k] == 0u;                // this lane created the (read, locus) entry
                         const bool hit = made || (on && old[k] == key);
-                        coll |= (u32)(on && !hit) << k;
+                        anyc |= on && !hit;
                         atomicOr(tab_mask(L, q[k]), hit ? bit : 0u);         // duplicate (read, target) records vanish here: bam_utils.py:322-325
                         const u64 mm = __ballot(made);
                         if (made) L.ent[n_ent + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u))] =
-                            (unsigned short)(q[k] | (rel << SBITS));
+                            (unsigned short)(q[k] | ((key >> KBITS) << SBITS));
                         n_ent += (u32)__popcll(mm);
                     }
                 }
-                if (__ballot(coll != 0u) || (cin && carry_n > 64u)) {    // slot taken by another (read, locus): probe on (rare)
+                if (__ballot(anyc) || (cin && carry_n > 64u)) {
+                    // Rare: probe on.  Every record goes through the whole protocol once more (its first slot again, then the ones
+                    // behind it): the lanes the rounds above served find their own entry and OR the same bit into it.
+                    if (__ballot(anyc)) {
 #pragma unroll
-                    for (int k = 0; k <= RPL; ++k) {
-                        const u32 key = k < RPL ? r_key[k] : c_key, bit = k < RPL ? 1u << (r_rh[k < RPL ? k : 0] >> 10) : c_bit;
-                        const u32 rel = k < RPL ? (r_rh[k < RPL ? k : 0] & 1023u) - r_lo : 0u;
-                        const bool go = coll >> k & 1u;
-                        bool made = false;
-                        if (go) {
-                            u32 o, it = 0;                       // (the table always has a free slot: the bound only keeps corrupted
-                            do {                                 //  state from spinning a wave for ever)
-                                if (++q[k] >= (u32)TSLOTS) q[k] = 0;
-                                o = atomicCAS(tab_key(L, q[k]), 0u, key);
-                            } while (o != 0u && o != key && ++it < (u32)TSLOTS);
-                            if (o != 0u && o != key) bad |= ERR_INTERNAL;
-                            else { made = (o == 0u); atomicOr(tab_mask(L, q[k]), bit); }
+                        for (int k = 0; k <= RPL; ++k) {
+                            const u32 key = k < RPL ? r_key[k < RPL ? k : 0] : c_key, bit = k < RPL ? r_bit[k < RPL ? k : 0] : c_bit;
+                            u32 qq = (key >> KBITS) * gp + (key & pm);
+                            bool made = false;
+                            if (act >> k & 1u) {
+                                u32 o, it = 0;                       // (the table always has a free slot: the bound only keeps corrupted
+                                for (;;) {                           //  state from spinning a wave for ever)
+                                    o = atomicCAS(tab_key(L, qq), 0u, key);
+                                    if (o == 0u || o == key || ++it >= (u32)TSLOTS) break;
+                                    if (++qq >= (u32)TSLOTS) qq = 0;
+                                }
+                                if (o != 0u && o != key) bad |= ERR_INTERNAL;
+                                else { made = (o == 0u); atomicOr(tab_mask(L, qq), bit); }
+                            }
+                            const u64 mm = __ballot(made);
+                            if (made) L.ent[n_ent + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u))] =
+                                (unsigned short)(qq | ((key >> KBITS) << SBITS));
+                            n_ent += (u32)__popcll(mm);
                         }
-                        const u64 mm = __ballot(made);
-                        if (made) L.ent[n_ent + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u))] =
-                            (unsigned short)(q[k] | (rel << SBITS));
-                        n_ent += (u32)__popcll(mm);
                     }
                     if (cin && carry_n > 64u) {                          // carried entries 64 .. CMAX - 1: a (rare) round of their own
                         const bool go = ln + 64u < carry_n;
@@ -720,10 +725,11 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                         u32 qq = cv.x & pm;
                         bool made = false;
                         if (go) {
-                            u32 o = atomicCAS(tab_key(L, qq), 0u, cv.x), it = 0;
-                            while (o != 0u && o != cv.x && ++it < (u32)TSLOTS) {
-                                if (++qq >= (u32)TSLOTS) qq = 0;
+                            u32 o, it = 0;
+                            for (;;) {
                                 o = atomicCAS(tab_key(L, qq), 0u, cv.x);
+                                if (o == 0u || o == cv.x || ++it >= (u32)TSLOTS) break;
+                                if (++qq >= (u32)TSLOTS) qq = 0;
                             }
                             if (o != 0u && o != cv.x) bad |= ERR_INTERNAL;
                             else { made = (o == 0u); atomicOr(tab_mask(L, qq), cv.y); }
