@@ -72,9 +72,10 @@ for N in (1, 2, 4, 8):
         del pieces
     rk = max(sum(x) for x in rank_ms)
     print("ranges N=%d: rank-side max %.2f ms (push %.2f, counts %.2f, cut+export %.2f) | my range: merge+export %.2f ms | root: adopt %.2f + "
-          "finalize %.2f ms | sent per rank %.0f MB, to root %.0f MB | model step %.2f ms  ECs %d" % (
+          "finalize %.2f ms | sent per rank %.0f MB, to root %.0f MB (xGMI at 153 GB/s per link, every peer on its own link: %.2f + %.2f ms, not in the model) | "
+          "model step %.2f ms  ECs %d" % (
               N, rk, max(x[0] for x in rank_ms), max(x[1] for x in rank_ms), max(x[2] for x in rank_ms), max(part_ms), adopt_ms,
-              (t6 - t5) * 1e3, max(sent), sum(moved[1:]), rk + max(part_ms) + adopt_ms + (t6 - t5) * 1e3, sz["n_ecs"]), flush=True)
+              (t6 - t5) * 1e3, max(sent), sum(moved[1:]), (max(sent) / max(N - 1, 1)) / 153.0, (max(moved[1:]) if N > 1 else 0.0) / 153.0, rk + max(part_ms) + adopt_ms + (t6 - t5) * 1e3, sz["n_ecs"]), flush=True)
 
 for N in (1, 2, 4, 8):
     for rep in range(2):

@@ -9,9 +9,9 @@ python - "$f" <<'PY'
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-# the last step = from the last k_stream<false> back to the memsets before it .. end
+# the last two steps: from the second-to-last k_stream<false> on (the reset's fills of the last step sit between them)
 ks = [i for i, r in enumerate(rows) if 'k_stream' in r['Kernel_Name']]
-i0 = ks[-1]
+i0 = ks[-2]
 t0 = int(rows[i0]['Start_Timestamp']); prev_end = t0
 print("%-28s %10s %10s %10s" % ("kernel", "start_us", "dur_us", "gap_us"))
 for r in rows[i0:]:
