@@ -992,16 +992,16 @@ __global__ __launch_bounds__(TPB) void k_ranges(const u32* loc, const u32* hf, c
 // per-read slot ids without global atomics: partition the (slot, read) pairs by slot range (LDS
 // histogram, scan, scatter), then one workgroup per range counts in LDS and owns its slots' counters.
 // ---------------------------------------------------------------------------------------------
-constexpr u32 BIN_BITS = 13;                   // slots per range = LDS bins of one k_count_bins workgroup
-constexpr u32 N_BINS = 1u << BIN_BITS;
-constexpr u32 MAX_BUCKETS = 8192;              // LDS histogram of the partition passes
+constexpr u32 BIN_BITS = 13;                   // slots per range = LDS bins of one k_count_bins workgroup: 2^13 up to a table of
+constexpr u32 MAX_BIN_BITS = 15;               // 2^26 slots, 2^14 and 2^15 (128 KB of LDS) beyond -- a run-time argument `bb`
+constexpr u32 MAX_BUCKETS = 8192;              // LDS histogram of the partition passes  (=> at most 2^28 slots)
 
 // Partition passes: few, fat workgroups.  Every workgroup keeps one open line per range in flight (2 048 of them at C3); with
 // 512 workgroups of 1 024 threads those lines stay in L2 until they are full far more often than with 1 024 x 256
 // (measured: -0.25 ms of 1.4 at C3; non-temporal stores, which skip that write-combining, cost +3.5 ms).
 constexpr int TPB_PART = 1024;
 constexpr u32 PART_G = 512;
-__global__ __launch_bounds__(TPB_PART) void k_part_hist(const u32* read_slot, u64 n_reads, u32 n_buckets, u32* hist) {
+__global__ __launch_bounds__(TPB_PART) void k_part_hist(const u32* read_slot, u64 n_reads, u32 n_buckets, u32 bb, u32* hist) {
     extern __shared__ u32 sh[];
     const u64 G = gridDim.x, g = blockIdx.x, per = (n_reads + G - 1) / G;
     const u64 r0 = g * per, r1 = min(r0 + per, n_reads);
@@ -1009,13 +1009,13 @@ __global__ __launch_bounds__(TPB_PART) void k_part_hist(const u32* read_slot, u6
     __syncthreads();
     for (u64 r = r0 + threadIdx.x; r < r1; r += TPB_PART) {
         const u32 s = read_slot[r];
-        if (s != PENDING) atomicAdd(&sh[s >> BIN_BITS], 1u);
+        if (s != PENDING) atomicAdd(&sh[s >> bb], 1u);
     }
     __syncthreads();
     for (u32 b = threadIdx.x; b < n_buckets; b += TPB_PART) hist[(u64)b * G + g] = sh[b];
 }
 
-__global__ __launch_bounds__(TPB_PART) void k_part_scatter(const u32* read_slot, u64 n_reads, u32 n_buckets, const u32* offs,
+__global__ __launch_bounds__(TPB_PART) void k_part_scatter(const u32* read_slot, u64 n_reads, u32 n_buckets, u32 bb, const u32* offs,
                                                       u32* pairs) {
     extern __shared__ u32 sh[];
     const u64 G = gridDim.x, g = blockIdx.x, per = (n_reads + G - 1) / G;
@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(TPB_PART) void k_part_scatter(const u32* read_slot,
             s[k] = r[k] < r1 ? read_slot[r[k]] : PENDING;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) if (s[k] != PENDING) pos[k] = atomicAdd(&sh[s[k] >> BIN_BITS], 1u);
+        for (int k = 0; k < 4; ++k) if (s[k] != PENDING) pos[k] = atomicAdd(&sh[s[k] >> bb], 1u);
 #pragma unroll
         for (int k = 0; k < 4; ++k) if (s[k] != PENDING) pairs[pos[k]] = s[k];
     }
@@ -1045,7 +1045,7 @@ __global__ __launch_bounds__(TPB_PART) void k_part_scatter(const u32* read_slot,
 // runs of consecutive addresses (STAGE / n_buckets of them on average) instead of one 8-byte store per lane and range.
 constexpr u32 STAGE = 8 * TPB_PART;            // 8 192 elements = 32 KB of LDS
 constexpr u32 STAGE_MAX_BUCKETS = 4096;        // 3 x 16 KB of counters / starts / cursors beside the stage
-__global__ __launch_bounds__(TPB_PART) void k_part_scatter_staged(const u32* read_slot, u64 n_reads, u32 n_buckets, const u32* offs,
+__global__ __launch_bounds__(TPB_PART) void k_part_scatter_staged(const u32* read_slot, u64 n_reads, u32 n_buckets, u32 bb, const u32* offs,
                                                              u32* pairs) {
     extern __shared__ u32 sh[];                   // cnt[nb] | start[nb] | gcur[nb] | stage[STAGE]
     u32 *cnt = sh, *start = sh + n_buckets, *gcur = sh + 2 * n_buckets;
@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(TPB_PART) void k_part_scatter_staged(const u32* rea
             s[k] = r < r1 ? read_slot[r] : PENDING;
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) if (s[k] != PENDING) lr[k] = atomicAdd(&cnt[s[k] >> BIN_BITS], 1u);
+        for (int k = 0; k < 8; ++k) if (s[k] != PENDING) lr[k] = atomicAdd(&cnt[s[k] >> bb], 1u);
         __syncthreads();
         // exclusive scan of cnt[] -> start[]: bpt consecutive ranges per thread, DPP scan per wave, wave totals through LDS
         u32 mine = 0;
@@ -1080,13 +1080,13 @@ __global__ __launch_bounds__(TPB_PART) void k_part_scatter_staged(const u32* rea
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-            if (s[k] != PENDING) stage[start[s[k] >> BIN_BITS] + lr[k]] = s[k];
+            if (s[k] != PENDING) stage[start[s[k] >> bb] + lr[k]] = s[k];
         __syncthreads();
         u32 n_here = 0;
         for (u32 k = 0; k < TPB_PART / 64; ++k) n_here += s_wave[k];
         for (u32 i = tid; i < n_here; i += TPB_PART) {
             const u32 e = stage[i];
-            const u32 b = e >> BIN_BITS;
+            const u32 b = e >> bb;
             pairs[gcur[b] + (i - start[b])] = e;
         }
         __syncthreads();
@@ -1132,8 +1132,9 @@ __global__ __launch_bounds__(1024) void k_build_work(const u32* starts, u32 n_bu
     }
     if (tid == 0) *n_work = min(s_carry, max_work);
 }
-__global__ __launch_bounds__(TPB_COUNT) void k_count_bins(const u32* pairs, const CountWork* work, const u32* n_work, Slot* table) {
-    __shared__ u32 cnt[N_BINS];
+__global__ __launch_bounds__(TPB_COUNT) void k_count_bins(const u32* pairs, const CountWork* work, const u32* n_work, u32 bb, Slot* table) {
+    extern __shared__ u32 cnt[];                           // 2^bb counters
+    const u32 N_BINS = 1u << bb;
     if (blockIdx.x >= *n_work) return;                     // (the grid is the list's upper bound: its length never visits the host)
     const CountWork wk = work[blockIdx.x];
     const u32 b = wk.bucket, lane = threadIdx.x & 63u;
@@ -1169,7 +1170,7 @@ __global__ __launch_bounds__(TPB_COUNT) void k_count_bins(const u32* pairs, cons
     for (u32 q = threadIdx.x; q < N_BINS; q += TPB_COUNT) {
         const u32 c = cnt[q];
         if (c) {
-            Slot* s = table + (((u64)b << BIN_BITS) | q);
+            Slot* s = table + (((u64)b << bb) | q);
             if (wk.shared) atomicAdd(&s->count, c);
             else s->count += c;                             // the only writer of its slots
         }
@@ -2113,7 +2114,7 @@ struct ecb_handle {
     bool finalized = false;
     bool counted = false;             // Slot::count / first_inv hold the reads pushed so far (k_count ran)
     u64* wave_arena = nullptr; u64 wave_arena_n = 0;   // see StreamArgs::wave_arena
-    bool scatter_attr_set = false;
+    bool scatter_attr_set = false, count_attr_set = false;
     u64 resident_blocks = 0, rounds = 32;     // k_stream's launch shape (queried once)
     bool ctr_synced = false;          // hctr is what the device holds (no kernel that counts has been queued since the last read-back)
     bool adopted = false;             // the table holds adopted entries in consecutive slots (no hashing): finalize / export only
@@ -2589,8 +2590,14 @@ int ensure_counts(ecb_handle* h) {
     if (h->counted) return ECB_OK;
     const u64 R = h->n_reads;
     if (R) {
-        const u32 nb = (u32)std::max<u64>(1, h->cap >> BIN_BITS);
-        if (nb > MAX_BUCKETS) return fail(h, ECB_ERR_LIMIT, "EC table larger than 2^26 slots is not supported yet");
+        u32 bb = BIN_BITS;
+        while (bb < MAX_BIN_BITS && (h->cap >> bb) > MAX_BUCKETS) ++bb;
+        const u32 nb = (u32)std::max<u64>(1, h->cap >> bb);
+        if (nb > MAX_BUCKETS) return fail(h, ECB_ERR_LIMIT, "EC table larger than 2^28 slots is not supported");
+        if (bb > 14 && !h->count_attr_set) {        // (more than 64 KB of dynamic LDS has to be asked for)
+            HIPCHK(h, hipFuncSetAttribute((const void*)k_count_bins, hipFuncAttributeMaxDynamicSharedMemorySize, 4 << MAX_BIN_BITS));
+            h->count_attr_set = true;
+        }
         const u32 G = (u32)std::min<u64>(PART_G, (R + 4095) / 4096);
         u32 *hist = nullptr, *offs = nullptr;
         u32* pairs = nullptr;
@@ -2598,7 +2605,7 @@ int ensure_counts(ecb_handle* h) {
         POOL(h, P_HIST, hist, (u64)nb * G); POOL(h, P_OFFS, offs, (u64)nb * G);
         POOL(h, P_PAIRS, pairs, R);
         POOL(h, P_TOTALS, d_tot, 8);
-        k_part_hist<<<G, TPB_PART, nb * 4, h->stream>>>(h->read_slot, R, nb, hist);
+        k_part_hist<<<G, TPB_PART, nb * 4, h->stream>>>(h->read_slot, R, nb, bb, hist);
         int rc = excl_scan_dev(h, hist, (u64)nb * G, offs, d_tot);
         if (rc != ECB_OK) return rc;
         if (nb <= STAGE_MAX_BUCKETS) {
@@ -2607,9 +2614,9 @@ int ensure_counts(ecb_handle* h) {
                                               3 * STAGE_MAX_BUCKETS * 4 + STAGE * 4));
                 h->scatter_attr_set = true;
             }
-            k_part_scatter_staged<<<G, TPB_PART, 3 * nb * 4 + STAGE * 4, h->stream>>>(h->read_slot, R, nb, offs, pairs);
+            k_part_scatter_staged<<<G, TPB_PART, 3 * nb * 4 + STAGE * 4, h->stream>>>(h->read_slot, R, nb, bb, offs, pairs);
         } else                                     // (tables beyond 2^25 slots: the counters would crowd the stage out of LDS)
-            k_part_scatter<<<G, TPB_PART, nb * 4, h->stream>>>(h->read_slot, R, nb, offs, pairs);
+            k_part_scatter<<<G, TPB_PART, nb * 4, h->stream>>>(h->read_slot, R, nb, bb, offs, pairs);
         // work list of k_count_bins: ranges far above the average are cut into pieces (see CountWork)
         u32* d_starts = nullptr;
         POOL(h, P_STARTS, d_starts, (u64)nb + 1);
@@ -2620,7 +2627,7 @@ int ensure_counts(ecb_handle* h) {
         POOL(h, P_WORK, d_work, (u64)max_work + 1);          // (+ 1: its length sits behind the list)
         u32* d_nwork = reinterpret_cast<u32*>(d_work + max_work);
         k_build_work<<<1, 1024, 0, h->stream>>>(d_starts, nb, piece, d_work, max_work, d_nwork);
-        k_count_bins<<<max_work, TPB_COUNT, 0, h->stream>>>(pairs, d_work, d_nwork, h->table);
+        k_count_bins<<<max_work, TPB_COUNT, 4u << bb, h->stream>>>(pairs, d_work, d_nwork, bb, h->table);
         HIPCHK(h, hipGetLastError());
     }
     h->counted = true;

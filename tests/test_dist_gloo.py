@@ -195,7 +195,7 @@ def _worker(rank, world, port, spec_args, out_path, protocol):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,paired,protocol", [(2, False, "ranges"), (2, True, "ranges"), (3, True, "ranges"), (2, True, "root")])
+@pytest.mark.parametrize("world,paired,protocol", [(2, False, "ranges"), (2, True, "ranges"), (3, True, "ranges"), (4, True, "ranges"), (2, True, "root"), (4, False, "root")])
 def test_multi_rank_merge_equals_single_process(tmp_path, world, paired, protocol):
     spec_args = dict(n_reads=3000, n_loci=300, n_haps=4, paired=paired)
     out = str(tmp_path / "merged.npz")
@@ -272,7 +272,7 @@ def _ms_worker(rank, world, port, spec_args, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_multisample_triples_over_ranks(tmp_path, world):
     """(EC, cell, file) read counts with the reads sharded over ranks == one process over the whole stream."""
     spec_args = dict(n_reads=3000, n_loci=300, n_haps=4, paired=True)

@@ -120,6 +120,25 @@ def test_device_resident_push_and_table_growth():
     _check(out, sizes, _expect(t, spec.n_loci, spec.n_haps))
 
 
+def test_table_of_2_to_the_27_slots_counts_like_a_small_one():
+    """Beyond 2^26 slots k_count's ranges hold 2^14 / 2^15 slots each (LDS counters as dynamic shared memory): same results."""
+    import torch
+    spec = synth.SynthSpec(30000, 2000, 8, paired=True)
+    t = synth.generate(spec, 0, spec.n_reads)
+    dev = torch.device("cuda:0")
+    d = {k: torch.from_numpy(t[k].view(np.int32)).to(dev) for k in ("read_id", "locus", "hapflag")}
+    for cap in (1 << 27, 1 << 28):
+        with ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=cap) as b:
+            b.push_device(d["read_id"], d["locus"], d["hapflag"])
+            sizes = b.finalize()
+            out = b.export()
+        _check(out, sizes, _expect(t, spec.n_loci, spec.n_haps))
+    with pytest.raises(ecb.EcbError):
+        with ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=1 << 29) as b:      # 32 GB of slots: allocates, counts refuse
+            b.push_device(d["read_id"], d["locus"], d["hapflag"])
+            b.finalize()
+
+
 def _hand(records, n_haps):
     """records: list of (read_id, locus, hap, flag)"""
     a = np.array(records, dtype=np.int64).reshape(-1, 4)
