@@ -73,11 +73,11 @@ typedef struct ecb_handle ecb_handle;
 typedef struct ecb_config {
     uint32_t struct_size;        /* = sizeof(ecb_config) */
     int32_t  device;             /* HIP device ordinal */
-    uint32_t n_loci;             /* T: number of main targets */
+    uint32_t n_loci;             /* T: number of main targets, 1 .. 2^26 - 3 (the stream kernel's LDS keys hold locus + 1 in 26 bits) */
     uint32_t n_haplotypes;       /* H: 1..31 */
     uint32_t flags;              /* ECB_F_* */
     uint32_t reserved;
-    uint64_t ec_capacity;        /* EC hash-table slots (rounded up to a power of two); 0 = default */
+    uint64_t ec_capacity;        /* EC hash-table slots (rounded up to a power of two; grows x4 at load 1/2, at most 2^28); 0 = default */
     uint64_t arena_capacity;     /* (locus, mask) pairs of EC key storage; 0 = default */
     uint64_t max_batch_records;  /* device staging size for ecb_push (host pointers); 0 = default */
 } ecb_config;
