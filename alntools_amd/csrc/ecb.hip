@@ -252,11 +252,14 @@ constexpr int WT = 64 * RPL;         // records per wave tile
 constexpr int WMAXR = 64;            // reads finished per wave tile (one lane each in phase (c))
 constexpr int NWAVE = TPB / 64;
 #ifndef ECB_WAVES_PER_SIMD
-#define ECB_WAVES_PER_SIMD 4
+#define ECB_WAVES_PER_SIMD 5   // 96 VGPRs, 7.4 KB of LDS per wave: five workgroups per CU (measured against four with 128 / 9.4 KB: -7.5 % on C3)
 #endif
 constexpr int CMAX = 80;                              // (locus, mask) entries an unfinished read may carry into the next tile
-constexpr int TSLOTS = 896;                           // LDS table slots per wave and pass (at most WT + CMAX = 592 entries)
-static_assert(TSLOTS >= 512 * 7 / 4 && WT + CMAX < TSLOTS && (TSLOTS * 8) % (16 * 64) == 0, "home regions / a free slot / clear loop");
+#ifndef ECB_TSLOTS
+#define ECB_TSLOTS (ECB_WAVES_PER_SIMD > 4 ? 640 : 896)
+#endif
+constexpr int TSLOTS = ECB_TSLOTS;                    // LDS table slots per wave and pass (at most WT + CMAX = 592 entries): 1.75 or 1.25 x 512
+static_assert((TSLOTS == 896 || TSLOTS == 640) && WT + CMAX < TSLOTS && (TSLOTS * 8) % (16 * 64) == 0, "home regions / a free slot / clear loop");
 constexpr u32 SBITS = 10;                             // bits of a table-slot index
 constexpr u32 SMASK = (1u << SBITS) - 1u;
 static_assert(TSLOTS <= (1 << SBITS), "ent[] packs slot | read << SBITS into 16 bits");
@@ -280,7 +283,7 @@ struct alignas(16) WaveLds {
     unsigned short npair[WMAXR];     // per read: number of (locus, mask) pairs
     u32 ws[5];                       // wave scalars that are touched once in a while (scalar registers are scarcer than the few LDS reads):
 };                                   //   [0,1] head record of the open read   [2,3] key-arena reservation: next pair   [4] ... pairs left
-static_assert(sizeof(WaveLds) * NWAVE * ECB_WAVES_PER_SIMD <= 160 * 1024, "four workgroups per CU");
+static_assert(sizeof(WaveLds) * NWAVE * ECB_WAVES_PER_SIMD <= 160 * 1024, "ECB_WAVES_PER_SIMD workgroups per CU");
 __device__ __forceinline__ u64 ws_get64(const WaveLds& L, int i) {
     const u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)L.ws[i]), hi = (u32)__builtin_amdgcn_readfirstlane((int)L.ws[i + 1]);
     return ((u64)hi << 32) | lo;
@@ -610,14 +613,20 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
         const bool again = r_lo + (u32)WMAXR < n_build;     // another pass over this tile follows
         TICK(1);
         // ---- prefetch the next tile while this one is hashed and looked up --------------------------
-        TileRegs N;
+        // Into the SAME registers: phase (a) has turned the tile into keys and bits, nothing reads R again.  The lane offset of
+        // the loads is made to depend on phase (a)'s results, so that the scheduler cannot start them while R is still being read
+        // (it did, and a second set of 24 registers plus 24 moves per tile was the price).
         u32 parked_next = 0;
         if (more || again) {
+            u32 lp = ln;
+#pragma unroll
+            for (int k = 0; k < RPL; ++k) asm volatile("" : "+v"(lp) : "v"(r_key[k]), "v"(r_bit[k]));
+            asm volatile("" : "+v"(lp) : "v"(m_act), "v"(m_head), "v"(bad), "v"(my_valid));
             const u64 nt = (u64)(again ? tix : tix + 1u) << 9;
-            load_tile(A, nt, min(nt + (u64)WT, A.n), ln, N);
+            load_tile(A, nt, min(nt + (u64)WT, A.n), lp, R);
             parked_next = __hip_atomic_load(&A.ctr->full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        bool taken = false;                        // N has been taken over into R
+        bool taken = false;                        // the prefetched tile has been waited for
         u32 new_carry = 0;
         bool giant = false;
         u32 last_pos = 0xFFFFFFFFu;                // tile-relative head of the tile's last read, if it started here (it may stay open)
@@ -637,7 +646,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
             }
             // The table's geometry (see WaveLds): two wave-uniform numbers
             const u32 lg = nb > 1u ? 32u - (u32)__builtin_clz(nb - 1u) : 0u;       // ceil(log2 nb)
-            const u32 pm = (512u >> lg) - 1u, gp = (512u >> lg) + (256u >> lg) + (128u >> lg);
+            const u32 pm = (512u >> lg) - 1u, gp = (512u >> lg) + (TSLOTS == 896 ? (256u >> lg) : 0u) + (128u >> lg);
             if (r_lo + nb == n_build) {                                 // head of the tile's last read (kept if it stays open): the tile's last head
                 const u64 h1 = __ballot((m_head >> 4) != 0u), h0 = __ballot((m_head & 15u) != 0u);
                 if (h1 | h0) {
@@ -797,7 +806,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                     }
                     if (!same) my_new += 1;                             // (counted as "mismatches" in verify mode)
                 }
-                R = N; parked = parked_next; taken = true;
+                parked = parked_next; taken = true;
             } else {
                 // Lookup; founders publish their keys; THEN lanes whose slot was claimed but not (visibly) complete settle it --
                 // the founder such a ln waits for may be a ln of this very wave.  One round in all but a handful of tiles.
@@ -812,7 +821,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                         // vmcnt counts in order: wherever the compiler first touches these registers it waits for everything issued before
                         // that point, and at the end of the tile (where the moves sink to if left alone) or at the top of the next one
                         // (the parked flag) that meant sitting out the round trips of the founders' stores -- ~3000 clocks per tile on C3.
-                        R = N; parked = parked_next; taken = true;
+                        parked = parked_next; taken = true;
 #pragma unroll
                         for (int k = 0; k < RPL; ++k) {
                             asm volatile("" : "+v"(R.rr[k])); asm volatile("" : "+v"(R.ll[k])); asm volatile("" : "+v"(R.hh[k]));
@@ -890,7 +899,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
             TICK(6);
         }
         if (!taken) {                                                // a tile without a read of mine (leading records of the slice)
-            R = N; parked = parked_next;
+            parked = parked_next;
 #pragma unroll
             for (int k = 0; k < RPL; ++k) {
                 asm volatile("" : "+v"(R.rr[k])); asm volatile("" : "+v"(R.ll[k])); asm volatile("" : "+v"(R.hh[k]));
