@@ -45,8 +45,21 @@ def build_sanitized(out=None, verbose=False):
     return out
 
 
+def build_ablate(verbose=False):
+    """Profiling build ``libecb_ablate.so`` (-DECB_ABLATE_RT): phases of k_stream can be switched off with env ECB_ABLATE;
+    used through ``ECB_LIB=libecb_ablate.so`` by tools/pmc_ladder.sh, tools_ablate.sh and tools_final.sh -- never by the product."""
+    out = os.path.join(HERE, "libecb_ablate.so")
+    cmd = [HIPCC] + FLAGS + ["-DECB_ABLATE_RT", "-o", out, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
-    if "--asan" in sys.argv:
+    if "--ablate" in sys.argv:
+        print(build_ablate(verbose=True))
+    elif "--asan" in sys.argv:
         print(build_sanitized(verbose=True))
     else:
         print(build(force="--force" in sys.argv, verbose=True))

@@ -312,6 +312,13 @@ struct StreamCold {
     u64 chunk;                       // records per slice (a multiple of WT)
     u32 prev_rid;                    // read_id of the record before this batch (0xFFFFFFFF at stream start)
 };
+// Phases of k_stream can be switched off at run time in a profiling build (libecb_ablate.so: tools/pmc_ladder.sh, tools_ablate.sh);
+// the product build has the tests compiled out -- they cost a scalar register and a handful of branches per tile.
+#ifdef ECB_ABLATE_RT
+#define ABL(A, bits) ((A).ablate & (bits))
+#else
+#define ABL(A, bits) 0u
+#endif
 struct StreamArgs {
     const u32* rid; const u32* loc; const u32* hf;
     u64 n;
@@ -320,7 +327,7 @@ struct StreamArgs {
     u32* read_slot;                  // slot of every read (indexed by read_id)
     u64 reads_hi;                    // read_slot holds [0, reads_hi): a read index beyond it is a broken run counter
     const StreamCold* cold;
-    u32 ablate;                      // profiling only (env ECB_ABLATE): 1 = stop after (a), 2 = after (b), 4 = no EC table, 8 / 16 / 32 see table_lookup
+    u32 ablate;                      // profiling builds only (-DECB_ABLATE_RT, env ECB_ABLATE): 1 = stop after (a), 2 = after (b), 4 = no EC table, 8 / 16 / 32 see table_lookup
 };
 
 __device__ __forceinline__ void wave_sync() {   // orders this wave's LDS traffic (lanes run in lockstep)
@@ -470,7 +477,8 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
     const u64 pw = (u64)blockIdx.x * NWAVE + w;   // this wave
     const StreamCold* const C = A.cold;
     static_assert(WT == 512, "tile index = record index >> 9");
-    u32 s_all = 0, my_valid = 0, my_new = 0;      // wave total / per lane; a wave sees far fewer than 2^32 records
+    u32 my_valid = 0, my_new = 0;                 // per lane; a wave sees far fewer than 2^32 records  (records OFFERED, bam_utils.py:261,
+                                                  //  are simply the batch's length: the host adds it)
     u32 bad = 0;
     // this wave's current reservation in the key arena: what the last launch left of it is used first (a stream pushed in
     // many small batches would otherwise leave the tail of a 512-pair chunk behind per wave and launch)
@@ -597,7 +605,6 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                 m_act |= (ok4 & mine4) << (4 * g); m_head |= head4 << (4 * g);
             }
         }
-        if (count_tile) s_all += (u32)te_rel;                      // records offered (bam_utils.py:261)
         TICK(0);
         if (__ballot(bad != 0u)) break;            // never index LDS with a broken run counter
         const u32 nheads = wave_sum(__popc(m_head));
@@ -626,7 +633,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
             load_tile(A, nt, min(nt + (u64)WT, A.n), lp, R);
             parked_next = __hip_atomic_load(&A.ctr->full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        bool taken = false;                        // the prefetched tile has been waited for
+        bool taken = false;                        // the prefetched tile has been waited for (on this path)
         u32 new_carry = 0;
         bool giant = false;
         u32 last_pos = 0xFFFFFFFFu;                // tile-relative head of the tile's last read, if it started here (it may stay open)
@@ -665,7 +672,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
             u32 n_ent = 0;
             const u32 rl_last = nb - 1u;                             // the pass's last read: if it stays open, its entries are kept
             const bool keep = carry_out && r_lo + nb == n_build;
-            if (!(A.ablate & 1u)) {
+            if (!ABL(A, 1u)) {
                 // What the open read brought along goes in WITH the records, as one more compare-and-swap per lane in the same
                 // round (a chain of LDS round trips of its own cost a fifth of the tile): entry c of the carry list is lane c's
                 // ninth "record" -- its haplotype "bit" is the whole mask so far.  (More than 64 of them: a second such round.)
@@ -779,7 +786,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
             u64 j = 0;
             u32 st = ST_NONE, probes = 0, np = 0, fseen = 0;       // fseen: ~(first read) as the slot's line showed it (0 = nothing yet)
             u64 lo = 0;
-            const bool on = ln < nproc && !(A.ablate & 3u);
+            const bool on = ln < nproc && !ABL(A, 3u);
             const u32 rd = base + r_lo + ln;
             LdsSetCmp cmp;
             cmp.L = &L; cmp.cold = C; cmp.home = ln * gp; cmp.pm = pm; cmp.tag = ln << KBITS; cmp.np = 0;
@@ -812,8 +819,8 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                 // the founder such a ln waits for may be a ln of this very wave.  One round in all but a handful of tiles.
                 for (u32 round = 0;; ++round) {
                     if (st == ST_LOOK) {
-                        if (A.ablate & 4u) st = ST_HIT;
-                        else st = table_lookup(A.table, A.cap_mask, lo, j, probes, cmp, A.ablate, &fseen);
+                        if (ABL(A, 4u)) st = ST_HIT;
+                        else st = table_lookup(A.table, A.cap_mask, lo, j, probes, cmp, ABL(A, 24u), &fseen);
                     }
                     if (round == 0u) {
                         TICK(5);
@@ -863,7 +870,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                             const u32 e = e0 + ln;
                             const u32 en = e < n_ent ? L.ent[e] : 0u, qq = en & SMASK, rl = en >> SBITS;
                             const u32 o = __shfl(off, rl), jj = __shfl(j32, rl);            // (all lanes: the loop bound is uniform)
-                            if (e < n_ent && (cmask >> rl & 1ull) && !(A.ablate & 32u)) {    // (32: profiling, no key stores)
+                            if (e < n_ent && (cmask >> rl & 1ull) && !ABL(A, 32u)) {    // (32: profiling, no key stores)
                                 const u32 was = atomicSub(reinterpret_cast<u32*>(&L.npair[rl & ~1u]), (rl & 1u) ? 0x10000u : 1u);
                                 const u32 pos = ((rl & 1u) ? was >> 16 : was & 0xFFFFu) - 1u;   // a place of its own among the read's pairs
                                 uint2* dst = pos < INL ? &A.table[jj].pair[pos] : arena + ((u64)o + (pos - INL));
@@ -935,7 +942,7 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
     if (stop) break;
   }
     // records offered / valid: one atomic pair per wave
-    const u32 wa = s_all, wv = wave_sum(my_valid);
+    const u32 wa = 0u, wv = wave_sum(my_valid);
     // per-wave totals go to their own words: thousands of waves adding to three shared counters serialise (~50 ns each)
     const u32 wn = VERIFY ? wave_sum(my_new) : my_new;
 #ifdef ECB_TIMING
@@ -951,7 +958,7 @@ __global__ void k_init_resume(u64* resume, u64 slices, u64 chunk) {
     if (b < slices) { resume[2 * b] = b * chunk; resume[2 * b + 1] = b * chunk; }
 }
 
-__global__ __launch_bounds__(1024) void k_sum_counts(const u32* wave_counts, u64 waves, Counters* ctr, u32 verify) {
+__global__ __launch_bounds__(1024) void k_sum_counts(const u32* wave_counts, u64 waves, Counters* ctr, u32 verify, u64 offered) {
     __shared__ u64 s[3][16];
     u64 a = 0, v = 0, e = 0;
     for (u64 i = threadIdx.x; i < waves; i += 1024) { a += wave_counts[3 * i]; v += wave_counts[3 * i + 1]; e += wave_counts[3 * i + 2]; }
@@ -963,7 +970,7 @@ __global__ __launch_bounds__(1024) void k_sum_counts(const u32* wave_counts, u64
         a = v = e = 0;
         for (int k = 0; k < 16; ++k) { a += s[0][k]; v += s[1][k]; e += s[2][k]; }
         if (verify) ctr->n_mismatch += e;                  // the exactness pass counts differing reads, and recounts nothing
-        else { ctr->all += a; ctr->valid += v; ctr->n_ecs += e; }
+        else { ctr->all += a + offered; ctr->valid += v; ctr->n_ecs += e; }
     }
 }
 
@@ -2374,7 +2381,7 @@ int verify_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d
     HIPCHK(h, hipMemcpyAsync(h->d_cold, h->pin_cold, sizeof(StreamCold), hipMemcpyHostToDevice, h->stream));
     StreamArgs a{d_rid, d_loc, d_hf, n, h->table, h->cap - 1, h->ctr, h->read_slot, h->reads_hi, h->d_cold, 0u};
     k_stream<true><<<(unsigned)P.blocks, TPB, 0, h->stream>>>(a);
-    k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, P.pwaves, h->ctr, 1u);
+    k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, P.pwaves, h->ctr, 1u, 0ull);
     HIPCHK(h, hipGetLastError());
     rc = sync_counters(h);
     if (rc != ECB_OK) return rc;
@@ -2436,6 +2443,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     StreamArgs a{d_rid, d_loc, d_hf, n, h->table, h->cap - 1, h->ctr, h->read_slot, h->reads_hi, h->d_cold,
                  getenv("ECB_ABLATE") ? (u32)atoi(getenv("ECB_ABLATE")) : 0u};
     h->ctr_synced = false;
+    u64 offered = n;                                    // records offered to the filter (bam_utils.py:261): all of the batch
     for (;;) {
         HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));   // per launch
         HIPCHK(h, hipMemsetAsync(&h->ctr->full, 0, sizeof(u32), h->stream));
@@ -2445,7 +2453,8 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
         if (h->prof) hipEventRecord(h->ev0, h->stream);
         k_stream<false><<<(unsigned)blocks, TPB, 0, h->stream>>>(a);
         if (h->prof) hipEventRecord(h->ev1, h->stream);
-        k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, pwaves, h->ctr, 0u);
+        k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, pwaves, h->ctr, 0u, offered);
+        offered = 0;                                    // (a relaunch after a park continues the same batch)
         HIPCHK(h, hipGetLastError());
         rc = sync_counters(h);
         if (h->prof) {

@@ -10,7 +10,7 @@ bash $R/tools/tools_pmc.sh $W gpurun_out/final_$W/pmc > $O/${TAG}_pmc_k_stream_$
 # loads, which gfx950 reports at half their bytes); the difference to the full kernel is the table's 64-byte lines (reported 1:1,
 # tools/fetch_calib.sh).  traffic = 2 x stream part + table part + WRITE_SIZE.
 cd /tmp && export TMPDIR=/tmp ECB_NO_VERIFY=1
-ECB_ABLATE=4 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "k_stream<false>" --output-format csv -d $O/abl -- python $R/bench.py --workload $W --steps 1 --warmup 0 --no-cpu-baseline > $O/abl.log 2>&1
+ECB_LIB=libecb_ablate.so ECB_ABLATE=4 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "k_stream<false>" --output-format csv -d $O/abl -- python $R/bench.py --workload $W --steps 1 --warmup 0 --no-cpu-baseline > $O/abl.log 2>&1
 cd $R
 python - "$(find $O/abl -name '*counter_collection.csv' | head -1)" $O/${TAG}_pmc_k_stream_$W.txt $W $TAG > $O/traffic_${W}_n1.json <<'PY'
 import csv, json, re, sys
