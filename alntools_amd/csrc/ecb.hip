@@ -561,12 +561,14 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                 const u32 prev0 = ln == 0 ? wrap : up;
                 u32 ok4 = 0, head4 = 0, hap_or = 0, mine4 = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const u32 f = R.hh[4 * g + j], nf = ~f;
+                for (int j = 3; j >= 0; --j) {
                     // record filter (bam_utils.py:264-270): not unmapped, and if paired: read1, proper, mate on the same
-                    // reference, next_pos >= 0  <=>  ((f ^ 2) & 0x3082) == 0
-                    const u32 pair_ok = ((((f ^ 0x2u) & 0x3082u) - 1u) >> 31);
-                    ok4 |= ((nf >> 2) & (nf | pair_ok) & 1u) << j;
+                    // reference, next_pos >= 0  <=>  ((f ^ 2) & 0x3082) == 0.  Worked out in the sign bit: x - 1 is negative only
+                    // for x = 0, a shift puts a flag bit there, and one funnel shift moves the verdict into the group's mask.
+                    const u32 f = R.hh[4 * g + j];
+                    const u32 pair_ok = ((f & 0x3082u) ^ 0x2u) - 1u;                              // bit 31
+                    const u32 ok31 = ~(f << 29) & (~(f << 31) | pair_ok);                        // bit 31: !unmapped && (!paired || pair_ok)
+                    ok4 = __builtin_amdgcn_alignbit(ok4, ok31, 31);                              // ok4 = ok4 << 1 | verdict
                 }
                 // The rest is per record position, and only for positions at which SOME lane holds a valid record: in a paired-end
                 // stream every second record is a mate the filter drops -- wave-uniform branches, two positions each.
