@@ -311,6 +311,8 @@ struct StreamCold {
     u64* timing;                     // profiling only (-DECB_TIMING): clocks per phase, summed over waves
     u64 chunk;                       // records per slice (a multiple of WT)
     u32 prev_rid;                    // read_id of the record before this batch (0xFFFFFFFF at stream start)
+    // ECB_F_RANGES (k_stream<false, true>): reference_start of every record and the per-(locus, haplotype) extremes
+    const int* pos; int* rng_min; int* rng_max; u32 n_loci, n_haps;
 };
 // Phases of k_stream can be switched off at run time in a profiling build (libecb_ablate.so: tools/pmc_ladder.sh, tools_ablate.sh);
 // the product build has the tests compiled out -- they cost a scalar register and a handful of branches per tile.
@@ -459,6 +461,28 @@ __device__ __forceinline__ void load_tile(const StreamArgs& A, u64 tb, u64 te, u
     }
 }
 
+// ECB_F_RANGES: the fourth stream of a tile, same shape as load_tile's three
+__device__ __forceinline__ void load_pos(const int* pos, u64 tb, u64 te, u32 lane, int* P) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    tb = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(tb >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)tb);
+    if (tb + (u64)WT <= te) {
+        const char* pp = reinterpret_cast<const char*>(pos + tb);
+        const u32 off = lane * 16u;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const i32x4 v = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(pp + (off + (u32)g * 1024u)));
+            P[4 * g] = v.x; P[4 * g + 1] = v.y; P[4 * g + 2] = v.z; P[4 * g + 3] = v.w;
+        }
+        return;
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const u64 i0 = tb + (u64)g * 256 + 4u * lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) P[4 * g + j] = i0 + j < te ? pos[i0 + j] : 0;
+    }
+}
+
 // VERIFY = false: the hot kernel.  VERIFY = true: the exactness pass (same tiling, compares instead of inserting).
 //
 // A wave walks its slice in tiles of WT records that start at multiples of WT: every record is loaded exactly once (plus
@@ -466,8 +490,9 @@ __device__ __forceinline__ void load_tile(const StreamArgs& A, u64 tb, u64 te, u
 // again: its {locus -> mask} entries so far (a few) are carried into the next tile, where they are put into that read's
 // table before the tile's own records.  A read that would carry more than CMAX entries goes to k_slow.  A tile with more
 // than WMAXR reads (short reads) is worked off in passes of WMAXR reads; every further pass loads the tile again.
-template <bool VERIFY>
-__global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A) {
+// (RANGES: the reference_start ranges of ECB_F_RANGES updated in the same pass -- more registers, four waves per SIMD)
+template <bool VERIFY, bool RANGES = false>
+__global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A) {
     __shared__ WaveLds wl[NWAVE];
     const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     WaveLds& L = wl[w];
@@ -542,6 +567,8 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
         // phase (b) needs of it; which records phase (b) takes at all (valid, of a read of this pass) is settled here too:
         // the reads of a tile of mine are numbered base ..., so "one of the pass's WMAXR reads" is one unsigned comparison.
         u32 r_key[RPL], r_bit[RPL];
+        int r_pos[RANGES ? RPL : 1];                // ECB_F_RANGES: reference_start of the tile's records (this tile only: not prefetched)
+        if (RANGES && r_lo == 0u) load_pos(C->pos, (u64)tix << 9, min(((u64)tix << 9) + (u64)WT, A.n), ln, r_pos);
         u32 m_act = 0, m_head = 0;                 // bit k: valid record of a read of this pass / head
         const u32 base_lo = base + r_lo;
         const u32 lim = own ? (u32)WMAXR : ((open && r_lo == 0u) ? 1u : 0u);   // (past my slice only the open read is mine)
@@ -589,6 +616,31 @@ __global__ __launch_bounds__(TPB, ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A
                             hap_or |= ((t & ~KMASK) | f) & (u32)((int)(ok4 << (31 - j)) >> 31);
                             head4 |= (step & 1u) << j;
                             mine4 |= (relx < lim ? 1u : 0u) << j;
+                        }
+                        if constexpr (RANGES) {
+                            // reference_start ranges per target (bam_utils.py:282-286), in the pass that has the record in registers anyway:
+                            // the 2 x n_loci x n_haps bounds stay in L2, and a record only issues an atomic when it moves a bound (almost
+                            // none do after the first few thousand).  Re-running a tile (park, further passes) changes nothing: min / max.
+                            if (r_lo == 0u) {
+                                const u32 nl = C->n_loci, nh = C->n_haps;
+                                int* const rmin = C->rng_min; int* const rmax = C->rng_max;
+                                u32 sl[2]; int mn[2], mx[2]; bool go[2];
+#pragma unroll
+                                for (int j = par; j < 4; j += 2) {
+                                    const int k = 4 * g + j;
+                                    const u32 lc = R.ll[k], hap = (R.hh[k] >> ECB_HAP_SHIFT) & 0xFFu;
+                                    go[j >> 1] = ((ok4 >> j) & 1u) && lc < nl && hap < nh;       // (out of range: reported at emit)
+                                    sl[j >> 1] = lc * nh + hap;
+                                    mn[j >> 1] = 0; mx[j >> 1] = 0;
+                                    if (go[j >> 1]) { mn[j >> 1] = rmin[sl[j >> 1]]; mx[j >> 1] = rmax[sl[j >> 1]]; }
+                                }
+#pragma unroll
+                                for (int j = par; j < 4; j += 2) {
+                                    const int ps = r_pos[RANGES ? 4 * g + j : 0];
+                                    if (go[j >> 1] && ps < mn[j >> 1]) atomicMin(rmin + sl[j >> 1], ps);
+                                    if (go[j >> 1] && ps > mx[j >> 1]) atomicMax(rmax + sl[j >> 1], ps);
+                                }
+                            }
                         }
                     } else {
 #pragma unroll
@@ -974,35 +1026,6 @@ __global__ __launch_bounds__(1024) void k_sum_counts(const u32* wave_counts, u64
         if (verify) ctr->n_mismatch += e;                  // the exactness pass counts differing reads, and recounts nothing
         else { ctr->all += a + offered; ctr->valid += v; ctr->n_ecs += e; }
     }
-}
-
-// reference_start ranges per target (bam_utils.py:282-286): a separate pass, only with ECB_F_RANGES
-// Four records per lane and load (16 B/lane, like k_stream); the 2 x n_loci x n_haps bounds stay in L2, and a record only
-// issues an atomic when it moves a bound, which almost none do after the first few thousand.
-__device__ __forceinline__ void range_one(u32 lc, u32 f, int ps, u32 n_loci, u32 n_haps, int* rng_min, int* rng_max) {
-    if (!rec_valid(f)) return;
-    const u32 hap = (f >> ECB_HAP_SHIFT) & 0xFFu;
-    if (lc >= n_loci || hap >= n_haps) return;                // k_stream reports these
-    const u32 sl = lc * n_haps + hap;
-    if (ps < rng_min[sl]) atomicMin(rng_min + sl, ps);
-    if (ps > rng_max[sl]) atomicMax(rng_max + sl, ps);
-}
-__global__ __launch_bounds__(TPB) void k_ranges(const u32* loc, const u32* hf, const int* pos, u64 n, u32 n_loci, u32 n_haps,
-                                                int* rng_min, int* rng_max) {
-    const u64 n4 = n / 4, step = (u64)gridDim.x * TPB;
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4* l4 = (const u32x4*)loc; const u32x4* f4 = (const u32x4*)hf; const u32x4* p4 = (const u32x4*)pos;
-    for (u64 i = (u64)blockIdx.x * TPB + threadIdx.x; i < n4; i += step) {
-        const u32x4 l = __builtin_nontemporal_load(l4 + i), f = __builtin_nontemporal_load(f4 + i);
-        const u32x4 q = __builtin_nontemporal_load(p4 + i);
-        const int4 p = make_int4((int)q.x, (int)q.y, (int)q.z, (int)q.w);
-        range_one(l.x, f.x, p.x, n_loci, n_haps, rng_min, rng_max);
-        range_one(l.y, f.y, p.y, n_loci, n_haps, rng_min, rng_max);
-        range_one(l.z, f.z, p.z, n_loci, n_haps, rng_min, rng_max);
-        range_one(l.w, f.w, p.w, n_loci, n_haps, rng_min, rng_max);
-    }
-    const u64 t = n4 * 4 + (u64)blockIdx.x * TPB + threadIdx.x;
-    if (t < n) range_one(loc[t], hf[t], pos[t], n_loci, n_haps, rng_min, rng_max);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2133,7 +2156,7 @@ struct ecb_handle {
     bool counted = false;             // Slot::count / first_inv hold the reads pushed so far (k_count ran)
     u64* wave_arena = nullptr; u64 wave_arena_n = 0;   // see StreamArgs::wave_arena
     bool scatter_attr_set = false, count_attr_set = false;
-    u64 resident_blocks = 0, rounds = 32;     // k_stream's launch shape (queried once)
+    u64 resident_blocks = 0, resident_blocks_rg = 0, rounds = 32;     // k_stream's launch shape (queried once)
     bool ctr_synced = false;          // hctr is what the device holds (no kernel that counts has been queued since the last read-back)
     bool adopted = false;             // the table holds adopted entries in consecutive slots (no hashing): finalize / export only
 
@@ -2333,15 +2356,18 @@ int excl_scan(ecb_handle* h, const u32* in, u64 n, u32* out, u64* total);
 // Launch shape of k_stream over n records: the stream is cut into ECB_ROUNDS x as many slices as waves are resident at
 // once; the launch holds the resident waves only, which claim slice after slice.
 struct StreamPlan { u64 slices, chunk, blocks, pwaves; };
-int plan_stream(ecb_handle* h, u64 n, StreamPlan* P) {
+int plan_stream(ecb_handle* h, u64 n, StreamPlan* P, bool ranges = false) {
     if (!h->resident_blocks) {                         // (asked once per handle: two runtime queries per batch add up on a streamed BAM)
         int cus = 256, bpc = 4;
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_stream<false>, TPB, 0);
         h->resident_blocks = (u64)std::max(cus, 1) * std::max(bpc, 1);
+        int bpr = 4;                                   // (the variant with the range update has fewer waves resident)
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpr, k_stream<false, true>, TPB, 0);
+        h->resident_blocks_rg = (u64)std::max(cus, 1) * std::max(bpr, 1);
         h->rounds = getenv("ECB_ROUNDS") ? std::max(1, atoi(getenv("ECB_ROUNDS"))) : 32;
     }
-    const u64 rounds = h->rounds, resident_blocks = h->resident_blocks;
+    const u64 rounds = h->rounds, resident_blocks = ranges ? h->resident_blocks_rg : h->resident_blocks;
     u64 waves = resident_blocks * NWAVE * rounds;
     waves = std::min<u64>(waves, (n + 2 * WT - 1) / (2 * WT));
     waves = std::max<u64>(waves, 1);
@@ -2379,7 +2405,8 @@ int verify_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d
     HIPCHK(h, hipMemsetAsync(&h->ctr->full, 0, sizeof(u32), h->stream));
     HIPCHK(h, hipMemsetAsync(&h->ctr->next_slice, 0, sizeof(u64), h->stream));
     HIPCHK(h, hipMemsetAsync(&h->ctr->n_mismatch, 0, sizeof(u64), h->stream));
-    *h->pin_cold = StreamCold{h->arena, h->arena_cap, h->queue, h->queue_cap, d_resume, d_wcounts, nullptr, nullptr, P.chunk, prev_rid};
+    *h->pin_cold = StreamCold{h->arena, h->arena_cap, h->queue, h->queue_cap, d_resume, d_wcounts, nullptr, nullptr, P.chunk, prev_rid,
+                              nullptr, nullptr, nullptr, 0u, 0u};
     HIPCHK(h, hipMemcpyAsync(h->d_cold, h->pin_cold, sizeof(StreamCold), hipMemcpyHostToDevice, h->stream));
     StreamArgs a{d_rid, d_loc, d_hf, n, h->table, h->cap - 1, h->ctr, h->read_slot, h->reads_hi, h->d_cold, 0u};
     k_stream<true><<<(unsigned)P.blocks, TPB, 0, h->stream>>>(a);
@@ -2413,15 +2440,12 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     // keep the table at most half full before a batch (it grows again, via k_slow, if a batch overfills it)
     while (h->n_ecs() * 2 > h->cap) { rc = grow_table(h, h->cap * 4); if (rc != ECB_OK) return rc; }
     StreamPlan P;
-    rc = plan_stream(h, n, &P);
+    rc = plan_stream(h, n, &P, h->rng_min != nullptr);
     if (rc != ECB_OK) return rc;
     const u64 waves = P.slices, chunk = P.chunk, blocks = P.blocks, pwaves = P.pwaves;
     u64* d_resume = nullptr;
     POOL(h, P_RESUME, d_resume, 2 * waves);
     k_init_resume<<<nblk(waves, TPB), TPB, 0, h->stream>>>(d_resume, waves, chunk);
-    if (h->rng_min)
-        k_ranges<<<(unsigned)std::min<u64>(8192, (n / 4 + TPB) / TPB), TPB, 0, h->stream>>>(
-            d_loc, d_hf, d_pos, n, h->cfg.n_loci, h->cfg.n_haplotypes, h->rng_min, h->rng_max);
     u32* d_wcounts = nullptr;
     POOL(h, P_WCOUNTS, d_wcounts, 3 * pwaves);
     if (h->wave_arena_n < pwaves) {                 // (only ever grows to the resident wave count; zero = nothing reserved)
@@ -2435,7 +2459,8 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
         }
         h->wave_arena = wa; h->wave_arena_n = pwaves;
     }
-    StreamCold cold{h->arena, h->arena_cap, h->queue, h->queue_cap, d_resume, d_wcounts, h->wave_arena, nullptr, chunk, h->prev_rid};
+    StreamCold cold{h->arena, h->arena_cap, h->queue, h->queue_cap, d_resume, d_wcounts, h->wave_arena, nullptr, chunk, h->prev_rid,
+                    d_pos, h->rng_min, h->rng_max, h->cfg.n_loci, h->cfg.n_haplotypes};
 #ifdef ECB_TIMING
     HIPCHK(h, hipMalloc(&cold.timing, 8 * sizeof(u64)));
     HIPCHK(h, hipMemset(cold.timing, 0, 8 * sizeof(u64)));
@@ -2453,7 +2478,8 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
         a.table = h->table; a.cap_mask = h->cap - 1;
         HIPCHK(h, hipMemsetAsync(d_wcounts, 0, 3 * pwaves * sizeof(u32), h->stream));
         if (h->prof) hipEventRecord(h->ev0, h->stream);
-        k_stream<false><<<(unsigned)blocks, TPB, 0, h->stream>>>(a);
+        if (h->rng_min) k_stream<false, true><<<(unsigned)blocks, TPB, 0, h->stream>>>(a);     // ... with the range update fused in
+        else k_stream<false><<<(unsigned)blocks, TPB, 0, h->stream>>>(a);
         if (h->prof) hipEventRecord(h->ev1, h->stream);
         k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, pwaves, h->ctr, 0u, offered);
         offered = 0;                                    // (a relaunch after a park continues the same batch)

@@ -354,7 +354,7 @@ def main():
                        "generate_s": round(t_gen, 2), "exactness_pass": exact},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_stream<false>", "kernel_ms_per_launch": k_ms_per_launch,
+                         "kernel": "k_stream<false, false>", "kernel_ms_per_launch": k_ms_per_launch,
                          "launches_per_step": launches_per_step,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "step_achieved": step_achieved, "step_frac": step_achieved / HBM_PEAK_GBS,

@@ -5,7 +5,7 @@ W=${1:-c3}; R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp ECB_NO_VERIFY=1
 for a in ${2:-1 2 4 8 0}; do
   O=/tmp/pmcl_$a; rm -rf $O; mkdir -p $O
-  ECB_LIB=libecb_ablate.so ECB_ABLATE=$a timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-include-regex "k_stream<false>" --output-format csv -d $O -- python $R/bench.py --workload $W --steps 1 --warmup 0 --no-cpu-baseline > $O/log 2>&1
+  ECB_LIB=libecb_ablate.so ECB_ABLATE=$a timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-include-regex "k_stream<false, false>" --output-format csv -d $O -- python $R/bench.py --workload $W --steps 1 --warmup 0 --no-cpu-baseline > $O/log 2>&1
   f=$(find $O -name "*counter_collection.csv" | head -1)
   python - "$f" $a <<'PY'
 import csv, sys, collections

@@ -10,7 +10,7 @@ bash $R/tools/tools_pmc.sh $W gpurun_out/final_$W/pmc > $O/${TAG}_pmc_k_stream_$
 # loads, which gfx950 reports at half their bytes); the difference to the full kernel is the table's 64-byte lines (reported 1:1,
 # tools/fetch_calib.sh).  traffic = 2 x stream part + table part + WRITE_SIZE.
 cd /tmp && export TMPDIR=/tmp ECB_NO_VERIFY=1
-ECB_LIB=libecb_ablate.so ECB_ABLATE=4 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "k_stream<false>" --output-format csv -d $O/abl -- python $R/bench.py --workload $W --steps 1 --warmup 0 --no-cpu-baseline > $O/abl.log 2>&1
+ECB_LIB=libecb_ablate.so ECB_ABLATE=4 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "k_stream<false, false>" --output-format csv -d $O/abl -- python $R/bench.py --workload $W --steps 1 --warmup 0 --no-cpu-baseline > $O/abl.log 2>&1
 cd $R
 python - "$(find $O/abl -name '*counter_collection.csv' | head -1)" $O/${TAG}_pmc_k_stream_$W.txt $W $TAG > $O/traffic_${W}_n1.json <<'PY'
 import csv, json, re, sys
@@ -19,7 +19,7 @@ stream_kib = sum(v) / max(len(v), 1)
 t = open(sys.argv[2]).read()
 fetch_kib = float(re.search(r'FETCH_SIZE\s+(\d+)', t).group(1)); write_kib = float(re.search(r'WRITE_SIZE\s+(\d+)', t).group(1))
 table_kib = max(fetch_kib - stream_kib, 0.0)
-print(json.dumps({"kernel": "k_stream<false>", "workload": sys.argv[3], "n_gpus": 1, "round": sys.argv[4],
+print(json.dumps({"kernel": "k_stream<false, false>", "workload": sys.argv[3], "n_gpus": 1, "round": sys.argv[4],
                   "FETCH_SIZE_KiB": fetch_kib, "FETCH_SIZE_KiB_without_ec_table": stream_kib, "WRITE_SIZE_KiB": write_kib,
                   "hbm_bytes_per_launch": int((2 * stream_kib + table_kib + write_kib) * 1024),
                   "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/tools_final.sh); the record streams' share of FETCH_SIZE "

@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT; mkdir -p $R/$OUT
 cd /tmp && export TMPDIR=/tmp ECB_NO_VERIFY=1
 run() { # name counters...
   name=$1; shift
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "k_stream<false>" --output-format csv -d $R/$OUT/$name -- python $R/bench.py --workload $W --steps 1 --warmup 0 --no-cpu-baseline > $R/$OUT/$name.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "k_stream<false, false>" --output-format csv -d $R/$OUT/$name -- python $R/bench.py --workload $W --steps 1 --warmup 0 --no-cpu-baseline > $R/$OUT/$name.log 2>&1
   f=$(find $R/$OUT/$name -name "*counter_collection.csv" | head -1)
   python - "$f" <<'PY'
 import csv, sys, collections

@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT; mkdir -p $R/$OUT
 cd /tmp && export TMPDIR=/tmp
 run() { # name counters...
   name=$1; shift
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "k_stream<false>" --output-format csv -d $R/$OUT/$name -- python $R/tools/exp_hits2.py > $R/$OUT/$name.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "k_stream<false, false>" --output-format csv -d $R/$OUT/$name -- python $R/tools/exp_hits2.py > $R/$OUT/$name.log 2>&1
   f=$(find $R/$OUT/$name -name "*counter_collection.csv" | head -1)
   python - "$f" <<'PY'
 import csv, sys, collections

@@ -5,7 +5,7 @@
 W=${1:-c3}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_abl; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp ECB_NO_VERIFY=1
 for abl in 0 4; do for c in FETCH_SIZE WRITE_SIZE; do
-  ECB_LIB=libecb_ablate.so ECB_ABLATE=$abl timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "k_stream<false>" --output-format csv -d $O/a${abl}_$c -- python $R/bench.py --workload $W --steps 1 --warmup 0 --no-cpu-baseline > $O/a${abl}_$c.log 2>&1
+  ECB_LIB=libecb_ablate.so ECB_ABLATE=$abl timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "k_stream<false, false>" --output-format csv -d $O/a${abl}_$c -- python $R/bench.py --workload $W --steps 1 --warmup 0 --no-cpu-baseline > $O/a${abl}_$c.log 2>&1
   f=$(find $O/a${abl}_$c -name "*counter_collection.csv" | head -1)
   python - "$f" "$abl" "$c" <<'PY'
 import csv, sys

@@ -6,7 +6,7 @@ if [ "$1" == "build" ]; then shift
   done
 else shift; W=$1; shift
   for round in 1 2; do for name in "$@"; do
-    ECB_LIB=libecb_$name.so timeout -k 5 120 python bench.py --workload $W --steps 3 --no-cpu-baseline 2>/dev/null | python -c "
+    ECB_LIB=libecb_$name.so timeout -k 5 120 python bench.py --workload $W --steps 6 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
