@@ -312,7 +312,7 @@ struct StreamCold {
     u64 chunk;                       // records per slice (a multiple of WT)
     u32 prev_rid;                    // read_id of the record before this batch (0xFFFFFFFF at stream start)
     // ECB_F_RANGES (k_stream<false, true>): reference_start of every record and the per-(locus, haplotype) extremes
-    const int* pos; int* rng_min; int* rng_max; u32 n_loci, n_haps;
+    const int* pos; int2* rng; u32 n_loci, n_haps;     // rng[locus * n_haps + hap] = {min, max}: one 8-byte load per record
 };
 // Phases of k_stream can be switched off at run time in a profiling build (libecb_ablate.so: tools/pmc_ladder.sh, tools_ablate.sh);
 // the product build has the tests compiled out -- they cost a scalar register and a handful of branches per tile.
@@ -537,6 +537,8 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
     u32 carry_n = 0;                              // its entries so far, in L.carry
     TileRegs R;
     load_tile(A, (u64)tix << 9, min(((u64)tix << 9) + (u64)WT, A.n), lane, R);
+    int r_pos[RANGES ? RPL : 1];                  // ECB_F_RANGES: reference_start of the tile's records, prefetched with them
+    if constexpr (RANGES) load_pos(C->pos, (u64)tix << 9, min(((u64)tix << 9) + (u64)WT, A.n), lane, r_pos);
     u32 parked = __hip_atomic_load(&A.ctr->full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("" : "+v"(parked));          // (settled before the loop: otherwise the loop header carries an s_waitcnt vmcnt(0) that every tile pays)
     bool slice_done = false;
@@ -567,8 +569,6 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
         // phase (b) needs of it; which records phase (b) takes at all (valid, of a read of this pass) is settled here too:
         // the reads of a tile of mine are numbered base ..., so "one of the pass's WMAXR reads" is one unsigned comparison.
         u32 r_key[RPL], r_bit[RPL];
-        int r_pos[RANGES ? RPL : 1];                // ECB_F_RANGES: reference_start of the tile's records (this tile only: not prefetched)
-        if (RANGES && r_lo == 0u) load_pos(C->pos, (u64)tix << 9, min(((u64)tix << 9) + (u64)WT, A.n), ln, r_pos);
         u32 m_act = 0, m_head = 0;                 // bit k: valid record of a read of this pass / head
         const u32 base_lo = base + r_lo;
         const u32 lim = own ? (u32)WMAXR : ((open && r_lo == 0u) ? 1u : 0u);   // (past my slice only the open read is mine)
@@ -623,22 +623,22 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
                             // none do after the first few thousand).  Re-running a tile (park, further passes) changes nothing: min / max.
                             if (r_lo == 0u) {
                                 const u32 nl = C->n_loci, nh = C->n_haps;
-                                int* const rmin = C->rng_min; int* const rmax = C->rng_max;
-                                u32 sl[2]; int mn[2], mx[2]; bool go[2];
+                                int2* const rng = C->rng;
+                                u32 sl[2]; int2 cur[2]; bool go[2];
 #pragma unroll
                                 for (int j = par; j < 4; j += 2) {
                                     const int k = 4 * g + j;
                                     const u32 lc = R.ll[k], hap = (R.hh[k] >> ECB_HAP_SHIFT) & 0xFFu;
                                     go[j >> 1] = ((ok4 >> j) & 1u) && lc < nl && hap < nh;       // (out of range: reported at emit)
                                     sl[j >> 1] = lc * nh + hap;
-                                    mn[j >> 1] = 0; mx[j >> 1] = 0;
-                                    if (go[j >> 1]) { mn[j >> 1] = rmin[sl[j >> 1]]; mx[j >> 1] = rmax[sl[j >> 1]]; }
+                                    cur[j >> 1] = make_int2(0, 0);
+                                    if (go[j >> 1]) cur[j >> 1] = rng[sl[j >> 1]];
                                 }
 #pragma unroll
                                 for (int j = par; j < 4; j += 2) {
                                     const int ps = r_pos[RANGES ? 4 * g + j : 0];
-                                    if (go[j >> 1] && ps < mn[j >> 1]) atomicMin(rmin + sl[j >> 1], ps);
-                                    if (go[j >> 1] && ps > mx[j >> 1]) atomicMax(rmax + sl[j >> 1], ps);
+                                    if (go[j >> 1] && ps < cur[j >> 1].x) atomicMin(&rng[sl[j >> 1]].x, ps);
+                                    if (go[j >> 1] && ps > cur[j >> 1].y) atomicMax(&rng[sl[j >> 1]].y, ps);
                                 }
                             }
                         }
@@ -685,6 +685,7 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
             asm volatile("" : "+v"(lp) : "v"(m_act), "v"(m_head), "v"(bad), "v"(my_valid));
             const u64 nt = (u64)(again ? tix : tix + 1u) << 9;
             load_tile(A, nt, min(nt + (u64)WT, A.n), lp, R);
+            if constexpr (RANGES) load_pos(C->pos, nt, min(nt + (u64)WT, A.n), lp, r_pos);
             parked_next = __hip_atomic_load(&A.ctr->full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         bool taken = false;                        // the prefetched tile has been waited for (on this path)
@@ -886,6 +887,7 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
 #pragma unroll
                         for (int k = 0; k < RPL; ++k) {
                             asm volatile("" : "+v"(R.rr[k])); asm volatile("" : "+v"(R.ll[k])); asm volatile("" : "+v"(R.hh[k]));
+                            if constexpr (RANGES) asm volatile("" : "+v"(r_pos[k]));
                         }
                         asm volatile("" : "+v"(parked));
                     }
@@ -964,6 +966,7 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
 #pragma unroll
             for (int k = 0; k < RPL; ++k) {
                 asm volatile("" : "+v"(R.rr[k])); asm volatile("" : "+v"(R.ll[k])); asm volatile("" : "+v"(R.hh[k]));
+                if constexpr (RANGES) asm volatile("" : "+v"(r_pos[k]));
             }
             asm volatile("" : "+v"(parked));
         }
@@ -1944,9 +1947,17 @@ __global__ void k_read_ec(const u32* read_slot, u64 n, const u32* rank_of_slot, 
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i < n) out[i] = read_slot[i] == 0xFFFFFFFFu ? -1 : (int)rank_of_slot[read_slot[i]];
 }
-__global__ void k_range_len(const int* mn, const int* mx, u64 n, long long* out) {
+__global__ void k_range_len(const int2* rng, u64 n, long long* out) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (i < n) out[i] = mx[i] == INT_MIN ? 0ll : (long long)mx[i] - (long long)mn[i] + 1ll;
+    if (i < n) { const int2 r = rng[i]; out[i] = r.y == INT_MIN ? 0ll : (long long)r.y - (long long)r.x + 1ll; }
+}
+__global__ void k_fill_minmax(int2* p, u64 n) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n) p[i] = make_int2(INT_MAX, INT_MIN);
+}
+__global__ void k_split_minmax(const int2* rng, u64 n, int* mn, int* mx) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n) { const int2 r = rng[i]; mn[i] = r.x; mx[i] = r.y; }
 }
 __global__ void k_fill_i32(int* p, u64 n, int v) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
@@ -2173,7 +2184,7 @@ struct ecb_handle {
     // ecb_ms_filter's results (device): kept cells in sample order, rows of A of the kept ECs, CSC N
     bool ms_filtered = false; ecb_ms_sizes msf{};
     u32* f_cells = nullptr; int *f_ipa = nullptr, *f_ixa = nullptr, *f_daa = nullptr, *f_ipn = nullptr, *f_ixn = nullptr, *f_dan = nullptr;
-    int *rng_min = nullptr, *rng_max = nullptr;
+    int2* rng = nullptr;                       // ECB_F_RANGES: {min, max} of reference_start per (locus, haplotype)
     u64* queue = nullptr; u64 queue_cap = 0;
     u64 n_ecs() const { return hctr.n_ecs; }
     u32 prev_rid = 0xFFFFFFFFu;       // read_id of the last record pushed so far
@@ -2406,7 +2417,7 @@ int verify_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d
     HIPCHK(h, hipMemsetAsync(&h->ctr->next_slice, 0, sizeof(u64), h->stream));
     HIPCHK(h, hipMemsetAsync(&h->ctr->n_mismatch, 0, sizeof(u64), h->stream));
     *h->pin_cold = StreamCold{h->arena, h->arena_cap, h->queue, h->queue_cap, d_resume, d_wcounts, nullptr, nullptr, P.chunk, prev_rid,
-                              nullptr, nullptr, nullptr, 0u, 0u};
+                              nullptr, nullptr, 0u, 0u};
     HIPCHK(h, hipMemcpyAsync(h->d_cold, h->pin_cold, sizeof(StreamCold), hipMemcpyHostToDevice, h->stream));
     StreamArgs a{d_rid, d_loc, d_hf, n, h->table, h->cap - 1, h->ctr, h->read_slot, h->reads_hi, h->d_cold, 0u};
     k_stream<true><<<(unsigned)P.blocks, TPB, 0, h->stream>>>(a);
@@ -2440,7 +2451,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     // keep the table at most half full before a batch (it grows again, via k_slow, if a batch overfills it)
     while (h->n_ecs() * 2 > h->cap) { rc = grow_table(h, h->cap * 4); if (rc != ECB_OK) return rc; }
     StreamPlan P;
-    rc = plan_stream(h, n, &P, h->rng_min != nullptr);
+    rc = plan_stream(h, n, &P, h->rng != nullptr);
     if (rc != ECB_OK) return rc;
     const u64 waves = P.slices, chunk = P.chunk, blocks = P.blocks, pwaves = P.pwaves;
     u64* d_resume = nullptr;
@@ -2460,7 +2471,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
         h->wave_arena = wa; h->wave_arena_n = pwaves;
     }
     StreamCold cold{h->arena, h->arena_cap, h->queue, h->queue_cap, d_resume, d_wcounts, h->wave_arena, nullptr, chunk, h->prev_rid,
-                    d_pos, h->rng_min, h->rng_max, h->cfg.n_loci, h->cfg.n_haplotypes};
+                    d_pos, h->rng, h->cfg.n_loci, h->cfg.n_haplotypes};
 #ifdef ECB_TIMING
     HIPCHK(h, hipMalloc(&cold.timing, 8 * sizeof(u64)));
     HIPCHK(h, hipMemset(cold.timing, 0, 8 * sizeof(u64)));
@@ -2478,7 +2489,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
         a.table = h->table; a.cap_mask = h->cap - 1;
         HIPCHK(h, hipMemsetAsync(d_wcounts, 0, 3 * pwaves * sizeof(u32), h->stream));
         if (h->prof) hipEventRecord(h->ev0, h->stream);
-        if (h->rng_min) k_stream<false, true><<<(unsigned)blocks, TPB, 0, h->stream>>>(a);     // ... with the range update fused in
+        if (h->rng) k_stream<false, true><<<(unsigned)blocks, TPB, 0, h->stream>>>(a);     // ... with the range update fused in
         else k_stream<false><<<(unsigned)blocks, TPB, 0, h->stream>>>(a);
         if (h->prof) hipEventRecord(h->ev1, h->stream);
         k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, pwaves, h->ctr, 0u, offered);
@@ -2776,10 +2787,8 @@ int ecb_create(const ecb_config* cfg, ecb_handle** out) {
     clear_counters(h);
     if (cfg->flags & ECB_F_RANGES) {
         const u64 ns = (u64)cfg->n_loci * cfg->n_haplotypes;
-        if ((e = hipMalloc(&h->rng_min, ns * sizeof(int))) != hipSuccess) return bail(ECB_ERR_HIP, "hipMalloc(ranges)", e);
-        if ((e = hipMalloc(&h->rng_max, ns * sizeof(int))) != hipSuccess) return bail(ECB_ERR_HIP, "hipMalloc(ranges)", e);
-        k_fill_i32<<<nblk(ns, TPB), TPB, 0, h->stream>>>(h->rng_min, ns, INT_MAX);
-        k_fill_i32<<<nblk(ns, TPB), TPB, 0, h->stream>>>(h->rng_max, ns, INT_MIN);
+        if ((e = hipMalloc(&h->rng, ns * sizeof(int2))) != hipSuccess) return bail(ECB_ERR_HIP, "hipMalloc(ranges)", e);
+        k_fill_minmax<<<nblk(ns, TPB), TPB, 0, h->stream>>>(h->rng, ns);
     }
     hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
     if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return bail(ECB_ERR_HIP, "init", e);
@@ -2793,7 +2802,7 @@ void ecb_destroy(ecb_handle* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     free_results(h);
     hipFree(h->table); hipFree(h->arena); hipFree(h->ctr); hipFree(h->read_slot); hipFree(h->meta);
-    hipFree(h->rng_min); hipFree(h->rng_max); hipFree(h->queue); hipFree(h->wave_arena);
+    hipFree(h->rng); hipFree(h->queue); hipFree(h->wave_arena);
     if (h->pin_ctr) hipHostFree(h->pin_ctr);
     if (h->pin_cold) hipHostFree(h->pin_cold);
     hipFree(h->d_cold);
@@ -2840,10 +2849,9 @@ int ecb_reset(ecb_handle* h) {
     { int rc_ = clear_counters(h); if (rc_ != ECB_OK) return rc_; }
     if (h->wave_arena) HIPCHK(h, hipMemsetAsync(h->wave_arena, 0, 2 * h->wave_arena_n * sizeof(u64), h->stream));
     if (h->read_slot && h->reads_hi) HIPCHK(h, hipMemsetAsync(h->read_slot, 0xFF, h->reads_hi * sizeof(u32), h->stream));
-    if (h->rng_min) {
+    if (h->rng) {
         const u64 ns = (u64)h->cfg.n_loci * h->cfg.n_haplotypes;
-        k_fill_i32<<<nblk(ns, TPB), TPB, 0, h->stream>>>(h->rng_min, ns, INT_MAX);
-        k_fill_i32<<<nblk(ns, TPB), TPB, 0, h->stream>>>(h->rng_max, ns, INT_MIN);
+        k_fill_minmax<<<nblk(ns, TPB), TPB, 0, h->stream>>>(h->rng, ns);
     }
     // (no wait: everything above is ordered on the handle's stream, where all later work goes too)
     h->prev_rid = 0xFFFFFFFFu; h->n_reads = 0; h->reads_hi = 0; h->meta_hi = 0; h->n_triples = 0; h->ms_ocount = nullptr; h->ms_adopted = false;
@@ -3044,7 +3052,7 @@ int ecb_export_ranges(ecb_handle* h, int64_t* out) {
     const u64 ns = (u64)h->cfg.n_loci * h->cfg.n_haplotypes;
     long long* d = nullptr;
     HIPCHK(h, hipMalloc(&d, ns * 8));
-    k_range_len<<<nblk(ns, TPB), TPB, 0, h->stream>>>(h->rng_min, h->rng_max, ns, d);
+    k_range_len<<<nblk(ns, TPB), TPB, 0, h->stream>>>(h->rng, ns, d);
     HIPCHK(h, hipMemcpyAsync(out, d, ns * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipFree(d));
@@ -3056,9 +3064,14 @@ int ecb_export_range_minmax(ecb_handle* h, int32_t* mn, int32_t* mx) {
     if (!(h->cfg.flags & ECB_F_RANGES)) return fail(h, ECB_ERR_STATE, "handle was created without ECB_F_RANGES");
     HIPCHK(h, hipSetDevice(h->device));
     const u64 ns = (u64)h->cfg.n_loci * h->cfg.n_haplotypes;
-    HIPCHK(h, hipMemcpyAsync(mn, h->rng_min, ns * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(mx, h->rng_max, ns * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int* d = nullptr;
+    HIPCHK(h, hipMalloc(&d, 2 * ns * sizeof(int)));
+    k_split_minmax<<<nblk(ns, TPB), TPB, 0, h->stream>>>(h->rng, ns, d, d + ns);
+    hipError_t e = hipMemcpyAsync(mn, d, ns * 4, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(mx, d + ns, ns * 4, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d);
+    if (e != hipSuccess) return fail(h, ECB_ERR_HIP, "range export: %s", hipGetErrorString(e));
     return ECB_OK;
 }
 
