@@ -1752,7 +1752,7 @@ __global__ __launch_bounds__(TPB) void k_scan_apply(const u32* in, u64 n, const 
 }
 
 __global__ void k_rank(const u32* list, const uint2* list_fn, u64 n, u64 n_bits, const u32* bitmap, const u32* wprefix,
-                       u32* order, u32* rowlen, u32* rank_of_slot) {
+                       u32* order, u32* rowlen) {
     const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (e >= n) return;
     const u32 si = list[e];
@@ -1763,7 +1763,12 @@ __global__ void k_rank(const u32* list, const uint2* list_fn, u64 n, u64 n_bits,
     if (r >= n) return;
     order[r] = si;
     rowlen[r] = fn.y;
-    rank_of_slot[si] = r;
+}
+// EC rank of every occupied slot: only the per-read EC ids need it (multisample, ecb_export_read_ec) -- a scatter over the
+// whole table's index space that the single-sample result never reads
+__global__ void k_slot_ranks(const u32* order, u64 n, u32* rank_of_slot) {
+    const u64 r = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (r < n) rank_of_slot[order[r]] = (u32)r;
 }
 
 // CSR rows: every (locus, mask) pair of an EC is ranked by locus and written in place (columns ascending, as scipy's
@@ -2641,6 +2646,14 @@ int handle_sort(ecb_handle* h, u64* k[2], u32* v[2], u64 n, int* where) {
     return ECB_OK;
 }
 
+int ensure_slot_ranks(ecb_handle* h, u64 E) {
+    if (h->rank_of_slot) return ECB_OK;
+    POOL(h, P_RANK, h->rank_of_slot, h->cap);
+    k_slot_ranks<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->order, E, h->rank_of_slot);
+    HIPCHK(h, hipGetLastError());
+    return ECB_OK;
+}
+
 // reads per EC / first appearance, from read_slot[0, n_reads) (once, when the stream is closed).  Only queues kernels:
 // the totals and the work list of k_count_bins stay on the device.
 int ensure_counts(ecb_handle* h) {
@@ -2962,7 +2975,8 @@ int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
     u64* d_tot = nullptr;                            // [0] occupied slots, [1] distinct first reads, [2] nnz, [3] long rows (u32)
     POOL(h, P_BITMAP, bitmap, words); POOL(h, P_WPOP, wpop, words); POOL(h, P_WPREFIX, wprefix, words);
     POOL(h, P_ROWLEN, rowlen, E); POOL(h, P_LISTFN, list_fn, E);
-    POOL(h, P_ORDER, h->order, E); POOL(h, P_RANK, h->rank_of_slot, h->cap);
+    POOL(h, P_ORDER, h->order, E);
+    h->rank_of_slot = nullptr;                       // (made on demand: ensure_slot_ranks)
     POOL(h, P_INDPTR, h->indptr, E + 1); POOL(h, P_COUNTS, h->counts, E);
     POOL(h, P_INDICES, h->indices, nnz_max); POOL(h, P_DATA, h->data, nnz_max);
     POOL(h, P_TOTALS, d_tot, 8);
@@ -2976,7 +2990,7 @@ int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
     k_popc<<<nblk(words, TPB), TPB, 0, h->stream>>>(bitmap, words, wpop);
     rc = excl_scan_dev(h, wpop, words, wprefix, d_tot + 1);
     if (rc != ECB_OK) return rc;
-    k_rank<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->list, list_fn, E, total_reads, bitmap, wprefix, h->order, rowlen, h->rank_of_slot);
+    k_rank<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->list, list_fn, E, total_reads, bitmap, wprefix, h->order, rowlen);
     rc = excl_scan_dev(h, rowlen, E, h->indptr, d_tot + 2);
     if (rc != ECB_OK) return rc;
     k_set_last<<<1, 1, 0, h->stream>>>(h->indptr + E, d_tot + 2);
@@ -3000,6 +3014,8 @@ int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
             h->n_triples = 0; h->sizes.n_samples = 0; h->sizes.nnz_n = 0;
         } else {
             if (h->extra_reads) return fail(h, ECB_ERR_STATE, "multisample across GPUs: adopt the merged ECs (ecb_table_adopt_device), then ecb_ms_adopt_triples_device");
+            rc = ensure_slot_ranks(h, E);
+            if (rc != ECB_OK) return rc;
             rc = ms_reduce(h, h->rank_of_slot);
             if (rc != ECB_OK) return rc;
             h->sizes.n_samples = 0; h->sizes.nnz_n = h->n_triples;
@@ -3099,6 +3115,7 @@ int ecb_export_read_ec(ecb_handle* h, int32_t* out) {
     HIPCHK(h, hipSetDevice(h->device));
     int* d = nullptr;
     HIPCHK(h, hipMalloc(&d, std::max<u64>(h->n_reads, 1) * 4));
+    { const int rc_ = ensure_slot_ranks(h, h->sizes.n_ecs); if (rc_ != ECB_OK) { hipFree(d); return rc_; } }
     k_read_ec<<<nblk(h->n_reads, TPB), TPB, 0, h->stream>>>(h->read_slot, h->n_reads, h->rank_of_slot, d);
     HIPCHK(h, hipMemcpyAsync(out, d, h->n_reads * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
