@@ -1631,7 +1631,8 @@ struct ListCmp {                                   // incoming key = a sorted pa
         return CMP_EQUAL;
     }
 };
-constexpr u32 MERGE_PER_BLOCK = 16 * TPB;     // entries per workgroup (one EC-count atomic per workgroup, not per wave: ~18 ns each on one address)
+constexpr u32 MERGE_PER_BLOCK = 2 * TPB;      // entries per workgroup: a piece of one key range is a few hundred thousand entries, and with 16 x TPB
+                                              // each it occupied 71 of the 256 CUs (one EC-count atomic per workgroup, fire and forget)
 __global__ __launch_bounds__(TPB) void k_merge(const Entry* ent, u64 n, const uint2* pairs, u64 n_pairs, Slot* table, u64 cap_mask,
                                                uint2* arena, u64 arena_cap, Counters* ctr) {
     __shared__ u32 s_new;
@@ -2172,7 +2173,7 @@ struct ecb_handle {
     bool counted = false;             // Slot::count / first_inv hold the reads pushed so far (k_count ran)
     u64* wave_arena = nullptr; u64 wave_arena_n = 0;   // see StreamArgs::wave_arena
     bool scatter_attr_set = false, count_attr_set = false;
-    u64 resident_blocks = 0, resident_blocks_rg = 0, rounds = 32;     // k_stream's launch shape (queried once)
+    u64 resident_blocks = 0, resident_blocks_rg = 0, rounds = 32, min_tiles = 32;     // k_stream's launch shape (queried once)
     bool ctr_synced = false;          // hctr is what the device holds (no kernel that counts has been queued since the last read-back)
     bool adopted = false;             // the table holds adopted entries in consecutive slots (no hashing): finalize / export only
 
@@ -2382,9 +2383,15 @@ int plan_stream(ecb_handle* h, u64 n, StreamPlan* P, bool ranges = false) {
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpr, k_stream<false, true>, TPB, 0);
         h->resident_blocks_rg = (u64)std::max(cus, 1) * std::max(bpr, 1);
         h->rounds = getenv("ECB_ROUNDS") ? std::max(1, atoi(getenv("ECB_ROUNDS"))) : 32;
+        h->min_tiles = getenv("ECB_MIN_TILES") ? std::max(2, atoi(getenv("ECB_MIN_TILES"))) : 32;
     }
     const u64 rounds = h->rounds, resident_blocks = ranges ? h->resident_blocks_rg : h->resident_blocks;
-    u64 waves = resident_blocks * NWAVE * rounds;
+    // slices: `rounds` per resident wave for balance, but not shorter than MIN_TILES tiles while every resident wave still gets
+    // one -- a wave runs on past its slice's end to finish its open read, so every slice costs about one tile read twice
+    // (at 5 tiles per slice, an eighth of config 3 on one of 8 GPUs, that was a fifth of the kernel)
+    const u64 MIN_TILES = h->min_tiles;
+    const u64 res_waves = resident_blocks * NWAVE;
+    u64 waves = std::min<u64>(res_waves * rounds, std::max<u64>(n / (MIN_TILES * WT), res_waves));
     waves = std::min<u64>(waves, (n + 2 * WT - 1) / (2 * WT));
     waves = std::max<u64>(waves, 1);
     u64 chunk = (n + waves - 1) / waves;

@@ -11,6 +11,8 @@ import bench
 from alntools_amd import ecb, synth, dist as ecdist
 
 w = sys.argv[1] if len(sys.argv) > 1 else "c3"
+NS = tuple(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 else (1, 2, 4, 8)
+SIMPLE = len(sys.argv) <= 3 or sys.argv[3] != "ranges"
 R, T, H, paired, _ = bench.WORKLOADS[w]
 dev = torch.device("cuda", 0)
 spec = synth.SynthSpec(R, T, H, paired=paired)
@@ -28,7 +30,7 @@ def sync():
 
 part = ecb.EcBuilder(T, H, device=0, ec_capacity=1 << 23, arena_capacity=1 << 26)
 peng = ecdist.GpuEngine(part, dev)
-for N in (1, 2, 4, 8):
+for N in NS:
     for rep in range(2):
         rank_ms, pieces, base, tot = [], [], 0, [0, 0, 0]
         for r in range(N):
@@ -50,7 +52,7 @@ for N in (1, 2, 4, 8):
             tot = [tot[0] + a, tot[1] + v, tot[2] + nreads]
             del s
         root.reset()
-        part_ms, adopt_ms, moved = [], 0.0, []
+        part_ms, adopt_ms, moved, merged = [], 0.0, [], []
         for q in range(N):
             t0 = sync()
             part.reset()
@@ -59,11 +61,13 @@ for N in (1, 2, 4, 8):
             pe_n, pp_n, _ = part.table_sizes()
             pe, pp = peng.table_export(0)
             t1 = sync()
-            reng.table_adopt(pe, pe_n, pp, pp_n)
-            t2 = sync()
+            merged.append((pe.clone(), pe_n, pp.clone(), pp_n))      # (what arrives at the root: all ranges, adopted in one call as dist.py does)
             part_ms.append((t1 - t0) * 1e3)
-            adopt_ms += (t2 - t1) * 1e3
             moved.append((pe_n * 32 + pp_n * 8) / 1e6)
+        t1 = sync()
+        reng.table_adopt_many(merged)
+        adopt_ms = (sync() - t1) * 1e3
+        del merged
         root.add_counters(*tot)
         t5 = sync()
         sz = root.finalize()
@@ -77,7 +81,7 @@ for N in (1, 2, 4, 8):
               N, rk, max(x[0] for x in rank_ms), max(x[1] for x in rank_ms), max(x[2] for x in rank_ms), max(part_ms), adopt_ms,
               (t6 - t5) * 1e3, max(sent), sum(moved[1:]), (max(sent) / max(N - 1, 1)) / 153.0, (max(moved[1:]) if N > 1 else 0.0) / 153.0, rk + max(part_ms) + adopt_ms + (t6 - t5) * 1e3, sz["n_ecs"]), flush=True)
 
-for N in (1, 2, 4, 8):
+for N in (NS if SIMPLE else ()):
     for rep in range(2):
         root.reset()
         rank_ms, merge_ms, tabs, base = [], [], [], 0
