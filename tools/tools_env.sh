@@ -2,7 +2,7 @@
 # GPU box: bench one workload under several values of one env var: tools_env.sh <workload> <VAR> v1 v2 ...
 W=$1; V=$2; shift 2
 for round in 1 2; do for x in "$@"; do
-  env $V=$x timeout -k 5 120 python bench.py --workload $W --steps 6 --no-cpu-baseline 2>/dev/null | python -c "
+  env $V=$x timeout -k 5 120 python bench.py --workload $W --steps 10 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
