@@ -5,7 +5,7 @@
 W=${1:-c2}
 for x in ${2:-1 2 4 0}; do
   a=${x%%:*}; cap=${x#*:}; [ "$cap" = "$x" ] && cap=""
-  env ECB_LIB=libecb_ablate.so ECB_ABLATE=$a ${cap:+ECB_EC_CAP_LOG2=$cap} ECB_NO_VERIFY=1 timeout -k 5 120 python bench.py --workload $W --steps 3 --no-cpu-baseline 2>/dev/null | python -c "
+  env ECB_LIB=libecb_ablate.so ECB_ABLATE=$a ${cap:+ECB_EC_CAP_LOG2=$cap} ECB_NO_VERIFY=1 timeout -k 5 120 python bench.py --workload $W --steps 8 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
