@@ -35,6 +35,7 @@ WORKLOADS = {
     "tiny": (400_000, 4_000, 8, True, "smoke-sized paired-end workload"),
     "c3h": (50_000_000, 80_000, 8, True, "half of config 3 (debug)"),
     "c2x": (150_000_000, 40_000, 8, False, "3x config 2 (debug: > 2^31 records)"),
+    "dip": (200_000_000, 40_000, 2, False, "diploid single-end reads: 2 hap x 40k transcripts, ~4 records per read (short reads: several passes per tile)"),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
