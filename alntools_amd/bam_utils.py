@@ -23,9 +23,15 @@ LOG = utils.get_logger()
 BATCH_RECORDS = 1 << 20
 
 
-def open_bam(filename):
-    """pysam when installed (the reference's decoder), else the built-in reader; both yield
-    ``(qname, flag, tid, pos, next_tid, next_pos)`` and expose ``.references`` / ``.lengths``."""
+def open_bam(filename, names=True):
+    """``names=False`` (the single-sample path, which only needs to know where the read names CHANGE): the native decoder
+    ``bamdec.NativeBamReader`` if ``libbamdec.so`` is built and ``ALNTOOLS_DECODER`` is not ``py``.  Otherwise pysam when
+    installed (the reference's decoder), else the built-in pure-Python reader; those yield
+    ``(qname, flag, tid, pos, next_tid, next_pos)``.  All expose ``.references`` / ``.lengths``."""
+    if not names and os.environ.get("ALNTOOLS_DECODER", "c") != "py":
+        from . import bamdec
+        if bamdec.available():
+            return bamdec.NativeBamReader(filename)
     try:
         import pysam
     except ImportError:
@@ -54,6 +60,21 @@ class _PysamReader(object):
         self._af.close()
 
 
+def iter_tuple_batches(reader, enc):
+    """Tuples of the whole file, a batch of records at a time, from either kind of reader (``open_bam``)."""
+    if hasattr(reader, "read_decoded"):            # native decoder: no names, no per-record Python
+        while True:
+            d = reader.read_decoded(BATCH_RECORDS)
+            if d is None:
+                return
+            yield enc.encode_decoded(**d)
+    while True:
+        q, flag, tid, pos, ntid, npos = reader.read_batch(BATCH_RECORDS)
+        if not len(q):
+            return
+        yield enc.encode(q, flag, tid, pos, ntid, npos)
+
+
 def write_range_file(range_filename, maps, range_len):
     """``bam_utils.py:735-766``: header ``#<TAB>haplotypes``, one row per main target, ``max-min+1`` or ``0``."""
     with open(range_filename, "w") as fw:
@@ -65,7 +86,7 @@ def write_range_file(range_filename, maps, range_len):
 def stream_bam_to_builder(bam_filename, builder, maps=None, target_filename=None, track_ranges=False,
                           encoder_factory=TupleEncoder):
     """Decode one BAM on the host and push its tuples; returns ``(maps, encoder, n_records)``."""
-    reader = open_bam(bam_filename)
+    reader = open_bam(bam_filename, names=builder is None or encoder_factory is not TupleEncoder)
     try:
         if maps is None:
             targets = list(utils.parse_targets(target_filename).keys()) if target_filename else None
@@ -74,13 +95,9 @@ def stream_bam_to_builder(bam_filename, builder, maps=None, target_filename=None
         if builder is None:
             return maps, enc, reader
         n_rec = 0
-        while True:
-            q, flag, tid, pos, ntid, npos = reader.read_batch(BATCH_RECORDS)
-            if not q:
-                break
-            t = enc.encode(q, flag, tid, pos, ntid, npos)
+        for t in iter_tuple_batches(reader, enc):
             builder.push(t["read_id"], t["locus"], t["hapflag"], t["pos"] if track_ranges else None)
-            n_rec += len(q)
+            n_rec += len(t["read_id"])
         return maps, enc, n_rec
     finally:
         if builder is not None:
@@ -141,14 +158,11 @@ def _rank_convert(rank, world, port, backend, devices, bam_filename, ec_filename
         tdist.init_process_group(backend, rank=rank, world_size=world)
     targets = list(utils.parse_targets(target_filename).keys()) if target_filename else None
     # pass 1: how many reads there are (name runs among valid records: only the host can tell)
-    reader = open_bam(bam_filename)
+    reader = open_bam(bam_filename, names=False)
     maps = HeaderMaps(reader.references, reader.lengths, targets)
     enc = TupleEncoder(maps)
-    while True:
-        q, flag, tid, pos, ntid, npos = reader.read_batch(BATCH_RECORDS)
-        if not len(q):
-            break
-        enc.encode(q, flag, tid, pos, ntid, npos)
+    for _ in iter_tuple_batches(reader, enc):
+        pass
     reader.close()
     R = 0 if enc.cur == 0xFFFFFFFF else enc.cur + 1
     r0, r1 = rank * R // world, (rank + 1) * R // world
@@ -156,13 +170,9 @@ def _rank_convert(rank, world, port, backend, devices, bam_filename, ec_filename
     track = range_filename is not None
     b = EcBuilder(maps.n_loci, maps.n_haplotypes, device=dev_index, track_ranges=track)
     # pass 2: my reads.  A record belongs to the read whose id it carries (records before the first read: to rank 0).
-    reader = open_bam(bam_filename)
+    reader = open_bam(bam_filename, names=False)
     enc = TupleEncoder(maps)
-    while True:
-        q, flag, tid, pos, ntid, npos = reader.read_batch(BATCH_RECORDS)
-        if not len(q):
-            break
-        t = enc.encode(q, flag, tid, pos, ntid, npos)
+    for t in iter_tuple_batches(reader, enc):
         rid = t["read_id"].astype(np.int64)
         rid[rid == 0xFFFFFFFF] = -1
         mine = (rid >= r0) & (rid < r1) if rank else (rid < r1)
@@ -225,7 +235,7 @@ def convert(bam_filename, ec_filename, emase_filename, num_chunks=0, number_proc
         LOG.info("Done, total time: {}".format(utils.format_time(start_time, time.time())))
         return sizes
     LOG.info("Parsing file information ...")
-    reader = open_bam(bam_filename)
+    reader = open_bam(bam_filename, names=False)
     targets = None
     if target_filename:
         targets = list(utils.parse_targets(target_filename).keys())
@@ -237,11 +247,7 @@ def convert(bam_filename, ec_filename, emase_filename, num_chunks=0, number_proc
     with EcBuilder(maps.n_loci, maps.n_haplotypes, device=device, track_ranges=range_filename is not None,
                    verify=bool(int(os.environ.get("ALNTOOLS_VERIFY", "0")))) as b:
         enc = TupleEncoder(maps)
-        while True:
-            q, flag, tid, pos, ntid, npos = reader.read_batch(BATCH_RECORDS)
-            if not len(q):
-                break
-            t = enc.encode(q, flag, tid, pos, ntid, npos)
+        for t in iter_tuple_batches(reader, enc):
             b.push(t["read_id"], t["locus"], t["hapflag"], t["pos"] if range_filename else None)
         reader.close()
         sizes = b.finalize()

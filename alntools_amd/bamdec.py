@@ -1,0 +1,109 @@
+# -*- coding: utf-8 -*-
+"""ctypes binding of ``libbamdec.so`` (``csrc/bamdec.c``): the BAM decoder of the host side.
+
+The reference iterates a ``pysam.AlignmentFile`` record by record in Python (``bam_utils.py:253-320``); here the BGZF blocks are
+inflated by a pool of threads and the records parsed in C, and what comes back are column arrays: the raw fields the tuple
+encoder needs, whether a record passes the reference's filter (``:264-270``) and whether it starts a new read (runs of equal,
+space-trimmed names among the records that pass, ``:289-320``).  ``alntools_amd.bamio.BamReader`` is the pure-Python reader of
+the same records (it also yields the names, which the multisample path needs); ``tests/test_host_logic.py`` holds the two to
+each other.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbamdec.so")
+SRC = os.path.join(_HERE, "csrc", "bamdec.c")
+SYMBOLS = ("bd_abi_version", "bd_open", "bd_close", "bd_last_error", "bd_n_references", "bd_reference_name",
+           "bd_reference_length", "bd_header_text", "bd_read")
+_lib = None
+
+
+def build(force=False):
+    """gcc + zlib, in-tree (``python -m alntools_amd.build`` calls this too)."""
+    import subprocess
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= os.path.getmtime(SRC):
+        return LIB_PATH
+    subprocess.check_call([os.environ.get("CC", "gcc"), "-O2", "-Wall", "-shared", "-fPIC", "-o", LIB_PATH, SRC, "-lz", "-lpthread"])
+    return LIB_PATH
+
+
+def available():
+    return os.path.exists(LIB_PATH)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        l = C.CDLL(LIB_PATH)
+        l.bd_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+        l.bd_close.argtypes = [C.c_void_p]
+        l.bd_close.restype = None
+        l.bd_last_error.argtypes = [C.c_void_p]
+        l.bd_last_error.restype = C.c_char_p
+        l.bd_n_references.argtypes = [C.c_void_p]
+        l.bd_reference_name.argtypes = [C.c_void_p, C.c_int32]
+        l.bd_reference_name.restype = C.c_char_p
+        l.bd_reference_length.argtypes = [C.c_void_p, C.c_int32]
+        l.bd_header_text.argtypes = [C.c_void_p]
+        l.bd_header_text.restype = C.c_char_p
+        l.bd_read.argtypes = [C.c_void_p, C.c_size_t, C.c_int] + [C.c_void_p] * 7 + [C.POINTER(C.c_size_t)]
+        _lib = l
+    return _lib
+
+
+class NativeBamReader(object):
+    """Same surface as ``bamio.BamReader`` where the single-sample path needs it (``references``, ``lengths``, ``close``);
+    ``read_decoded`` instead of ``read_batch``: no names cross into Python."""
+
+    def __init__(self, path, threads=None, trim=True):
+        self._l = lib()
+        self._h = C.c_void_p()
+        threads = threads or int(os.environ.get("ALNTOOLS_DECODE_THREADS", min(os.cpu_count() or 1, 16)))
+        rc = self._l.bd_open(os.fsencode(path), threads, C.byref(self._h))
+        if rc != 0:
+            raise (IOError if rc == -1 else ValueError)("%s: cannot read as BAM (bamdec error %d)" % (path, rc))
+        n = self._l.bd_n_references(self._h)
+        self.references = tuple(self._l.bd_reference_name(self._h, i).decode("utf-8") for i in range(n))
+        self.lengths = tuple(self._l.bd_reference_length(self._h, i) for i in range(n))
+        self.text = (self._l.bd_header_text(self._h) or b"").decode("utf-8", "replace")
+        self.trim = 1 if trim else 0
+        self._cap = 0
+
+    def _arrays(self, n):
+        if n > self._cap:
+            self._flag = np.empty(n, np.uint16)
+            self._i32 = [np.empty(n, np.int32) for _ in range(4)]
+            self._u8 = [np.empty(n, np.uint8) for _ in range(2)]
+            self._cap = n
+
+    def read_decoded(self, max_records):
+        """-> dict(flag u16, tid, pos, next_tid, next_pos i32, valid u8, head u8) of up to ``max_records`` records, or ``None``
+        at the end of the file.  The arrays are views of buffers the next call overwrites."""
+        self._arrays(max_records)
+        n = C.c_size_t(0)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        rc = self._l.bd_read(self._h, max_records, self.trim, p(self._flag), p(self._i32[0]), p(self._i32[1]), p(self._i32[2]),
+                             p(self._i32[3]), p(self._u8[0]), p(self._u8[1]), C.byref(n))
+        if rc != 0:
+            raise ValueError("BAM decode failed: %s" % self._l.bd_last_error(self._h).decode())
+        k = n.value
+        if k == 0:
+            return None
+        return dict(flag=self._flag[:k], tid=self._i32[0][:k], pos=self._i32[1][:k], next_tid=self._i32[2][:k],
+                    next_pos=self._i32[3][:k], valid=self._u8[0][:k], head=self._u8[1][:k])
+
+    def close(self):
+        if self._h:
+            self._l.bd_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -23,6 +23,8 @@ def needs_build():
 
 def build(force=False, verbose=False):
     """Compile the HIP extension; returns the path of the shared library."""
+    from . import bamdec
+    bamdec.build(force=force)                    # the host side's BAM decoder (plain C + zlib): a library of its own
     if not force and not needs_build():
         return OUT
     cmd = [HIPCC] + FLAGS + ["-o", OUT, SRC]

@@ -1,0 +1,263 @@
+/* bamdec -- the host side's BAM decoder: what iterating a pysam.AlignmentFile gives the reference's scan loop
+ * (alntools/bam_utils.py:253-320), as column arrays, without a Python loop over records.
+ *
+ * Per record it yields the raw fields the tuple encoder needs (flag, refID, pos, next_refID, next_pos), whether the record
+ * passes the reference's filter (bam_utils.py:264-270) and whether it starts a new read: reads are RUNS of equal names among
+ * the records that pass the filter, a name being cut at its first space if that space is not its first character
+ * (bam_utils.py:289-320).  Names are compared as bytes here (the reference compares the decoded strings: the same thing for
+ * valid UTF-8).  BGZF blocks are inflated by a small pool of threads (blocks are independent; ISIZE gives every block's
+ * place in the output before it is inflated); records are parsed by the caller's thread.
+ *
+ * Plain C + zlib; bound from Python with ctypes (alntools_amd/bamdec.py).  Not part of libecb: the device library never
+ * touches files.
+ */
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+#define BD_OK 0
+#define BD_ERR_IO -1
+#define BD_ERR_FORMAT -2
+#define BD_ERR_MEM -3
+#define BD_ERR_ARG -4
+
+#define BLOCKS_PER_FILL 512            /* up to 32 MB of inflated data per refill */
+#define MAX_THREADS 32
+
+typedef struct {
+    const uint8_t* src; uint32_t src_len;       /* raw deflate stream of one block */
+    uint8_t* dst; uint32_t dst_len;             /* where it goes, and ISIZE */
+    uint32_t crc;
+} bd_block;
+
+typedef struct bd_handle {
+    FILE* f;
+    uint8_t* raw; size_t raw_cap;               /* compressed bytes of the blocks being inflated */
+    uint8_t* buf; size_t cap, len, pos;         /* inflated stream: [pos, len) is unread */
+    bd_block blocks[BLOCKS_PER_FILL];
+    int n_threads;
+    int eof;
+    /* header */
+    char* text; int32_t l_text; int32_t n_ref; char** names; int32_t* lens;
+    /* the (trimmed) name of the latest record that passed the filter */
+    uint8_t* last; size_t last_cap; int32_t last_len; int has_last;
+    char err[256];
+} bd_handle;
+
+static int fail(bd_handle* h, int code, const char* msg) {
+    if (h) { strncpy(h->err, msg, sizeof(h->err) - 1); h->err[sizeof(h->err) - 1] = 0; }
+    return code;
+}
+
+/* ---- inflate pool ---------------------------------------------------------------------------------------------- */
+typedef struct { bd_block* blocks; int n, first, step; int rc; } bd_job;
+
+static void* inflate_worker(void* arg) {
+    bd_job* j = (bd_job*)arg;
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, -15) != Z_OK) { j->rc = BD_ERR_MEM; return NULL; }
+    for (int i = j->first; i < j->n; i += j->step) {
+        bd_block* b = &j->blocks[i];
+        if (b->dst_len == 0) continue;
+        inflateReset(&zs);
+        zs.next_in = (Bytef*)b->src; zs.avail_in = b->src_len;
+        zs.next_out = b->dst; zs.avail_out = b->dst_len;
+        const int r = inflate(&zs, Z_FINISH);
+        if (r != Z_STREAM_END || zs.avail_out != 0 || crc32(crc32(0L, Z_NULL, 0), b->dst, b->dst_len) != b->crc) { j->rc = BD_ERR_FORMAT; break; }
+    }
+    inflateEnd(&zs);
+    return NULL;
+}
+
+/* read up to BLOCKS_PER_FILL BGZF blocks and append their inflated bytes to the stream buffer */
+static int refill(bd_handle* h) {
+    if (h->eof) return BD_OK;
+    /* keep the unread tail at the front */
+    if (h->pos) { memmove(h->buf, h->buf + h->pos, h->len - h->pos); h->len -= h->pos; h->pos = 0; }
+    size_t raw_used = 0, out_total = 0;
+    int nb = 0;
+    while (nb < BLOCKS_PER_FILL) {
+        uint8_t hd[18];
+        const size_t got = fread(hd, 1, 18, h->f);
+        if (got == 0) { h->eof = 1; break; }
+        if (got != 18 || hd[0] != 0x1f || hd[1] != 0x8b || hd[2] != 8 || !(hd[3] & 4)) return fail(h, BD_ERR_FORMAT, "not a BGZF block");
+        const uint32_t xlen = hd[10] | (hd[11] << 8);
+        /* the BC subfield is the first one in every BGZF writer's output; walk the extra field to be safe */
+        uint32_t bsize = 0;
+        uint8_t extra[65536];
+        memcpy(extra, hd + 12, 6);
+        if (xlen > 6 && fread(extra + 6, 1, xlen - 6, h->f) != xlen - 6) return fail(h, BD_ERR_IO, "truncated BGZF header");
+        for (uint32_t o = 0; o + 4 <= xlen;) {
+            const uint32_t sl = extra[o + 2] | (extra[o + 3] << 8);
+            if (extra[o] == 'B' && extra[o + 1] == 'C' && sl == 2 && o + 6 <= xlen) { bsize = (extra[o + 4] | (extra[o + 5] << 8)) + 1u; break; }
+            o += 4 + sl;
+        }
+        if (bsize < 12 + xlen + 8) return fail(h, BD_ERR_FORMAT, "BGZF block without a BC field");
+        const uint32_t clen = bsize - 12 - xlen;             /* deflate data + CRC32 + ISIZE */
+        if (raw_used + clen > h->raw_cap) {
+            const size_t nc = (raw_used + clen) * 2 + (1 << 20);
+            uint8_t* nr = (uint8_t*)realloc(h->raw, nc);
+            if (!nr) return fail(h, BD_ERR_MEM, "out of memory");
+            /* pointers into the old buffer */
+            for (int i = 0; i < nb; ++i) h->blocks[i].src = nr + (h->blocks[i].src - h->raw);
+            h->raw = nr; h->raw_cap = nc;
+        }
+        if (fread(h->raw + raw_used, 1, clen, h->f) != clen) return fail(h, BD_ERR_IO, "truncated BGZF block");
+        const uint8_t* tail = h->raw + raw_used + clen - 8;
+        bd_block* b = &h->blocks[nb++];
+        b->src = h->raw + raw_used; b->src_len = clen - 8;
+        b->crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
+        b->dst_len = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
+        b->dst = (uint8_t*)(uintptr_t)out_total;             /* offset for now */
+        if (b->dst_len > 65536) return fail(h, BD_ERR_FORMAT, "BGZF block larger than 64 KiB");
+        raw_used += clen; out_total += b->dst_len;
+    }
+    if (nb == 0) return BD_OK;
+    if (h->len + out_total > h->cap) {
+        const size_t nc = (h->len + out_total) * 2 + (1 << 20);
+        uint8_t* nbuf = (uint8_t*)realloc(h->buf, nc);
+        if (!nbuf) return fail(h, BD_ERR_MEM, "out of memory");
+        h->buf = nbuf; h->cap = nc;
+    }
+    for (int i = 0; i < nb; ++i) h->blocks[i].dst = h->buf + h->len + (size_t)(uintptr_t)h->blocks[i].dst;
+    int nt = h->n_threads < nb ? h->n_threads : nb;
+    if (nt < 1) nt = 1;
+    bd_job jobs[MAX_THREADS];
+    pthread_t th[MAX_THREADS];
+    for (int t = 0; t < nt; ++t) { jobs[t].blocks = h->blocks; jobs[t].n = nb; jobs[t].first = t; jobs[t].step = nt; jobs[t].rc = BD_OK; }
+    int started = 0;
+    for (int t = 1; t < nt; ++t) { if (pthread_create(&th[t], NULL, inflate_worker, &jobs[t]) != 0) break; started = t; }
+    if (started != nt - 1) {                                  /* could not start them all: the caller's thread does every block */
+        for (int t = 1; t <= started; ++t) pthread_join(th[t], NULL);
+        jobs[0].first = 0; jobs[0].step = 1;
+        inflate_worker(&jobs[0]);
+        if (jobs[0].rc != BD_OK) return fail(h, jobs[0].rc, "corrupt BGZF block");
+    } else {
+        inflate_worker(&jobs[0]);
+        for (int t = 1; t < nt; ++t) pthread_join(th[t], NULL);
+        for (int t = 0; t < nt; ++t) if (jobs[t].rc != BD_OK) return fail(h, jobs[t].rc, "corrupt BGZF block");
+    }
+    h->len += out_total;
+    return BD_OK;
+}
+
+/* make sure n unread bytes are there; 0 = yes, 1 = the stream ended before, < 0 = error */
+static int need(bd_handle* h, size_t n) {
+    while (h->len - h->pos < n) {
+        if (h->eof) return 1;
+        const int rc = refill(h);
+        if (rc != BD_OK) return rc;
+    }
+    return 0;
+}
+
+static int32_t rd_i32(const uint8_t* p) { return (int32_t)(p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24)); }
+
+/* ---- API ------------------------------------------------------------------------------------------------------- */
+int bd_abi_version(void) { return 1; }
+
+void bd_close(bd_handle* h) {
+    if (!h) return;
+    if (h->f) fclose(h->f);
+    free(h->raw); free(h->buf); free(h->text); free(h->last);
+    if (h->names) { for (int32_t i = 0; i < h->n_ref; ++i) free(h->names[i]); free(h->names); }
+    free(h->lens);
+    free(h);
+}
+
+const char* bd_last_error(const bd_handle* h) { return h ? h->err : "null handle"; }
+
+int bd_open(const char* path, int n_threads, bd_handle** out) {
+    if (!path || !out) return BD_ERR_ARG;
+    *out = NULL;
+    bd_handle* h = (bd_handle*)calloc(1, sizeof(bd_handle));
+    if (!h) return BD_ERR_MEM;
+    h->n_threads = n_threads < 1 ? 1 : (n_threads > MAX_THREADS ? MAX_THREADS : n_threads);
+    h->f = fopen(path, "rb");
+    if (!h->f) { free(h); return BD_ERR_IO; }
+    setvbuf(h->f, NULL, _IOFBF, 1 << 22);
+    int rc = need(h, 12);
+    if (rc != 0 || memcmp(h->buf + h->pos, "BAM\1", 4) != 0) { bd_close(h); return BD_ERR_FORMAT; }
+    h->l_text = rd_i32(h->buf + h->pos + 4);
+    if (h->l_text < 0 || need(h, 12 + (size_t)h->l_text) != 0) { bd_close(h); return BD_ERR_FORMAT; }
+    h->text = (char*)malloc((size_t)h->l_text + 1);
+    if (!h->text) { bd_close(h); return BD_ERR_MEM; }
+    memcpy(h->text, h->buf + h->pos + 8, (size_t)h->l_text); h->text[h->l_text] = 0;
+    h->n_ref = rd_i32(h->buf + h->pos + 8 + h->l_text);
+    h->pos += 12 + (size_t)h->l_text;
+    if (h->n_ref < 0) { bd_close(h); return BD_ERR_FORMAT; }
+    h->names = (char**)calloc((size_t)h->n_ref + 1, sizeof(char*));
+    h->lens = (int32_t*)calloc((size_t)h->n_ref + 1, sizeof(int32_t));
+    if (!h->names || !h->lens) { bd_close(h); return BD_ERR_MEM; }
+    for (int32_t i = 0; i < h->n_ref; ++i) {
+        if (need(h, 4) != 0) { bd_close(h); return BD_ERR_FORMAT; }
+        const int32_t ln = rd_i32(h->buf + h->pos);
+        if (ln < 1 || need(h, 8 + (size_t)ln) != 0) { bd_close(h); return BD_ERR_FORMAT; }
+        h->names[i] = (char*)malloc((size_t)ln);
+        if (!h->names[i]) { bd_close(h); return BD_ERR_MEM; }
+        memcpy(h->names[i], h->buf + h->pos + 4, (size_t)ln); h->names[i][ln - 1] = 0;
+        h->lens[i] = rd_i32(h->buf + h->pos + 4 + ln);
+        h->pos += 8 + (size_t)ln;
+    }
+    *out = h;
+    return BD_OK;
+}
+
+int32_t bd_n_references(const bd_handle* h) { return h ? h->n_ref : 0; }
+const char* bd_reference_name(const bd_handle* h, int32_t i) { return (h && i >= 0 && i < h->n_ref) ? h->names[i] : NULL; }
+int32_t bd_reference_length(const bd_handle* h, int32_t i) { return (h && i >= 0 && i < h->n_ref) ? h->lens[i] : 0; }
+const char* bd_header_text(const bd_handle* h) { return h ? h->text : NULL; }
+
+/* Up to max_records records.  Arrays of max_records elements each; *n_out = records written (0 = end of file).
+ * valid[i] = the record passes bam_utils.py:264-270; head[i] = it is valid and its (trimmed, if trim != 0) name differs from
+ * the previous valid record's -- across calls too. */
+int bd_read(bd_handle* h, size_t max_records, int trim, uint16_t* flag, int32_t* tid, int32_t* pos, int32_t* next_tid, int32_t* next_pos,
+            uint8_t* valid, uint8_t* head, size_t* n_out) {
+    if (!h || !flag || !tid || !pos || !next_tid || !next_pos || !valid || !head || !n_out) return BD_ERR_ARG;
+    size_t n = 0;
+    while (n < max_records) {
+        int rc = need(h, 4);
+        if (rc == 1) { if (h->len != h->pos) return fail(h, BD_ERR_FORMAT, "truncated BAM"); break; }
+        if (rc < 0) return rc;
+        const int32_t bs = rd_i32(h->buf + h->pos);
+        if (bs < 32) return fail(h, BD_ERR_FORMAT, "BAM record shorter than its fixed part");
+        rc = need(h, 4 + (size_t)bs);
+        if (rc != 0) return rc < 0 ? rc : fail(h, BD_ERR_FORMAT, "truncated BAM record");
+        const uint8_t* p = h->buf + h->pos + 4;
+        const int32_t ref = rd_i32(p), ps = rd_i32(p + 4);
+        const uint32_t l_name = p[8];
+        const uint16_t fl = (uint16_t)(p[14] | (p[15] << 8));
+        const int32_t nref = rd_i32(p + 20), npos = rd_i32(p + 24);
+        if (l_name < 1 || 32 + l_name > (uint32_t)bs) return fail(h, BD_ERR_FORMAT, "BAM record: name runs past the record");
+        flag[n] = fl; tid[n] = ref; pos[n] = ps; next_tid[n] = nref; next_pos[n] = npos;
+        int ok = !(fl & 0x4);
+        if (ok && (fl & 0x1)) ok = !((fl & 0x80) || !(fl & 0x2) || ref != nref || npos < 0);
+        uint8_t hd = 0;
+        if (ok) {
+            const uint8_t* name = p + 32;
+            int32_t len = (int32_t)l_name - 1;                     /* without the NUL */
+            if (trim) {
+                const uint8_t* sp = (const uint8_t*)memchr(name, ' ', (size_t)len);
+                if (sp && sp > name) len = (int32_t)(sp - name);
+            }
+            if (!h->has_last || len != h->last_len || memcmp(name, h->last, (size_t)len) != 0) {
+                hd = 1;
+                if ((size_t)len > h->last_cap) {
+                    uint8_t* nl = (uint8_t*)realloc(h->last, (size_t)len + 64);
+                    if (!nl) return fail(h, BD_ERR_MEM, "out of memory");
+                    h->last = nl; h->last_cap = (size_t)len + 64;
+                }
+                memcpy(h->last, name, (size_t)len); h->last_len = len; h->has_last = 1;
+            }
+        }
+        valid[n] = (uint8_t)ok; head[n] = hd;
+        h->pos += 4 + (size_t)bs;
+        ++n;
+    }
+    *n_out = n;
+    return BD_OK;
+}

@@ -124,3 +124,23 @@ class TupleEncoder(object):
         hapflag = (flag.astype(np.int64) & 0xFFF) | hostbits | (hap.astype(np.int64) << HAP_SHIFT)
         return dict(read_id=(rid & 0xFFFFFFFF).astype(np.uint32), locus=locus.astype(np.uint32),
                     hapflag=hapflag.astype(np.uint32), pos=np.asarray(pos, dtype=np.int32), n_valid=int(valid.sum()))
+
+    def encode_decoded(self, flag, tid, pos, next_tid, next_pos, valid, head):
+        """The same tuples from what ``bamdec.NativeBamReader.read_decoded`` returns: the filter verdict and the read heads come
+        from the decoder (which compares the names where they are, in the inflated BAM stream), the rest is array arithmetic."""
+        flag = np.asarray(flag)
+        tid = np.asarray(tid, dtype=np.int64)
+        valid = np.asarray(valid).astype(bool)
+        n = len(flag)
+        rid = np.cumsum(np.asarray(head, dtype=np.int64)) + (np.int64(self.cur) if self.cur != 0xFFFFFFFF else -1)
+        if n:
+            last = int(rid[-1])
+            self.cur = last if last >= 0 else 0xFFFFFFFF
+        safe_tid = np.where(valid, tid, 0)
+        locus = self.maps.tid2locus[safe_tid]
+        hap = self.maps.tid2hap[safe_tid]
+        hostbits = np.where(tid != np.asarray(next_tid, dtype=np.int64), FLAG_MATE_OTHER_REF, 0) | \
+            np.where(np.asarray(next_pos, dtype=np.int64) < 0, FLAG_NEXT_POS_NEG, 0)
+        hapflag = (flag.astype(np.int64) & 0xFFF) | hostbits | (hap.astype(np.int64) << HAP_SHIFT)
+        return dict(read_id=(rid & 0xFFFFFFFF).astype(np.uint32), locus=locus.astype(np.uint32),
+                    hapflag=hapflag.astype(np.uint32), pos=np.asarray(pos, dtype=np.int32).copy(), n_valid=int(valid.sum()))
