@@ -18,11 +18,8 @@
 #include <string.h>
 #include <zlib.h>
 
-#define BD_OK 0
-#define BD_ERR_IO -1
-#define BD_ERR_FORMAT -2
-#define BD_ERR_MEM -3
-#define BD_ERR_ARG -4
+#include "../../include/bamdec.h"
+
 
 #define BLOCKS_PER_FILL 512            /* up to 32 MB of inflated data per refill */
 #define MAX_THREADS 32

@@ -1,0 +1,45 @@
+/* bamdec.h -- C ABI of libbamdec.so (alntools_amd/csrc/bamdec.c): the host side's BAM decoder.
+ *
+ * Stands where the reference iterates a pysam.AlignmentFile in Python (alntools/bam_utils.py:253-320): it hands the tuple encoder
+ * column arrays instead of record objects.  Host only (plain C + zlib + pthreads); the device library libecb.so never touches
+ * files.  Bound with ctypes in alntools_amd/bamdec.py.  Every function returns 0 or a negative BD_ERR_* code.
+ */
+#ifndef ALNTOOLS_AMD_BAMDEC_H
+#define ALNTOOLS_AMD_BAMDEC_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BD_OK          0
+#define BD_ERR_IO     -1   /* cannot open / read the file */
+#define BD_ERR_FORMAT -2   /* not BGZF / not BAM / truncated / CRC mismatch */
+#define BD_ERR_MEM    -3
+#define BD_ERR_ARG    -4
+
+typedef struct bd_handle bd_handle;
+
+int bd_abi_version(void);
+/* Opens the file and reads the header (pysam.AlignmentFile(path), bam_utils.py:561); n_threads inflate BGZF blocks. */
+int bd_open(const char* path, int n_threads, bd_handle** out);
+void bd_close(bd_handle* h);
+const char* bd_last_error(const bd_handle* h);
+/* .references / .lengths / the header text (bam_utils.py:582, 615) */
+int32_t bd_n_references(const bd_handle* h);
+const char* bd_reference_name(const bd_handle* h, int32_t i);
+int32_t bd_reference_length(const bd_handle* h, int32_t i);
+const char* bd_header_text(const bd_handle* h);
+/* Up to max_records records in file order into caller-owned arrays of max_records elements; *n_out = 0 at the end of the file.
+ * flag, tid (refID), pos, next_tid, next_pos: the raw BAM fields (alignment.flag, reference_id, reference_start,
+ * next_reference_id, next_reference_start).  valid[i] = 1 if the record passes the reference's filter (bam_utils.py:264-270).
+ * head[i] = 1 if it is valid and its query name -- cut at its first space when trim != 0 and that space is not the first
+ * character (bam_utils.py:292-294) -- differs from the previous valid record's: the first alignment of a read
+ * (bam_utils.py:289-320).  The previous name is kept across calls. */
+int bd_read(bd_handle* h, size_t max_records, int trim, uint16_t* flag, int32_t* tid, int32_t* pos, int32_t* next_tid,
+            int32_t* next_pos, uint8_t* valid, uint8_t* head, size_t* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

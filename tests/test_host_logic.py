@@ -113,6 +113,15 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(lib, s), s
     assert lib.ecb_abi_version() == 2
+    # the host-side decoder library and its header
+    from alntools_amd import bamdec
+    bamdec.build()
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "bamdec.h")).read()
+    declared = set(re.findall(r"\b(bd_[a-z_]+)\s*\(", hdr))
+    assert declared == set(bamdec.SYMBOLS), declared ^ set(bamdec.SYMBOLS)
+    for s in declared:
+        assert hasattr(bamdec.lib(), s), s
+    assert bamdec.lib().bd_abi_version() == 1
 
 
 def test_plain_c_program_links_against_the_abi(tmp_path):
