@@ -24,31 +24,6 @@ def format_time(start, end):
     return "{:0>2}:{:0>2}:{:05.2f}".format(int(hours), int(minutes), seconds)
 
 
-def partition(lst, n):
-    """``n`` contiguous, near-equal parts, empty trailing parts dropped (``utils.py:67-87``)."""
-    q, r = divmod(len(lst), n)
-    cuts = [q * i + min(i, r) for i in range(n + 1)]
-    out = []
-    for i in range(n):
-        part = lst[cuts[i]:cuts[i + 1]]
-        if len(part) == 0:
-            break
-        out.append(part)
-    return out
-
-
-def list_to_int(lst):
-    c = 0
-    for i, on_off in enumerate(lst):
-        if on_off == 1:
-            c |= 1 << i
-    return c
-
-
-def int_to_list(c, size):
-    return [1 if (c & (1 << i)) != 0 else 0 for i in range(size)]
-
-
 def parse_targets(target_file):
     """First whitespace token of every line not starting with '#', in file order (``utils.py:161-178``)."""
     targets = OrderedDict()

@@ -181,6 +181,9 @@ def main():
     ap.add_argument("--e2e-slice-reads", type=int, default=100_000, help="reads of the config-2 slice converted from a real BAM file")
     args = ap.parse_args()
 
+    # (before anything can touch the GPU runtime: the host driver of this pool only supports dmabuf IPC, and the variable is read
+    #  when the runtime starts, not when the process group does)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     from alntools_amd import dist as ecdist

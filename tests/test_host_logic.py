@@ -79,18 +79,6 @@ def test_bin_writer_is_byte_exact(golden_dir):
         assert c.indptr.tolist() == ref["indptr"] and c.indices.tolist() == ref["indices"]
 
 
-def test_utils_truth_tables(golden_dir):
-    g = json.load(open(os.path.join(golden_dir, "g6_utils.json")))
-    for k, v in g["partition"].items():
-        n_items, n = map(int, k.split("/"))
-        assert utils.partition(list(range(n_items)), n) == v
-    for k, v in g["int_to_list"].items():
-        c, s = map(int, k.split("/"))
-        assert utils.int_to_list(c, s) == v
-    for k, v in g["list_to_int"].items():
-        assert utils.list_to_int(json.loads(k)) == v
-
-
 def test_synthetic_read_ids_follow_the_contract():
     for paired in (False, True):
         spec = synth.SynthSpec(3000, 200, 4, paired=paired)
