@@ -1176,7 +1176,9 @@ __global__ __launch_bounds__(1024) void k_build_work(const u32* starts, u32 n_bu
     }
     if (tid == 0) *n_work = min(s_carry, max_work);
 }
-__global__ __launch_bounds__(TPB_COUNT) void k_count_bins(const u32* pairs, const CountWork* work, const u32* n_work, u32 bb, Slot* table) {
+// sink (optional): what finalize's k_compact would otherwise find by scanning the whole table -- see the end of the kernel
+struct CompactSink { u32* list; u64 max_list; u64* n_list; u32* bitmap; u64 n_bits; uint2* list_fn; };
+__global__ __launch_bounds__(TPB_COUNT) void k_count_bins(const u32* pairs, const CountWork* work, const u32* n_work, u32 bb, Slot* table, CompactSink sink) {
     extern __shared__ u32 cnt[];                           // 2^bb counters
     const u32 N_BINS = 1u << bb;
     if (blockIdx.x >= *n_work) return;                     // (the grid is the list's upper bound: its length never visits the host)
@@ -1211,13 +1213,45 @@ __global__ __launch_bounds__(TPB_COUNT) void k_count_bins(const u32* pairs, cons
         }
     }
     __syncthreads();
+    // Every EC of a handle that has only seen its own reads has at least one read: the slots this workgroup adds a count to are
+    // exactly the occupied slots of its range, and the first to add to a slot (counts start at zero) puts it on the list of
+    // occupied slots, with its first read and key length, and marks that read in the first-appearance bitmap -- the slot's line
+    // is in hand here.  finalize then needs no pass over the table (1 GB at 2^24 slots) to find 3.7 M entries.
+    u32 mine = 0;
     for (u32 q = threadIdx.x; q < N_BINS; q += TPB_COUNT) {
         const u32 c = cnt[q];
+        u32 first = 0;
         if (c) {
             Slot* s = table + (((u64)b << bb) | q);
-            if (wk.shared) atomicAdd(&s->count, c);
-            else s->count += c;                             // the only writer of its slots
+            if (wk.shared) first = atomicAdd(&s->count, c) == 0u;
+            else { s->count += c; first = 1u; }             // the only writer of its slots
         }
+        if (sink.list) { cnt[q] = first; mine += first; }
+    }
+    if (!sink.list) return;
+    __shared__ u32 s_wtot[TPB_COUNT / 64];
+    __shared__ u64 s_base;
+    const u32 incl = wave_incl_scan(mine);
+    if (lane == 63) s_wtot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 run = 0;
+        for (int k = 0; k < TPB_COUNT / 64; ++k) { const u32 c = s_wtot[k]; s_wtot[k] = run; run += c; }
+        s_base = run ? atomicAdd(sink.n_list, (u64)run) : 0ull;
+    }
+    __syncthreads();
+    u64 at = s_base + s_wtot[threadIdx.x >> 6] + (incl - mine);
+    for (u32 q = threadIdx.x; q < N_BINS; q += TPB_COUNT) {
+        if (!cnt[q]) continue;
+        const u64 i = ((u64)b << bb) | q;
+        if (at < sink.max_list) {
+            const Slot* s = table + i;
+            sink.list[at] = (u32)i;
+            const u32 f = ~s->first_inv;
+            sink.list_fn[at] = make_uint2(f, s->n1 - 1u);
+            if (f < sink.n_bits) atomicOr(&sink.bitmap[f >> 5], 1u << (f & 31u));
+        }
+        ++at;
     }
 }
 
@@ -2200,6 +2234,7 @@ struct ecb_handle {
     bool counted = false;             // Slot::count / first_inv hold the reads pushed so far (k_count ran)
     u64* wave_arena = nullptr; u64 wave_arena_n = 0;   // see StreamArgs::wave_arena
     bool scatter_attr_set = false, count_attr_set = false;
+    bool list_from_counts = false;             // finalize: k_count_bins listed the occupied slots (no k_compact pass)
     u64 resident_blocks = 0, resident_blocks_rg = 0, rounds = 24, min_tiles = 32;     // k_stream's launch shape (queried once)
     bool ctr_synced = false;          // hctr is what the device holds (no kernel that counts has been queued since the last read-back)
     bool adopted = false;             // the table holds adopted entries in consecutive slots (no hashing): finalize / export only
@@ -2690,7 +2725,7 @@ int ensure_slot_ranks(ecb_handle* h, u64 E) {
 
 // reads per EC / first appearance, from read_slot[0, n_reads) (once, when the stream is closed).  Only queues kernels:
 // the totals and the work list of k_count_bins stay on the device.
-int ensure_counts(ecb_handle* h) {
+int ensure_counts(ecb_handle* h, const CompactSink* sink = nullptr) {
     if (h->counted) return ECB_OK;
     const u64 R = h->n_reads;
     if (R) {
@@ -2710,6 +2745,7 @@ int ensure_counts(ecb_handle* h) {
         POOL(h, P_PAIRS, pairs, R);
         POOL(h, P_TOTALS, d_tot, 8);
         k_part_hist<<<G, TPB_PART, nb * 4, h->stream>>>(h->read_slot, R, nb, bb, hist);
+        d_tot += 6;                                 // ([0..3] are finalize's, which may run this with its own totals already zeroed; [7] is excl_scan's)
         int rc = excl_scan_dev(h, hist, (u64)nb * G, offs, d_tot);
         if (rc != ECB_OK) return rc;
         if (nb <= STAGE_MAX_BUCKETS) {
@@ -2731,7 +2767,8 @@ int ensure_counts(ecb_handle* h) {
         POOL(h, P_WORK, d_work, (u64)max_work + 1);          // (+ 1: its length sits behind the list)
         u32* d_nwork = reinterpret_cast<u32*>(d_work + max_work);
         k_build_work<<<1, 1024, 0, h->stream>>>(d_starts, nb, piece, d_work, max_work, d_nwork);
-        k_count_bins<<<max_work, TPB_COUNT, 4u << bb, h->stream>>>(pairs, d_work, d_nwork, bb, h->table);
+        k_count_bins<<<max_work, TPB_COUNT, 4u << bb, h->stream>>>(pairs, d_work, d_nwork, bb, h->table, sink ? *sink : CompactSink{nullptr, 0, nullptr, nullptr, 0, nullptr});
+        if (sink) h->list_from_counts = true;
         HIPCHK(h, hipGetLastError());
     }
     h->counted = true;
@@ -2991,8 +3028,6 @@ int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
         }
         int rc = h->ctr_synced ? ECB_OK : sync_counters(h);
         if (rc != ECB_OK) return rc;
-        rc = ensure_counts(h);
-        if (rc != ECB_OK) return rc;
     }
     const u64 E = h->n_ecs();
     const u64 valid = h->hctr.valid + h->extra_valid;
@@ -3019,8 +3054,21 @@ int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
     u32* d_nbig = reinterpret_cast<u32*>(d_tot + 3);
     HIPCHK(h, hipMemsetAsync(bitmap, 0, words * 4, h->stream));
     HIPCHK(h, hipMemsetAsync(d_tot, 0, 8 * sizeof(u64), h->stream));
-    int rc = compact_table_dev(h, d_tot, bitmap, total_reads, list_fn);
-    if (rc != ECB_OK) return rc;
+    int rc = ECB_OK;
+    h->list_from_counts = false;
+    if (!h->finalized && !h->counted && h->n_reads) {  // the usual case: the counting pass lists the occupied slots as it goes
+        POOL(h, P_LIST, h->list, E);
+        const CompactSink sink{h->list, E, d_tot, bitmap, total_reads, list_fn};
+        rc = ensure_counts(h, &sink);
+        if (rc != ECB_OK) return rc;
+    } else if (!h->finalized) {
+        rc = ensure_counts(h);
+        if (rc != ECB_OK) return rc;
+    }
+    if (!h->list_from_counts) {                        // (counts were made earlier -- a table export, a merge -- or there were none to make)
+        rc = compact_table_dev(h, d_tot, bitmap, total_reads, list_fn);
+        if (rc != ECB_OK) return rc;
+    }
     k_popc<<<nblk(words, TPB), TPB, 0, h->stream>>>(bitmap, words, wpop);
     rc = excl_scan_dev(h, wpop, words, wprefix, d_tot + 1);
     if (rc != ECB_OK) return rc;
