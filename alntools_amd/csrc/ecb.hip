@@ -874,7 +874,8 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
                 // the founder such a ln waits for may be a ln of this very wave.  One round in all but a handful of tiles.
                 for (u32 round = 0;; ++round) {
                     if (st == ST_LOOK) {
-                        if (ABL(A, 4u)) st = ST_HIT;
+                        if (ABL(A, 64u)) { st = ST_HIT; fseen = 0xFFFFFFFFu; }   // (profiling: no table access at all, no first-read atomic)
+                        else if (ABL(A, 4u)) st = ST_HIT;
                         else st = table_lookup(A.table, A.cap_mask, lo, j, probes, cmp, ABL(A, 24u), &fseen);
                     }
                     if (round == 0u) {

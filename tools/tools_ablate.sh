@@ -1,7 +1,7 @@
 #!/bin/bash
 # (needs the profiling build: python -m alntools_amd.build --ablate  ->  alntools_amd/libecb_ablate.so)
 # profiling helper (GPU box): k_stream time with phases ablated (ECB_ABLATE bits: 1 stop after (a), 2 after (b), 4 no table,
-# 8 no key compare, 16 first 16 bytes of a slot only, 32 no key stores); "a:cap" sets ECB_EC_CAP_LOG2 too
+# 8 no key compare, 16 first 16 bytes of a slot only, 32 no key stores, 64 no table access); "a:cap" sets ECB_EC_CAP_LOG2 too
 W=${1:-c2}
 for x in ${2:-1 2 4 0}; do
   a=${x%%:*}; cap=${x#*:}; [ "$cap" = "$x" ] && cap=""
