@@ -8,8 +8,6 @@ space-trimmed query names of consecutive *valid* records (``bam_utils.py:289-320
 """
 from __future__ import annotations
 
-from collections import OrderedDict
-
 import numpy as np
 
 from .ecb import FLAG_MATE_OTHER_REF, FLAG_NEXT_POS_NEG, HAP_SHIFT
@@ -27,34 +25,37 @@ class HeaderMaps(object):
     """``tid -> (locus, haplotype)`` and the names/lengths the writers need (``bam_utils.py:561-633``)."""
 
     def __init__(self, references, lengths, target_ids=None):
-        main_targets = OrderedDict((t, i) for i, t in enumerate(target_ids or []))   # target file first (:571-579)
+        references = list(references)
+        parts = [split_reference_name(n) for n in references]
+        targets = [p[0] for p in parts]
+        haps = [p[1] for p in parts]
+        # target file first (:571-579), then header order of first appearance (:596-598); dicts keep insertion order
+        main_targets = dict.fromkeys(target_ids or [])
+        main_targets.update(dict.fromkeys(targets))
+        self.main_targets = list(main_targets.keys())
+        self.haplotypes = sorted(set(haps))                          # '' sorts first (:602)
+        t_idx = {t: i for i, t in enumerate(self.main_targets)}
+        h_idx = {h: i for i, h in enumerate(self.haplotypes)}
+        T, H = len(self.main_targets), len(self.haplotypes)
+        # The reference tests "gettid(target_hap) in key" per (EC, target, haplotype) (:754, :801-809); that equals "this tid is
+        # in the key" only when names and (target, haplotype) correspond one to one: the name rebuilt from its parts must be the
+        # name, and no name may appear twice.  (A name splits back into itself unless it ends in '_' behind a non-empty target.)
         first_tid = {}
         for tid, name in enumerate(references):
             first_tid.setdefault(name, tid)
-        parts = [split_reference_name(n) for n in references]
-        for target, _ in parts:                                      # then header order (:596-598)
-            if target not in main_targets:
-                main_targets[target] = len(main_targets)
-        self.haplotypes = sorted(set(h for _, h in parts))           # '' sorts first (:602)
-        hap_idx = {h: i for i, h in enumerate(self.haplotypes)}
-        self.main_targets = list(main_targets.keys())
-        T, H = len(self.main_targets), len(self.haplotypes)
+        if len(first_tid) != len(references) or any(len(h) == 0 and len(t) != len(n) for n, (t, h) in zip(references, parts)):
+            for tid, (target, hap) in enumerate(parts):
+                rebuilt = target if len(hap) == 0 else '{}_{}'.format(target, hap)
+                if first_tid.get(rebuilt, -1) != tid:
+                    raise ValueError("reference name %r does not round-trip through (target=%r, haplotype=%r): "
+                                     "such headers (duplicate names, or a trailing '_') are not supported" %
+                                     (references[tid], target, hap))
+        self.tid2locus = np.fromiter((t_idx[t] for t in targets), dtype=np.uint32, count=len(parts))
+        self.tid2hap = np.fromiter((h_idx[h] for h in haps), dtype=np.uint32, count=len(parts))
         self.lengths = np.zeros((T, H), dtype=np.int32)              # :605
-        self.tid2locus = np.zeros(len(references), dtype=np.uint32)
-        self.tid2hap = np.zeros(len(references), dtype=np.uint32)
+        self.lengths[self.tid2locus, self.tid2hap] = np.asarray(lengths, dtype=np.int32)   # :615-633
         self.slot2tid = np.full(T * H, -1, dtype=np.int64)           # gettid(target_hap), -1 if absent (:754, :809)
-        for tid, (target, hap) in enumerate(parts):
-            l, h = main_targets[target], hap_idx[hap]
-            self.lengths[l, h] = lengths[tid]                        # :615-633
-            self.tid2locus[tid], self.tid2hap[tid] = l, h
-            rebuilt = target if len(hap) == 0 else '{}_{}'.format(target, hap)   # :801-806
-            if first_tid.get(rebuilt, -1) != tid:
-                # The reference tests "gettid(target_hap) in key" per (EC, target, haplotype); that equals
-                # "this tid is in the key" only when names and (target, haplotype) correspond one to one.
-                raise ValueError("reference name %r does not round-trip through (target=%r, haplotype=%r): "
-                                 "such headers (duplicate names, or a trailing '_') are not supported" %
-                                 (references[tid], target, hap))
-            self.slot2tid[l * H + h] = tid
+        self.slot2tid[self.tid2locus.astype(np.int64) * H + self.tid2hap] = np.arange(len(parts), dtype=np.int64)
         if H > 31:
             raise ValueError("more than 31 haplotypes cannot be stored in the .bin bitmask (bin_utils.py:208-210)")
         self.n_loci, self.n_haplotypes = T, H
