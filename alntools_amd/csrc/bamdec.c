@@ -152,7 +152,7 @@ static int need(bd_handle* h, size_t n) {
     return 0;
 }
 
-static int32_t rd_i32(const uint8_t* p) { return (int32_t)(p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24)); }
+static inline int32_t rd_i32(const uint8_t* p) { int32_t v; memcpy(&v, p, 4); return v; }   /* (little-endian hosts only, like the rest of the repo) */
 
 /* ---- API ------------------------------------------------------------------------------------------------------- */
 int bd_abi_version(void) { return 1; }
@@ -217,13 +217,19 @@ int bd_read(bd_handle* h, size_t max_records, int trim, uint16_t* flag, int32_t*
     if (!h || !flag || !tid || !pos || !next_tid || !next_pos || !valid || !head || !n_out) return BD_ERR_ARG;
     size_t n = 0;
     while (n < max_records) {
-        int rc = need(h, 4);
-        if (rc == 1) { if (h->len != h->pos) return fail(h, BD_ERR_FORMAT, "truncated BAM"); break; }
-        if (rc < 0) return rc;
-        const int32_t bs = rd_i32(h->buf + h->pos);
+        /* fast path: the whole record is in the buffer (all but one record per 32 MB refill) */
+        size_t avail = h->len - h->pos;
+        int32_t bs = avail >= 4 ? rd_i32(h->buf + h->pos) : 0;
+        if (avail < 4 || avail < 4 + (size_t)(bs < 0 ? 0 : bs)) {
+            int rc = need(h, 4);
+            if (rc == 1) { if (h->len != h->pos) return fail(h, BD_ERR_FORMAT, "truncated BAM"); break; }
+            if (rc < 0) return rc;
+            bs = rd_i32(h->buf + h->pos);
+            if (bs < 32) return fail(h, BD_ERR_FORMAT, "BAM record shorter than its fixed part");
+            rc = need(h, 4 + (size_t)bs);
+            if (rc != 0) return rc < 0 ? rc : fail(h, BD_ERR_FORMAT, "truncated BAM record");
+        }
         if (bs < 32) return fail(h, BD_ERR_FORMAT, "BAM record shorter than its fixed part");
-        rc = need(h, 4 + (size_t)bs);
-        if (rc != 0) return rc < 0 ? rc : fail(h, BD_ERR_FORMAT, "truncated BAM record");
         const uint8_t* p = h->buf + h->pos + 4;
         const int32_t ref = rd_i32(p), ps = rd_i32(p + 4);
         const uint32_t l_name = p[8];
