@@ -2000,6 +2000,13 @@ __global__ void k_split_minmax(const int2* rng, u64 n, int* mn, int* mx) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i < n) { const int2 r = rng[i]; mn[i] = r.x; mx[i] = r.y; }
 }
+__global__ void k_clear_slots(Slot* table, const u32* list, u64 n) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint4* s = reinterpret_cast<uint4*>(table + list[i]);
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    s[0] = z; s[1] = z; s[2] = z; s[3] = z;
+}
 __global__ void k_fill_i32(int* p, u64 n, int v) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -2914,6 +2921,8 @@ int ecb_verify_device(ecb_handle* h, const void* d_read_id, const void* d_locus,
 int ecb_reset(ecb_handle* h) {
     if (!h) return ECB_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
+    const u32* occupied = h->finalized ? h->list : nullptr;     // (a finalized handle knows its occupied slots: every one of them, checked)
+    const u64 n_occupied = h->n_list;
     free_results(h);
     // The used stretches of the key arena go back to zero: a key pair is only ever compared against bytes that are either
     // zero (no haplotype mask: never equal to a pair) or final, whatever a cache still holds of them.
@@ -2930,7 +2939,13 @@ int ecb_reset(ecb_handle* h) {
 #if defined(ECB_TIMING) || defined(ECB_EXPERIMENTS)     // experiment builds only (tools/exp_hits.py: a pass over a table that holds every EC already)
     if (!getenv("ECB_KEEP_TABLE"))
 #endif
-    HIPCHK(h, hipMemsetAsync(h->table, 0, h->cap * sizeof(Slot), h->stream));
+    {
+        // a sparsely filled table is cleared slot by slot from that list (config 3: 3.7 M of 16.8 M slots, 0.24 of 1 GB)
+        if (occupied && n_occupied && n_occupied == h->n_ecs() && !h->hctr.err && n_occupied * 3 < h->cap)
+            k_clear_slots<<<nblk(n_occupied, TPB), TPB, 0, h->stream>>>(h->table, occupied, n_occupied);
+        else
+            HIPCHK(h, hipMemsetAsync(h->table, 0, h->cap * sizeof(Slot), h->stream));
+    }
     { int rc_ = clear_counters(h); if (rc_ != ECB_OK) return rc_; }
     if (h->wave_arena) HIPCHK(h, hipMemsetAsync(h->wave_arena, 0, 2 * h->wave_arena_n * sizeof(u64), h->stream));
     if (h->read_slot && h->reads_hi) HIPCHK(h, hipMemsetAsync(h->read_slot, 0xFF, h->reads_hi * sizeof(u32), h->stream));
