@@ -23,9 +23,10 @@ LOG = utils.get_logger()
 BATCH_RECORDS = 1 << 20
 
 
-def open_bam(filename, names=True):
+def open_bam(filename, names=True, ms=False):
     """``names=False`` (the single-sample path, which only needs to know where the read names CHANGE): the native decoder
-    ``bamdec.NativeBamReader`` if ``libbamdec.so`` is built and ``ALNTOOLS_DECODER`` is not ``py``.  Otherwise pysam when
+    ``bamdec.NativeBamReader`` if ``libbamdec.so`` is built and ``ALNTOOLS_DECODER`` is not ``py`` (``ms``: for the multisample
+    scan, which takes the cell barcodes out of the names in C as well).  Otherwise pysam when
     installed (the reference's decoder), else the built-in pure-Python reader; those yield
     ``(qname, flag, tid, pos, next_tid, next_pos)``.  All expose ``.references`` / ``.lengths``."""
     if not names and os.environ.get("ALNTOOLS_DECODER", "c") != "py":

@@ -41,6 +41,18 @@ def scan_file(reader, maps):
     run_cells = []
     tracked, run = None, -1
     n_all = n_valid = 0
+    while hasattr(reader, "read_ms"):                                  # native decoder: the same rule, applied where the names are
+        d, cells = reader.read_ms(BATCH_RECORDS)
+        if d is None:
+            c = {k: (np.concatenate(v) if v else np.zeros(0, dtype=np.int64)) for k, v in cols.items()}
+            return c, c["run"] < run, run_cells[:max(run, 0)], dict(all=n_all, valid=n_valid)
+        runs = run + np.cumsum(d["newrun"], dtype=np.int64)
+        run = int(runs[-1])
+        run_cells.extend(cells)
+        n_all += len(runs)
+        n_valid += int(d["valid"].sum())
+        for k, v in (("flag", d["flag"]), ("tid", d["tid"]), ("pos", d["pos"]), ("ntid", d["next_tid"]), ("npos", d["next_pos"]), ("run", runs)):
+            cols[k].append(np.array(v))
     while True:
         q, flag, tid, pos, ntid, npos = reader.read_batch(BATCH_RECORDS)
         if not q:
@@ -109,7 +121,7 @@ def convert_files(bam_files, ec_filename, emase_filename, minimum_count=-1, rang
     with EcBuilder(maps.n_loci, maps.n_haplotypes, device=device, track_ranges=track, multisample=True) as b:
         read_base = 0
         for fi, path in enumerate(bam_files):
-            rd = open_bam(path)
+            rd = open_bam(path, names=False, ms=True)
             c, keep, cells, ctr = scan_file(rd, maps)
             rd.close()
             n_all += ctr["all"]

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbamdec.so")
 SRC = os.path.join(_HERE, "csrc", "bamdec.c")
 SYMBOLS = ("bd_abi_version", "bd_open", "bd_close", "bd_last_error", "bd_n_references", "bd_reference_name",
-           "bd_reference_length", "bd_header_text", "bd_read")
+           "bd_reference_length", "bd_header_text", "bd_read", "bd_read_ms", "bd_ms_cells")
 _lib = None
 
 
@@ -52,6 +52,8 @@ def lib():
         l.bd_header_text.argtypes = [C.c_void_p]
         l.bd_header_text.restype = C.c_char_p
         l.bd_read.argtypes = [C.c_void_p, C.c_size_t, C.c_int] + [C.c_void_p] * 7 + [C.POINTER(C.c_size_t)]
+        l.bd_read_ms.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 7 + [C.POINTER(C.c_size_t)]
+        l.bd_ms_cells.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_size_t)]
         _lib = l
     return _lib
 
@@ -96,6 +98,30 @@ class NativeBamReader(object):
             return None
         return dict(flag=self._flag[:k], tid=self._i32[0][:k], pos=self._i32[1][:k], next_tid=self._i32[2][:k],
                     next_pos=self._i32[3][:k], valid=self._u8[0][:k], head=self._u8[1][:k])
+
+    def read_ms(self, max_records):
+        """The multisample path's scan (``bam_utils_multisample.py:257-300``): as ``read_decoded`` with ``newrun`` (that path's run
+        rule: the tracked name is cut at its first space only until the first switch) instead of ``head``, plus the cell
+        barcodes (field 14 of the tracked name split at ``'|||'``) of the runs started, as a list of ``str``."""
+        self._arrays(max_records)
+        n = C.c_size_t(0)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        rc = self._l.bd_read_ms(self._h, max_records, p(self._flag), p(self._i32[0]), p(self._i32[1]), p(self._i32[2]),
+                                p(self._i32[3]), p(self._u8[0]), p(self._u8[1]), C.byref(n))
+        if rc != 0:
+            raise ValueError("BAM decode failed: %s" % self._l.bd_last_error(self._h).decode())
+        k = n.value
+        if k == 0:
+            return None, []
+        bytes_p, off_p, nc = C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint32)(), C.c_size_t(0)
+        self._l.bd_ms_cells(self._h, C.byref(bytes_p), C.byref(off_p), C.byref(nc))
+        cells = []
+        if nc.value:
+            off = np.ctypeslib.as_array(off_p, shape=(nc.value + 1,))
+            raw = bytes(np.ctypeslib.as_array(bytes_p, shape=(int(off[-1]),))) if off[-1] else b""
+            cells = [raw[off[i]:off[i + 1]].decode("utf-8") for i in range(nc.value)]
+        return dict(flag=self._flag[:k], tid=self._i32[0][:k], pos=self._i32[1][:k], next_tid=self._i32[2][:k],
+                    next_pos=self._i32[3][:k], valid=self._u8[0][:k], newrun=self._u8[1][:k]), cells
 
     def close(self):
         if self._h:

@@ -41,6 +41,8 @@ typedef struct bd_handle {
     char* text; int32_t l_text; int32_t n_ref; char** names; int32_t* lens;
     /* the (trimmed) name of the latest record that passed the filter */
     uint8_t* last; size_t last_cap; int32_t last_len; int has_last;
+    /* multisample (bd_read_ms): the cell ids of the runs the last call started, back to back, and where each begins */
+    uint8_t* cells; size_t cells_cap, cells_len; uint32_t* cell_off; size_t cell_off_cap, n_cells;
     char err[256];
 } bd_handle;
 
@@ -160,7 +162,7 @@ int bd_abi_version(void) { return 1; }
 void bd_close(bd_handle* h) {
     if (!h) return;
     if (h->f) fclose(h->f);
-    free(h->raw); free(h->buf); free(h->text); free(h->last);
+    free(h->raw); free(h->buf); free(h->text); free(h->last); free(h->cells); free(h->cell_off);
     if (h->names) { for (int32_t i = 0; i < h->n_ref; ++i) free(h->names[i]); free(h->names); }
     free(h->lens);
     free(h);
@@ -262,5 +264,102 @@ int bd_read(bd_handle* h, size_t max_records, int trim, uint16_t* flag, int32_t*
         ++n;
     }
     *n_out = n;
+    return BD_OK;
+}
+
+/* ---- multisample scan (alntools/bam_utils_multisample.py:257-300) -------------------------------------------------- */
+/* field 14 of the name split at every "|||" (the cell barcode, :270-280); -1 if there are fewer than 15 fields */
+static int32_t cell_field(const uint8_t* s, int32_t n, int32_t* start) {
+    int32_t pos = 0, field = 0, f0 = 0;
+    while (field < 14) {
+        int32_t k = pos;
+        for (; k + 3 <= n; ++k) if (s[k] == '|' && s[k + 1] == '|' && s[k + 2] == '|') break;
+        if (k + 3 > n) return -1;
+        pos = k + 3; ++field; f0 = pos;
+    }
+    int32_t k = pos;
+    for (; k + 3 <= n; ++k) if (s[k] == '|' && s[k + 1] == '|' && s[k + 2] == '|') break;
+    *start = f0;
+    return (k + 3 <= n ? k : n) - f0;
+}
+
+/* As bd_read, with the multisample path's run rule instead of `head`: newrun[i] = 1 if the record is valid and starts a run.
+ * The tracked name starts as the first valid record's name cut at its first space (if that is not its first character); a
+ * record whose name -- cut the same way -- differs from the tracked name starts a new run, and the tracked name becomes its
+ * WHOLE name (:288-292: from then on a name with a space in it never equals what follows it).  The cell id of every run
+ * started is field 14 of the tracked name split at "|||"; bd_ms_cells returns them.  BD_ERR_FORMAT if a run's name has no such
+ * field (the reference raises there). */
+int bd_read_ms(bd_handle* h, size_t max_records, uint16_t* flag, int32_t* tid, int32_t* pos, int32_t* next_tid, int32_t* next_pos,
+               uint8_t* valid, uint8_t* newrun, size_t* n_out) {
+    if (!h || !flag || !tid || !pos || !next_tid || !next_pos || !valid || !newrun || !n_out) return BD_ERR_ARG;
+    size_t n = 0;
+    h->cells_len = 0; h->n_cells = 0;
+    while (n < max_records) {
+        int rc = need(h, 4);
+        if (rc == 1) { if (h->len != h->pos) return fail(h, BD_ERR_FORMAT, "truncated BAM"); break; }
+        if (rc < 0) return rc;
+        const int32_t bs = rd_i32(h->buf + h->pos);
+        if (bs < 32) return fail(h, BD_ERR_FORMAT, "BAM record shorter than its fixed part");
+        rc = need(h, 4 + (size_t)bs);
+        if (rc != 0) return rc < 0 ? rc : fail(h, BD_ERR_FORMAT, "truncated BAM record");
+        const uint8_t* p = h->buf + h->pos + 4;
+        const int32_t ref = rd_i32(p), ps = rd_i32(p + 4);
+        const uint32_t l_name = p[8];
+        const uint16_t fl = (uint16_t)(p[14] | (p[15] << 8));
+        const int32_t nref = rd_i32(p + 20), npos = rd_i32(p + 24);
+        if (l_name < 1 || 32 + l_name > (uint32_t)bs) return fail(h, BD_ERR_FORMAT, "BAM record: name runs past the record");
+        flag[n] = fl; tid[n] = ref; pos[n] = ps; next_tid[n] = nref; next_pos[n] = npos;
+        int ok = !(fl & 0x4);
+        if (ok && (fl & 0x1)) ok = !((fl & 0x80) || !(fl & 0x2) || ref != nref || npos < 0);
+        uint8_t nr = 0;
+        if (ok) {
+            const uint8_t* name = p + 32;
+            const int32_t full = (int32_t)l_name - 1;
+            int32_t cut = full;
+            const uint8_t* sp = (const uint8_t*)memchr(name, ' ', (size_t)full);
+            if (sp && sp > name) cut = (int32_t)(sp - name);
+            int32_t keep = -1;                                         /* length of the name to track from here on, if it changes */
+            if (!h->has_last) { keep = cut; nr = 1; }                  /* :257-262: the first tracked name is the cut one */
+            else if (cut != h->last_len || memcmp(name, h->last, (size_t)cut) != 0) { keep = full; nr = 1; }   /* :288-292: ... later ones are not */
+            if (nr) {
+                if ((size_t)keep > h->last_cap) {
+                    uint8_t* nl = (uint8_t*)realloc(h->last, (size_t)keep + 64);
+                    if (!nl) return fail(h, BD_ERR_MEM, "out of memory");
+                    h->last = nl; h->last_cap = (size_t)keep + 64;
+                }
+                memcpy(h->last, name, (size_t)keep); h->last_len = keep; h->has_last = 1;
+                int32_t c0 = 0;
+                const int32_t cl = cell_field(h->last, h->last_len, &c0);
+                if (cl < 0) return fail(h, BD_ERR_FORMAT, "a read name has no cell id in '|||' field 14 (bam_utils_multisample.py:270-280)");
+                if (h->cells_len + (size_t)cl > h->cells_cap) {
+                    const size_t nc = (h->cells_len + (size_t)cl) * 2 + 4096;
+                    uint8_t* nb = (uint8_t*)realloc(h->cells, nc);
+                    if (!nb) return fail(h, BD_ERR_MEM, "out of memory");
+                    h->cells = nb; h->cells_cap = nc;
+                }
+                if (h->n_cells + 2 > h->cell_off_cap) {
+                    const size_t nc = (h->n_cells + 2) * 2 + 1024;
+                    uint32_t* no = (uint32_t*)realloc(h->cell_off, nc * sizeof(uint32_t));
+                    if (!no) return fail(h, BD_ERR_MEM, "out of memory");
+                    h->cell_off = no; h->cell_off_cap = nc;
+                }
+                h->cell_off[h->n_cells++] = (uint32_t)h->cells_len;
+                memcpy(h->cells + h->cells_len, h->last + c0, (size_t)cl);
+                h->cells_len += (size_t)cl;
+                h->cell_off[h->n_cells] = (uint32_t)h->cells_len;
+            }
+        }
+        valid[n] = (uint8_t)ok; newrun[n] = nr;
+        h->pos += 4 + (size_t)bs;
+        ++n;
+    }
+    *n_out = n;
+    return BD_OK;
+}
+
+/* the cell ids of the runs the last bd_read_ms started: n of them, cell k = bytes [off[k], off[k + 1]) of *bytes (valid until the next call) */
+int bd_ms_cells(const bd_handle* h, const uint8_t** bytes, const uint32_t** off, size_t* n) {
+    if (!h || !bytes || !off || !n) return BD_ERR_ARG;
+    *bytes = h->cells; *off = h->cell_off; *n = h->n_cells;
     return BD_OK;
 }

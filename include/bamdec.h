@@ -39,6 +39,14 @@ const char* bd_header_text(const bd_handle* h);
 int bd_read(bd_handle* h, size_t max_records, int trim, uint16_t* flag, int32_t* tid, int32_t* pos, int32_t* next_tid,
             int32_t* next_pos, uint8_t* valid, uint8_t* head, size_t* n_out);
 
+/* The multisample path's scan (alntools/bam_utils_multisample.py:257-300): as bd_read, but newrun[i] follows that path's run rule
+ * -- the tracked name starts cut at its first space and becomes the WHOLE name of every record that starts a later run (:288-292)
+ * -- and the cell barcode of every run started (field 14 of the tracked name split at "|||", :270-280) is kept for bd_ms_cells:
+ * n cells, cell k = bytes [off[k], off[k + 1]), valid until the next call.  Do not mix with bd_read on one handle. */
+int bd_read_ms(bd_handle* h, size_t max_records, uint16_t* flag, int32_t* tid, int32_t* pos, int32_t* next_tid, int32_t* next_pos,
+               uint8_t* valid, uint8_t* newrun, size_t* n_out);
+int bd_ms_cells(const bd_handle* h, const uint8_t** bytes, const uint32_t** off, size_t* n);
+
 #ifdef __cplusplus
 }
 #endif

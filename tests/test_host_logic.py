@@ -267,3 +267,42 @@ def test_native_bam_decoder_yields_the_tuples_of_the_python_reader(golden_dir, t
         assert sum(t["n_valid"] for t in want) == sum(t["n_valid"] for t in got)
     with pytest.raises((IOError, ValueError)):
         bamdec.NativeBamReader(os.path.join(golden_dir, "g1_edge.json"))
+
+
+def test_native_multisample_scan_matches_the_python_scan(golden_dir, tmp_path):
+    """csrc/bamdec.c:bd_read_ms (the multisample run rule -- tracked name cut at its first space only until the first switch,
+    bam_utils_multisample.py:257-300 -- and the cell barcodes, field 14 of the tracked name) against the Python restatement in
+    bam_utils_multisample.scan_file on the reference's multisample fixture (which has names with spaces) and on names built to
+    hit the quirk in both states: same runs per record, same cells, same counters."""
+    from alntools_amd import bamdec, bamio, bam_utils, bam_utils_multisample as bum
+    bamdec.build()
+    g = json.load(open(os.path.join(golden_dir, "g4_multi.json")))
+    refs = [tuple(r) for r in g["references"]]
+    files = {k: [tuple(r) for r in v] for k, v in g["files"].items()}
+    cell = lambda c: "|||".join(["x"] * 14 + [c, "tail"])
+    quirk = [(cell("C1") + " a", 0, 0, 10, -1, -1), (cell("C1") + " b", 0, 1, 11, -1, -1),      # first run: tracked is the cut name
+             (cell("C2") + " a", 0, 0, 12, -1, -1), (cell("C2") + " a", 0, 1, 13, -1, -1),      # after a switch: tracked is the whole name
+             (cell("C2"), 4, 0, 14, -1, -1), (cell("C3"), 0, 2, 15, -1, -1), (cell("C3"), 0, 1, 16, -1, -1),
+             (" " + cell("C4"), 0, 0, 17, -1, -1), (" " + cell("C4"), 0, 1, 18, -1, -1), (cell("C5"), 0, 0, 19, -1, -1)]
+    files["quirk.bam"] = quirk
+    for name, recs in files.items():
+        bam = str(tmp_path / name)
+        bamio.write_bam(bam, refs, recs)
+        for batch in (3, 100000):
+            old = bam_utils.BATCH_RECORDS, bum.BATCH_RECORDS
+            bam_utils.BATCH_RECORDS = bum.BATCH_RECORDS = batch
+            try:
+                py = bamio.BamReader(bam)
+                want = bum.scan_file(py, None)
+                py.close()
+                nat = bamdec.NativeBamReader(bam, threads=2)
+                got = bum.scan_file(nat, None)
+                nat.close()
+            finally:
+                bam_utils.BATCH_RECORDS, bum.BATCH_RECORDS = old
+            for k in ("flag", "tid", "pos", "ntid", "npos", "run"):
+                assert np.array_equal(np.asarray(want[0][k], dtype=np.int64), np.asarray(got[0][k], dtype=np.int64)), (name, batch, k)
+            assert np.array_equal(want[1], got[1]) and want[2] == got[2] and want[3] == got[3], (name, batch)
+    bamio.write_bam(str(tmp_path / "nocell.bam"), refs, [("plain_name", 0, 0, 1, -1, -1)])
+    with pytest.raises(ValueError):
+        bum.scan_file(bamdec.NativeBamReader(str(tmp_path / "nocell.bam")), None)
