@@ -1295,13 +1295,22 @@ struct SlowArgs {
 
 __device__ __forceinline__ u64 slow_probe_start(u32 lc, u64 cap2) { return __umul64hi((u64)(lc * 0x9E3779B1u) << 32, cap2); }
 
+// The read's {locus -> mask} table (2 slots per record) sits in LDS when it fits SLOW_LDS slots (reads of up to 2 048 records:
+// all but the pathological ones), in the global scratch otherwise: its compare-and-swaps are what a long read costs.
+constexpr u32 SLOW_LDS = 4096;
 __global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
+    extern __shared__ u32 sh_scr[];                // SLOW_LDS keys, SLOW_LDS masks
     const u64 q = blockIdx.x;
     const u32 tid = threadIdx.x, lane = tid & 63u;
     const u64 h = A.queue[q], L = A.len[q];
     const u64 cap2 = 2 * L;
-    u32* key = A.scr_key + A.scr_off[q];
-    u32* msk = A.scr_mask + A.scr_off[q];
+    const bool in_lds = cap2 <= (u64)SLOW_LDS;
+    u32* key = in_lds ? sh_scr : A.scr_key + A.scr_off[q];
+    u32* msk = in_lds ? sh_scr + SLOW_LDS : A.scr_mask + A.scr_off[q];
+    if (in_lds) {
+        for (u32 p = tid; p < (u32)cap2; p += TPB) { key[p] = 0; msk[p] = 0; }
+        __syncthreads();
+    }
     __shared__ u64 s_acc[TPB / 64];
     __shared__ u32 s_n[TPB / 64];
     __shared__ u64 s_lo, s_j;
@@ -1447,7 +1456,7 @@ __global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
         }
     }
     __syncthreads();
-    for (u64 p = tid; p < cap2; p += TPB) {                 // leave the scratch zeroed for the next round
+    if (!in_lds) for (u64 p = tid; p < cap2; p += TPB) {    // leave the global scratch zeroed for the next round
         if (__hip_atomic_load(&key[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { key[p] = 0; msk[p] = 0; }
     }
 }
@@ -2427,7 +2436,7 @@ int run_slow(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf,
         HIPCHK(h, hipMemcpyAsync(d_off, off.data(), nq * sizeof(u64), hipMemcpyHostToDevice, h->stream));
         SlowArgs a{d_rid, d_loc, d_hf, d_q, d_len, d_off, sk, sm, h->cfg.n_loci, h->cfg.n_haplotypes,
                    h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr, h->read_slot, h->reads_hi, nre_buf, d_nre, verify ? 1u : 0u};
-        k_slow<<<(unsigned)nq, TPB, 0, h->stream>>>(a);
+        k_slow<<<(unsigned)nq, TPB, 2 * SLOW_LDS * sizeof(u32), h->stream>>>(a);
         u64 nre = 0;
         HIPCHK(h, hipMemcpyAsync(&nre, d_nre, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
         rc = sync_counters(h);                          // (waits: `off` lives on this stack frame)
