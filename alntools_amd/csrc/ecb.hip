@@ -358,6 +358,19 @@ __device__ __forceinline__ u32 group_mask(int lo, int hi) {
 
 struct TileRegs { u32 rr[RPL], ll[RPL], hh[RPL]; };
 
+// Where a key goes when its first slot (home region + low locus bits) is taken by another key: a second start anywhere in the
+// table, then steps of a key-dependent stride that is coprime to the table size -- double hashing.  (Walking on slot by slot
+// from the first probe made a tile with one read of several hundred distinct loci quadratic: its entries filled its
+// neighbours' regions in one long run.)  it = probes made so far beyond the first.
+__device__ __forceinline__ u32 next_slot(u32 key, u32 q, u32 it) {
+    if (it == 0u) return __umulhi(key * 0x9E3779B1u, (u32)TSLOTS);
+    constexpr u32 ODD_FACTOR = TSLOTS == 640 ? 5u : 7u;            // 640 = 2^7 x 5, 896 = 2^7 x 7
+    u32 s = 1u + 2u * ((key >> 5) & 31u);
+    if (s % ODD_FACTOR == 0u) s += 2u;
+    q += s;
+    return q >= (u32)TSLOTS ? q - (u32)TSLOTS : q;
+}
+
 // "is the key of this slot the target set of my read?" -- the read's set is what the pass's LDS table holds under its tag,
 // probed from home + (key & pm) exactly as phase (b) inserted it.  Both sides hold distinct loci, so equal sizes and every
 // stored pair found with the same mask means the sets are equal.
@@ -404,7 +417,7 @@ struct LdsSetCmp {
                 const uint2 t = tab_get(*L, q);
                 if (t.x == key) { found = t.y == pr.y; break; }
                 if (t.x == 0u) break;
-                if (++q == (u32)TSLOTS) q = 0;
+                q = next_slot(key, q, it);
             }
             if (!found) return CMP_DIFFERENT;
         }
@@ -778,8 +791,8 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
                                 u32 o, it = 0;                       // (the table always has a free slot: the bound only keeps corrupted
                                 for (;;) {                           //  state from spinning a wave for ever)
                                     o = atomicCAS(tab_key(L, qq), 0u, key);
-                                    if (o == 0u || o == key || ++it >= (u32)TSLOTS) break;
-                                    if (++qq >= (u32)TSLOTS) qq = 0;
+                                    if (o == 0u || o == key || it >= (u32)TSLOTS) break;
+                                    qq = next_slot(key, qq, it); ++it;
                                 }
                                 if (o != 0u && o != key) bad |= ERR_INTERNAL;
                                 else { made = (o == 0u); atomicOr(tab_mask(L, qq), bit); }
@@ -799,8 +812,8 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
                             u32 o, it = 0;
                             for (;;) {
                                 o = atomicCAS(tab_key(L, qq), 0u, cv.x);
-                                if (o == 0u || o == cv.x || ++it >= (u32)TSLOTS) break;
-                                if (++qq >= (u32)TSLOTS) qq = 0;
+                                if (o == 0u || o == cv.x || it >= (u32)TSLOTS) break;
+                                qq = next_slot(cv.x, qq, it); ++it;
                             }
                             if (o != 0u && o != cv.x) bad |= ERR_INTERNAL;
                             else { made = (o == 0u); atomicOr(tab_mask(L, qq), cv.y); }
