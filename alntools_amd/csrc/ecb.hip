@@ -1261,9 +1261,11 @@ __global__ __launch_bounds__(TPB_COUNT) void k_count_bins(const u32* pairs, cons
         if (at < sink.max_list) {
             const Slot* s = table + i;
             sink.list[at] = (u32)i;
-            const u32 f = ~s->first_inv;
-            sink.list_fn[at] = make_uint2(f, s->n1 - 1u);
-            if (f < sink.n_bits) atomicOr(&sink.bitmap[f >> 5], 1u << (f & 31u));
+            if (sink.list_fn) {
+                const u32 f = ~s->first_inv;
+                sink.list_fn[at] = make_uint2(f, s->n1 - 1u);
+                if (f < sink.n_bits) atomicOr(&sink.bitmap[f >> 5], 1u << (f & 31u));
+            }
         }
         ++at;
     }
@@ -2265,6 +2267,8 @@ struct ecb_handle {
     u64* wave_arena = nullptr; u64 wave_arena_n = 0;   // see StreamArgs::wave_arena
     bool scatter_attr_set = false, count_attr_set = false;
     bool list_from_counts = false;             // finalize: k_count_bins listed the occupied slots (no k_compact pass)
+    bool list_counted = false;                 // ... and so it did for a table export (the list alone; its length at *d_list_n)
+    u64* d_list_n = nullptr;
     u64 resident_blocks = 0, resident_blocks_rg = 0, rounds = 24, min_tiles = 32;     // k_stream's launch shape (queried once)
     bool ctr_synced = false;          // hctr is what the device holds (no kernel that counts has been queued since the last read-back)
     bool adopted = false;             // the table holds adopted entries in consecutive slots (no hashing): finalize / export only
@@ -2403,7 +2407,7 @@ int grow_table(ecb_handle* h, u64 new_cap) {
     }
     if (e != hipSuccess) { hipFree(nt); return fail(h, ECB_ERR_HIP, "grow_table: %s", hipGetErrorString(e)); }
     HIPCHK(h, hipFree(h->table));
-    h->table = nt; h->cap = new_cap;
+    h->table = nt; h->cap = new_cap; h->list_counted = false;     // (slot ids changed)
     return ECB_OK;
 }
 
@@ -2758,6 +2762,15 @@ int ensure_slot_ranks(ecb_handle* h, u64 E) {
 int ensure_counts(ecb_handle* h, const CompactSink* sink = nullptr) {
     if (h->counted) return ECB_OK;
     const u64 R = h->n_reads;
+    CompactSink own{nullptr, 0, nullptr, nullptr, 0, nullptr};
+    if (R && !sink && !h->adopted && h->n_ecs()) {         // (a table export follows: it wants the list of occupied slots, see k_count_bins)
+        u64* d_n = nullptr;
+        POOL(h, P_LIST, h->list, h->n_ecs());
+        POOL(h, P_CNT, d_n, 1);
+        HIPCHK(h, hipMemsetAsync(d_n, 0, sizeof(u64), h->stream));
+        own = CompactSink{h->list, h->n_ecs(), d_n, nullptr, 0, nullptr};
+        sink = &own;
+    }
     if (R) {
         u32 bb = BIN_BITS;
         while (bb < MAX_BIN_BITS && (h->cap >> bb) > MAX_BUCKETS) ++bb;
@@ -2798,7 +2811,8 @@ int ensure_counts(ecb_handle* h, const CompactSink* sink = nullptr) {
         u32* d_nwork = reinterpret_cast<u32*>(d_work + max_work);
         k_build_work<<<1, 1024, 0, h->stream>>>(d_starts, nb, piece, d_work, max_work, d_nwork);
         k_count_bins<<<max_work, TPB_COUNT, 4u << bb, h->stream>>>(pairs, d_work, d_nwork, bb, h->table, sink ? *sink : CompactSink{nullptr, 0, nullptr, nullptr, 0, nullptr});
-        if (sink) h->list_from_counts = true;
+        if (sink == &own) { h->list_counted = true; h->d_list_n = own.n_list; }
+        else if (sink) h->list_from_counts = true;
         HIPCHK(h, hipGetLastError());
     }
     h->counted = true;
@@ -2815,9 +2829,15 @@ int compact_table_dev(ecb_handle* h, u64* d_n, u32* bitmap = nullptr, u64 n_bits
 }
 int compact_table(ecb_handle* h) {
     u64* d_n = nullptr;
-    POOL(h, P_CNT, d_n, 1);
-    int rc = compact_table_dev(h, d_n);
-    if (rc != ECB_OK) return rc;
+    int rc = ECB_OK;
+    if (h->list_counted) {                               // the counting pass listed them: no scan of the table
+        POOL(h, P_LIST, h->list, h->n_ecs());            // (the pool's buffer, contents and all)
+        d_n = h->d_list_n;
+    } else {
+        POOL(h, P_CNT, d_n, 1);
+        rc = compact_table_dev(h, d_n);
+        if (rc != ECB_OK) return rc;
+    }
     HIPCHK(h, hipMemcpyAsync(&h->n_list, d_n, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->n_list != h->n_ecs()) return fail(h, ECB_ERR_HIP, "internal: %llu occupied slots but %llu ECs created",
@@ -2980,6 +3000,7 @@ int ecb_reset(ecb_handle* h) {
     h->extra_all = h->extra_valid = h->extra_reads = 0;
     h->c_rid.clear(); h->c_loc.clear(); h->c_hf.clear(); h->c_pos.clear();
     h->finalized = false; h->counted = false; h->adopted = false; h->sizes = ecb_sizes{}; h->n_list = 0;
+    h->list_counted = false; h->list_from_counts = false;
     h->n_mismatch = 0; h->ms_filtered = false;
     return ECB_OK;
 }
@@ -3285,6 +3306,7 @@ int ecb_table_merge_batch_device(ecb_handle* h, uint32_t n_tables, const void* c
     // room for every entry being new: one growth up front, then the merges queue up behind each other with one sync at the end
     while ((h->n_ecs() + total) * 2 > h->cap) { rc = grow_table(h, h->cap * 4); if (rc != ECB_OK) return rc; }
     HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));
+    h->list_counted = false;                     // (new ECs may join)
     for (u32 t = 0; t < n_tables; ++t)
         if (n_entries[t])
             k_merge<<<nblk(n_entries[t], MERGE_PER_BLOCK), TPB, 0, h->stream>>>((const Entry*)d_entries[t], n_entries[t], (const uint2*)d_pairs[t],
@@ -3357,7 +3379,7 @@ int ecb_table_adopt_batch_device(ecb_handle* h, uint32_t n_tables, const void* c
         if (n_entries[t] && (!d_entries[t] || (n_pairs[t] && !d_pairs[t]))) return fail(h, ECB_ERR_ARG, "null table buffers");
         if (n_entries[t]) { add_e += n_entries[t]; add_p += n_pairs[t]; }
     }
-    h->adopted = true; h->counted = true;
+    h->adopted = true; h->counted = true; h->list_counted = false;
     if (!add_e) return ECB_OK;
     u64 have = h->n_ecs(), top = h->hctr.arena_top;
     if (top + add_p > h->arena_cap || top + add_p >= (1ull << 32))
