@@ -141,8 +141,8 @@ def _rank_convert(rank, world, port, backend, devices, bam_filename, ec_filename
                   target_filename, result_path):
     """One process per GPU (the reference: one process per contiguous chunk range, ``bam_utils.py:646-680``): every rank
     decodes the BAM, takes the contiguous read range ``[rank R / world, (rank + 1) R / world)``, builds its EC table on its
-    GPU; the tables are merged by key range over RCCL (``dist.exchange_and_merge``: the ordered merge of ``:680-724``) and
-    rank 0 finalizes and writes.  The decode is not shared: every rank reads the file (twice: reads are counted first)."""
+    GPU; the tables are merged by key range over RCCL (``dist.exchange_and_merge``: the ordered merge of ``:680-724``), every
+    rank finalizes its range, rank 0 puts the ranges together and writes.  The decode is not shared: every rank reads the file (twice: reads are counted first)."""
     import json
     import torch
     import torch.distributed as tdist
@@ -183,7 +183,7 @@ def _rank_convert(rank, world, port, backend, devices, bam_filename, ec_filename
     reader.close()
     eng = wrap(ecdist.GpuEngine(b, device))
     fresh = lambda: wrap(ecdist.GpuEngine(EcBuilder(maps.n_loci, maps.n_haplotypes, device=dev_index, track_ranges=False), device))
-    merged = ecdist.exchange_and_merge(eng, fresh, fresh, root=0)
+    merged = ecdist.exchange_and_merge(eng, fresh, fresh, root=0, finalize_ranges=True)     # (every rank ranks and emits its own key range)
     range_len = None
     if track:
         mn, mx = b.export_range_minmax()

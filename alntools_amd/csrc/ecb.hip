@@ -2267,6 +2267,7 @@ struct ecb_handle {
     u64* wave_arena = nullptr; u64 wave_arena_n = 0;   // see StreamArgs::wave_arena
     bool scatter_attr_set = false, count_attr_set = false;
     bool list_from_counts = false;             // finalize: k_count_bins listed the occupied slots (no k_compact pass)
+    bool assembled = false;                    // the result was put together from per-range results (ecb_assemble_ranges_device)
     bool list_counted = false;                 // ... and so it did for a table export (the list alone; its length at *d_list_n)
     u64* d_list_n = nullptr;
     u64 resident_blocks = 0, resident_blocks_rg = 0, rounds = 24, min_tiles = 32;     // k_stream's launch shape (queried once)
@@ -2873,6 +2874,56 @@ int ms_reduce(ecb_handle* h, const u32* ec_of_slot) {
     return ECB_OK;
 }
 
+// ---- finalize per key range (multi-GPU): every rank ranks and emits the ECs of its own key range, the root only puts the pieces
+// in the order of first appearance.  The rank of an EC = the number of ECs whose first read comes before its own
+// (bam_utils.py:682-698): a bitmap over the reads, marked from every piece's first reads, and its prefix popcount.
+__global__ void k_export_firsts(const Slot* table, const u32* order, u64 n, u32* firsts) {
+    const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (e < n) firsts[e] = ~table[order[e]].first_inv;
+}
+struct PieceDesc { const u32* firsts; const int *indptr, *indices, *data, *counts; u64 n, nnz, at; };   // one finalized key range (at: its first EC among all pieces')
+// (all pieces in one launch: blockIdx.y = piece)
+__global__ void k_mark_bits(const PieceDesc* P, u64 n_bits, u32* bitmap, Counters* ctr) {
+    const PieceDesc d = P[blockIdx.y];
+    const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (e >= d.n) return;
+    const u32 f = d.firsts[e];
+    if (f >= n_bits) { atomicOr(&ctr->err, ERR_CONTRACT); return; }
+    atomicOr(&bitmap[f >> 5], 1u << (f & 31u));
+}
+__global__ void k_piece_place(const PieceDesc* P, u64 n_total, u64 n_bits, const u32* bitmap, const u32* wprefix, u32* src_of, u32* rowlen,
+                              int* counts, Counters* ctr) {
+    const PieceDesc d = P[blockIdx.y];
+    const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (e >= d.n) return;
+    const u32 f = d.firsts[e];
+    if (f >= n_bits) return;                             // (reported by k_mark_bits)
+    const long long s0 = d.indptr[e], s1 = d.indptr[e + 1];
+    if (s0 < 0 || s1 < s0 || (u64)s1 > d.nnz) { atomicOr(&ctr->err, ERR_CONTRACT); return; }
+    const u32 r = wprefix[f >> 5] + __popc(bitmap[f >> 5] & ((1u << (f & 31u)) - 1u));
+    if (r >= n_total) return;
+    src_of[r] = (u32)(d.at + e);                         // (two pieces claiming one first read: either; the caller reports it)
+    rowlen[r] = (u32)(s1 - s0);
+    counts[r] = d.counts[e];
+}
+// One thread per row of the result: neighbours write neighbouring rows, and read rows that follow each other within their piece
+// (a piece is in first-read order itself).
+__global__ void k_piece_rows(const PieceDesc* P, u32 n_pieces, const u32* src_of, u64 n_total, const u32* indptr, int* indices, int* data) {
+    const u64 r = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (r >= n_total) return;
+    const u32 g = src_of[r];
+    if (g == 0xFFFFFFFFu) return;
+    u32 q = 0;
+    while (q + 1 < n_pieces && P[q + 1].at <= g) ++q;
+    const u64 e = g - P[q].at;
+    const int* ip = P[q].indptr;
+    const int s0 = ip[e], s1 = ip[e + 1];
+    const u32 d0 = indptr[r];
+    if (indptr[r + 1] - d0 != (u32)(s1 - s0)) return;   // (a row length from another claimant: nothing is written past a row)
+    const int *sj = P[q].indices, *sd = P[q].data;
+    for (int i = s0; i < s1; ++i) { indices[d0 + (u32)(i - s0)] = sj[i]; data[d0 + (u32)(i - s0)] = sd[i]; }
+}
+
 }  // namespace
 
 extern "C" {
@@ -2983,7 +3034,9 @@ int ecb_reset(ecb_handle* h) {
 #endif
     {
         // a sparsely filled table is cleared slot by slot from that list (config 3: 3.7 M of 16.8 M slots, 0.24 of 1 GB)
-        if (occupied && n_occupied && n_occupied == h->n_ecs() && !h->hctr.err && n_occupied * 3 < h->cap)
+        if (h->assembled) {
+            // (a result assembled from per-range pieces never touched this handle's table)
+        } else if (occupied && n_occupied && n_occupied == h->n_ecs() && !h->hctr.err && n_occupied * 3 < h->cap)
             k_clear_slots<<<nblk(n_occupied, TPB), TPB, 0, h->stream>>>(h->table, occupied, n_occupied);
         else
             HIPCHK(h, hipMemsetAsync(h->table, 0, h->cap * sizeof(Slot), h->stream));
@@ -3000,7 +3053,7 @@ int ecb_reset(ecb_handle* h) {
     h->extra_all = h->extra_valid = h->extra_reads = 0;
     h->c_rid.clear(); h->c_loc.clear(); h->c_hf.clear(); h->c_pos.clear();
     h->finalized = false; h->counted = false; h->adopted = false; h->sizes = ecb_sizes{}; h->n_list = 0;
-    h->list_counted = false; h->list_from_counts = false;
+    h->list_counted = false; h->list_from_counts = false; h->assembled = false;
     h->n_mismatch = 0; h->ms_filtered = false;
     return ECB_OK;
 }
@@ -3080,6 +3133,7 @@ int ecb_push_cells(ecb_handle* h, const uint32_t* meta, uint64_t first_read, siz
 int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
     if (!h || !out) return ECB_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
+    if (h->assembled) { *out = h->sizes; return ECB_OK; }   // (the result of ecb_assemble_ranges_device: nothing left to rank)
     if (!h->finalized) {
         if (!h->c_rid.empty()) {                     // the stream ends here: the carried read is complete
             int rc = stage_and_process(h, nullptr, nullptr, nullptr, nullptr, 0);
@@ -3170,6 +3224,89 @@ int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
     return ECB_OK;
 }
 
+int ecb_export_firsts_device(ecb_handle* h, void* d_firsts) {
+    if (!h || !d_firsts) return ECB_ERR_ARG;
+    if (!h->finalized || h->assembled) return fail(h, ECB_ERR_STATE, "first reads are exported from a finalized table");
+    HIPCHK(h, hipSetDevice(h->device));
+    const u64 E = h->sizes.n_ecs;
+    k_export_firsts<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->table, h->order, E, (u32*)d_firsts);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ECB_OK;
+}
+
+int ecb_assemble_ranges_device(ecb_handle* h, uint32_t n_pieces, const void* const* d_indptr, const void* const* d_indices,
+                               const void* const* d_data, const void* const* d_counts, const void* const* d_firsts,
+                               const uint64_t* n_ecs, const uint64_t* nnz, uint64_t total_reads, uint64_t all_alignments,
+                               uint64_t valid_alignments, ecb_sizes* out) {
+    if (!h || !out) return ECB_ERR_ARG;
+    if (h->finalized || h->adopted || h->n_reads || !h->c_rid.empty() || h->n_ecs()) return fail(h, ECB_ERR_STATE, "assembling needs an empty handle");
+    if (h->cfg.flags & ECB_F_MULTISAMPLE) return fail(h, ECB_ERR_STATE, "multisample results are assembled from adopted tables (ecb_table_adopt_device)");
+    if (n_pieces && (!d_indptr || !d_indices || !d_data || !d_counts || !d_firsts || !n_ecs || !nnz)) return fail(h, ECB_ERR_ARG, "null piece lists");
+    if (n_pieces > 65535u) return fail(h, ECB_ERR_LIMIT, "at most 65535 pieces");
+    u64 E = 0, NNZ = 0;
+    for (u32 q = 0; q < n_pieces; ++q) {
+        if (n_ecs[q] && (!d_indptr[q] || !d_counts[q] || !d_firsts[q] || (nnz[q] && (!d_indices[q] || !d_data[q])))) return fail(h, ECB_ERR_ARG, "null piece buffers");
+        E += n_ecs[q]; NNZ += nnz[q];
+    }
+    if (E == 0 || valid_alignments == 0) return fail(h, ECB_ERR_EMPTY, "no valid alignments: nothing to build (the reference fails here too)");
+    if (E >= (1ull << 31) - 1) return fail(h, ECB_ERR_LIMIT, "more than 2^31-2 equivalence classes");
+    if (NNZ >= (1ull << 31)) return fail(h, ECB_ERR_LIMIT, "A has more than 2^31-1 non-zeros");
+    if (total_reads >= (1ull << 32) - 1) return fail(h, ECB_ERR_LIMIT, "more than 2^32-2 reads in total");
+    HIPCHK(h, hipSetDevice(h->device));
+    free_results(h);
+    const u64 words = (total_reads + 31) / 32 + 1;
+    u32 *bitmap = nullptr, *wpop = nullptr, *wprefix = nullptr, *rowlen = nullptr, *rank_q = nullptr;
+    u64* d_tot = nullptr;
+    POOL(h, P_BITMAP, bitmap, words); POOL(h, P_WPOP, wpop, words); POOL(h, P_WPREFIX, wprefix, words);
+    POOL(h, P_ROWLEN, rowlen, E); POOL(h, P_ORDER, rank_q, E);
+    POOL(h, P_INDPTR, h->indptr, E + 1); POOL(h, P_COUNTS, h->counts, E);
+    POOL(h, P_INDICES, h->indices, std::max<u64>(NNZ, 1)); POOL(h, P_DATA, h->data, std::max<u64>(NNZ, 1));
+    POOL(h, P_TOTALS, d_tot, 8);
+    HIPCHK(h, hipMemsetAsync(bitmap, 0, words * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(d_tot, 0, 8 * sizeof(u64), h->stream));
+    HIPCHK(h, hipMemsetAsync(rowlen, 0, E * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(rank_q, 0xFF, E * 4, h->stream));       // (source of every row: piece-major EC index)
+    int rc = clear_counters(h);
+    if (rc != ECB_OK) return rc;
+    std::vector<PieceDesc> desc;
+    u64 most = 0;
+    for (u32 q = 0, at = 0; q < n_pieces; ++q) {
+        if (!n_ecs[q]) continue;
+        desc.push_back(PieceDesc{(const u32*)d_firsts[q], (const int*)d_indptr[q], (const int*)d_indices[q], (const int*)d_data[q], (const int*)d_counts[q],
+                                 n_ecs[q], nnz[q], at});
+        at += n_ecs[q]; most = std::max<u64>(most, n_ecs[q]);
+    }
+    u64* d_desc_raw = nullptr;
+    POOL(h, P_PARTS, d_desc_raw, desc.size() * sizeof(PieceDesc) / sizeof(u64));
+    const PieceDesc* d_desc = reinterpret_cast<const PieceDesc*>(d_desc_raw);
+    HIPCHK(h, hipMemcpyAsync(d_desc_raw, desc.data(), desc.size() * sizeof(PieceDesc), hipMemcpyHostToDevice, h->stream));
+    const dim3 grid((unsigned)nblk(most, TPB), (unsigned)desc.size());
+    k_mark_bits<<<grid, TPB, 0, h->stream>>>(d_desc, total_reads, bitmap, h->ctr);
+    k_popc<<<nblk(words, TPB), TPB, 0, h->stream>>>(bitmap, words, wpop);
+    rc = excl_scan_dev(h, wpop, words, wprefix, d_tot + 1);
+    if (rc != ECB_OK) return rc;
+    k_piece_place<<<grid, TPB, 0, h->stream>>>(d_desc, E, total_reads, bitmap, wprefix, rank_q, rowlen, h->counts, h->ctr);
+    rc = excl_scan_dev(h, rowlen, E, h->indptr, d_tot + 2);
+    if (rc != ECB_OK) return rc;
+    k_set_last<<<1, 1, 0, h->stream>>>(h->indptr + E, d_tot + 2);
+    k_piece_rows<<<nblk(E, TPB), TPB, 0, h->stream>>>(d_desc, (u32)desc.size(), rank_q, E, h->indptr, h->indices, h->data);
+    u64 tot[8];
+    HIPCHK(h, hipMemcpyAsync(tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, h->stream));
+    h->ctr_synced = false;
+    rc = sync_counters(h);                                   // (waits)
+    if (rc == ECB_ERR_CONTRACT) return fail(h, rc, "a piece is malformed: a first read beyond the run's reads, or row offsets that are not its own");
+    if (rc != ECB_OK) return rc;
+    if (tot[1] != E) return fail(h, ECB_ERR_CONTRACT, "the pieces hold %llu ECs but %llu distinct first reads: ranges overlap or a first read is missing",
+                                 (unsigned long long)E, (unsigned long long)tot[1]);
+    if (tot[2] != NNZ) return fail(h, ECB_ERR_HIP, "internal: %llu non-zeros placed, %llu received", (unsigned long long)tot[2], (unsigned long long)NNZ);
+    h->sizes = ecb_sizes{};
+    h->sizes.n_ecs = E; h->sizes.nnz_a = NNZ; h->sizes.n_samples = 1; h->sizes.nnz_n = E;
+    h->sizes.all_alignments = all_alignments; h->sizes.valid_alignments = valid_alignments; h->sizes.n_reads = total_reads;
+    h->finalized = true; h->assembled = true; h->counted = true;
+    *out = h->sizes;
+    return ECB_OK;
+}
+
 int ecb_export_device(ecb_handle* h, void* ia, void* ja, void* da, void* in_, void* jn, void* dn) {
     if (!h) return ECB_ERR_ARG;
     if (!h->finalized) return fail(h, ECB_ERR_STATE, "export before finalize");
@@ -3252,7 +3389,7 @@ int ecb_export_pairs(ecb_handle* h, uint32_t* ec, uint32_t* meta, uint32_t* coun
 int ecb_export_read_ec(ecb_handle* h, int32_t* out) {
     if (!h || !out) return ECB_ERR_ARG;
     if (!h->finalized) return fail(h, ECB_ERR_STATE, "export before finalize");
-    if (h->extra_reads) return fail(h, ECB_ERR_STATE, "per-read EC ids are not kept across a multi-GPU merge");
+    if (h->extra_reads || h->assembled) return fail(h, ECB_ERR_STATE, "per-read EC ids are not kept across a multi-GPU merge");
     HIPCHK(h, hipSetDevice(h->device));
     int* d = nullptr;
     HIPCHK(h, hipMalloc(&d, std::max<u64>(h->n_reads, 1) * 4));
@@ -3415,6 +3552,7 @@ int ecb_table_adopt_device(ecb_handle* h, const void* d_entries, uint64_t n_entr
 int ecb_export_ec_keys_device(ecb_handle* h, void* d_keys) {
     if (!h || !d_keys) return ECB_ERR_ARG;
     if (!h->finalized) return fail(h, ECB_ERR_STATE, "export before finalize");
+    if (h->assembled) return fail(h, ECB_ERR_STATE, "an assembled result holds no table to take hashes from");
     HIPCHK(h, hipSetDevice(h->device));
     const u64 E = h->sizes.n_ecs;
     k_export_keys<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->table, h->order, E, (u64*)d_keys);

@@ -11,11 +11,14 @@ export), then
    ``1/world`` of a table each;
 2. rank q merges the ``world`` pieces of range q in rank order (``ecb_table_merge_device``): the hashing and key
    comparison of the merge is spread over the GPUs instead of queueing on the root;
-3. the merged ranges hold disjoint ECs: they are sent to the root, which loads them without hashing
-   (``ecb_table_adopt_device``) and finalizes (rank by first appearance, CSR emit).
+3. the merged ranges hold disjoint ECs.  Single-sample runs (``finalize_ranges=True``): rank q finalizes its own range --
+   ranks its ECs by first read and emits their CSR rows and counts, 1/world of the work -- and sends the rows to the root,
+   which only places the pieces in the global order of first reads (``ecb_assemble_ranges_device``).  Multisample runs
+   (the shards need the root's table for the second exchange): the merged tables are sent to the root, which loads them
+   without hashing (``ecb_table_adopt_device``) and finalizes.
 
 The functions only need an *engine* with ``table_sizes/counters/table_export/table_export_parts/table_merge(_many)/
-table_adopt(_many)/add_counters`` -- :class:`GpuEngine` wraps an :class:`alntools_amd.ecb.EcBuilder`; the CPU ``gloo`` tests
+table_adopt(_many)/add_counters/finalize_range/assemble_ranges`` -- :class:`GpuEngine` wraps an :class:`alntools_amd.ecb.EcBuilder`; the CPU ``gloo`` tests
 plug in an oracle-backed engine.
 """
 from __future__ import annotations
@@ -51,6 +54,18 @@ def unpack_ec_keys(packed, n_ecs, nnz):
     a = 2 * ((n_ecs + 2) // 2)
     b = a + 2 * ((nnz + 1) // 2)
     return packed[:n_ecs], w[:n_ecs + 1], w[a:a + nnz], w[b:b + nnz]
+
+
+def piece_words(n_ecs, nnz):
+    """int32 words of one finalized key range: indptr | counts | first reads | indices | data."""
+    return 3 * n_ecs + 1 + 2 * nnz
+
+
+def unpack_piece(packed, n_ecs, nnz):
+    """-> views (indptr, counts, firsts, indices, data) of a :func:`piece_words` tensor."""
+    a = n_ecs + 1
+    return (packed[:a], packed[a:a + n_ecs], packed[a + n_ecs:a + 2 * n_ecs], packed[a + 2 * n_ecs:a + 2 * n_ecs + nnz],
+            packed[a + 2 * n_ecs + nnz:a + 2 * n_ecs + 2 * nnz])
 
 
 class GpuEngine(object):
@@ -120,6 +135,28 @@ class GpuEngine(object):
     def add_counters(self, a, v, r):
         self.b.add_counters(a, v, r)
 
+    # finalize per key range
+    def finalize_range(self, n_all, n_valid, n_reads):
+        """On the handle that merged one key range: rank and emit its ECs against the whole run's read numbering ->
+        (packed int32 tensor [:func:`piece_words`], n_ecs, nnz)."""
+        if not self.b.table_sizes()[0]:
+            return torch.zeros(1, dtype=torch.int32, device=self.device), 0, 0
+        self.b.add_counters(n_all, n_valid, n_reads)
+        s = self.b.finalize()
+        n_ecs, nnz = s["n_ecs"], s["nnz_a"]
+        packed = torch.empty(piece_words(n_ecs, nnz), dtype=torch.int32, device=self.device)
+        ip, cn, fi, ix, da = unpack_piece(packed, n_ecs, nnz)
+        self.b.export_piece_device(ip, ix, da, cn, fi)
+        return packed, n_ecs, nnz
+
+    def assemble_ranges(self, pieces, n_all, n_valid, n_reads):
+        """``pieces``: [(packed, n_ecs, nnz), ...] -> this (empty) handle holds the finalized result."""
+        rows = []
+        for packed, n_ecs, nnz in pieces:
+            ip, cn, fi, ix, da = unpack_piece(packed, n_ecs, nnz)
+            rows.append((ip, ix, da, cn, fi, n_ecs, nnz))
+        return self.b.assemble_ranges_device(rows, n_reads, n_all, n_valid)
+
 
 class HostStagedEngine(object):
     """A :class:`GpuEngine` seen through CPU tensors, for process groups that only move host memory (``gloo``): used to
@@ -159,6 +196,13 @@ class HostStagedEngine(object):
     def table_adopt_many(self, tables):
         self.e.table_adopt_many([(self._up(a), n, self._up(b), m) for a, n, b, m in tables])
 
+    def finalize_range(self, *a):
+        packed, n_ecs, nnz = self.e.finalize_range(*a)
+        return packed.cpu(), n_ecs, nnz
+
+    def assemble_ranges(self, pieces, *a):
+        return self.e.assemble_ranges([(self._up(p), n, m) for p, n, m in pieces], *a)
+
     def ec_keys(self, n_ecs):
         packed, nnz = self.e.ec_keys(n_ecs)
         return packed.cpu(), nnz
@@ -178,9 +222,10 @@ def _p2p(ops):
         req.wait()
 
 
-def exchange_and_merge(engine, make_part_engine, make_root_engine, group=None, root=0):
-    """All ranks call this after pushing their shard.  Returns the merged engine on ``root`` (ready to finalize),
-    ``None`` elsewhere.  Two small all-gathers (sizes) and two rounds of point-to-point messages; see the module text."""
+def exchange_and_merge(engine, make_part_engine, make_root_engine, group=None, root=0, finalize_ranges=False):
+    """All ranks call this after pushing their shard.  Returns the merged engine on ``root`` (ready to finalize; already
+    finalized with ``finalize_ranges``, where ``finalize()`` only reports the sizes), ``None`` elsewhere.  Two small
+    all-gathers (sizes) and two rounds of point-to-point messages; see the module text."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = engine.device
@@ -228,6 +273,10 @@ def exchange_and_merge(engine, make_part_engine, make_root_engine, group=None, r
     part.table_merge_many([(piece_e[r], in_e[r], piece_p[r], in_p[r]) for r in range(world) if in_e[r]])
     del piece_e, piece_p, ent, prs
 
+    totals = (sum(s[3] for s in sizes), sum(s[4] for s in sizes), sum(s[2] for s in sizes))
+    if finalize_ranges:
+        return _finalize_ranges(part, make_root_engine, totals, world, rank, dev, group, root)
+
     # 3. the merged ranges are disjoint: gather them on the root, which adopts them as they are
     pe_n, pp_n, _ = part.table_sizes()
     pe, pp = part.table_export(0)
@@ -261,7 +310,35 @@ def exchange_and_merge(engine, make_part_engine, make_root_engine, group=None, r
     merged = make_root_engine()
     merged.table_adopt_many([(pe, sz2[r][0], pp, sz2[r][1]) if r == root else (bufs[r][0], sz2[r][0], bufs[r][1], sz2[r][1])
                              for r in range(world) if sz2[r][0]])
-    merged.add_counters(sum(s[3] for s in sizes), sum(s[4] for s in sizes), sum(s[2] for s in sizes))
+    merged.add_counters(*totals)
+    return merged
+
+
+def _finalize_ranges(part, make_root_engine, totals, world, rank, dev, group, root):
+    """Step 3 of :func:`exchange_and_merge` for single-sample runs: every rank finalizes the key range it merged, the root
+    places the finished rows.  One message of ``piece_words`` int32 per rank."""
+    packed, n_ecs, nnz = part.finalize_range(*totals)
+    mine = torch.tensor([n_ecs, nnz], dtype=torch.int64, device=dev)
+    sz = torch.empty(world * 2, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sz, mine, group=group)
+    sz = sz.view(world, 2).cpu().tolist()
+    if rank != root:
+        if n_ecs:
+            _p2p([dist.P2POp(dist.isend, packed, root, group)])
+            if dev.type == "cuda":
+                torch.cuda.current_stream(dev).synchronize()
+        return None
+    bufs, ops = {}, []
+    for r in range(world):
+        if r == root or not sz[r][0]:
+            continue
+        bufs[r] = torch.empty(piece_words(*sz[r]), dtype=torch.int32, device=dev)
+        ops.append(dist.P2POp(dist.irecv, bufs[r], r, group))
+    _p2p(ops)
+    if dev.type == "cuda":
+        torch.cuda.current_stream(dev).synchronize()
+    merged = make_root_engine()
+    merged.assemble_ranges([(packed if r == root else bufs[r], sz[r][0], sz[r][1]) for r in range(world) if sz[r][0]], *totals)
     return merged
 
 

@@ -30,6 +30,7 @@ SYMBOLS = ("ecb_abi_version", "ecb_device_count", "ecb_create", "ecb_destroy", "
            "ecb_export_read_ec", "ecb_table_sizes",
            "ecb_table_export_device", "ecb_table_merge_device", "ecb_table_export_parts_device",
            "ecb_table_adopt_device", "ecb_table_merge_batch_device", "ecb_table_adopt_batch_device",
+           "ecb_export_firsts_device", "ecb_assemble_ranges_device",
            "ecb_export_ec_keys_device", "ecb_ms_local_triples_device", "ecb_ms_adopt_triples_device", "ecb_counters", "ecb_add_counters", "ecb_profile",
            "ecb_profile_read", "ecb_csr_to_hapcsc_device", "ecb_hapcsc_to_csr_device")
 
@@ -107,6 +108,8 @@ def load():
     for f in (lib.ecb_table_merge_batch_device, lib.ecb_table_adopt_batch_device):
         f.argtypes = [vp, C.c_uint32, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64)]
     lib.ecb_export_ec_keys_device.argtypes = [vp, vp]
+    lib.ecb_export_firsts_device.argtypes = [vp, vp]
+    lib.ecb_assemble_ranges_device.argtypes = [vp, C.c_uint32] + [C.POINTER(vp)] * 5 + [C.POINTER(u64)] * 2 + [u64, u64, u64, C.POINTER(Sizes)]
     lib.ecb_ms_local_triples_device.argtypes = [vp, vp, vp, vp, vp, u64, u64, vp, vp, vp, C.POINTER(u64)]
     lib.ecb_ms_adopt_triples_device.argtypes = [vp, C.c_uint32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
     lib.ecb_counters.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
@@ -335,6 +338,24 @@ class EcBuilder(object):
 
     def table_adopt_device(self, entries, n_entries, pairs, n_pairs):
         self._chk(self._lib.ecb_table_adopt_device(self._h, _dev_ptr(entries), n_entries, _dev_ptr(pairs), n_pairs))
+
+    # -- finalize per key range ----------------------------------------------
+    def export_piece_device(self, indptr, indices, data, counts, firsts):
+        """After finalize, on the handle that merged one key range: CSR A, the EC counts and every EC's first read (global
+        index) into int32 device tensors of E + 1 / nnz / nnz / E / E elements."""
+        self._chk(self._lib.ecb_export_device(self._h, _dev_ptr(indptr), _dev_ptr(indices), _dev_ptr(data), None, None, _dev_ptr(counts)))
+        self._chk(self._lib.ecb_export_firsts_device(self._h, _dev_ptr(firsts)))
+
+    def assemble_ranges_device(self, pieces, n_reads, all_alignments, valid_alignments):
+        """``pieces``: [(indptr, indices, data, counts, firsts, n_ecs, nnz), ...] of int32 device tensors, one per key range,
+        into this (empty) handle, which is finalized afterwards -> sizes."""
+        k = len(pieces)
+        ptrs = [(C.c_void_p * k)(*[p[i].data_ptr() for p in pieces]) for i in range(5)]
+        ne, nz = (C.c_uint64 * k)(*[p[5] for p in pieces]), (C.c_uint64 * k)(*[p[6] for p in pieces])
+        s = Sizes()
+        self._chk(self._lib.ecb_assemble_ranges_device(self._h, k, *ptrs, ne, nz, n_reads, all_alignments, valid_alignments, C.byref(s)))
+        self.sizes = {k_: int(getattr(s, k_)) for k_, _ in Sizes._fields_}
+        return self.sizes
 
     # -- multisample across GPUs ----------------------------------------------
     def export_ec_keys_device(self, keys):

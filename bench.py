@@ -254,12 +254,13 @@ def main():
         return part_eng
 
     sizes = {}
+    per_range = os.environ.get("ECB_DIST_FINALIZE", "ranges") != "root"      # ("root": the merged tables go to rank 0, which finalizes alone)
 
     def step():
         b.reset()
         b.push_device(rid, loc, hf)
         if use_dist:
-            m = ecdist.exchange_and_merge(eng, make_part, make_root, root=0)
+            m = ecdist.exchange_and_merge(eng, make_part, make_root, root=0, finalize_ranges=per_range)
             if m is not None:
                 sizes.update(m.b.finalize())
         elif os.environ.get("ECB_ABLATE"):      # profiling-only builds of the kernel produce no ECs

@@ -196,6 +196,20 @@ int ecb_table_merge_batch_device(ecb_handle* h, uint32_t n_tables, const void* c
                                  const void* const* d_pairs, const uint64_t* n_pairs);
 int ecb_table_adopt_batch_device(ecb_handle* h, uint32_t n_tables, const void* const* d_entries, const uint64_t* n_entries,
                                  const void* const* d_pairs, const uint64_t* n_pairs);
+/* Finalize per key range (single-sample runs): instead of sending its merged range's table to the root, rank q sets the
+ * totals of the whole run on the handle that merged range q (ecb_add_counters: read indices are global there) and calls
+ * ecb_finalize on it -- the ranking and the CSR emit of 1/N of the ECs -- then exports CSR A / counts (ecb_export_device) and
+ * the first read of every EC, in the same order (ecb_export_firsts_device: n_ecs x uint32).  The root puts the N pieces
+ * together on an EMPTY handle with ecb_assemble_ranges_device: the global rank of an EC = the number of ECs with an earlier
+ * first read (a bitmap over the reads, marked from all pieces, and its prefix popcount), rows copied to their places.
+ * Afterwards that handle behaves as finalized (ecb_finalize returns the sizes again; ecb_export, ecb_export_device), but it
+ * holds no table: the per-read and hash exports refuse.  ECB_ERR_CONTRACT if two pieces name the same first read.
+ * (bam_utils.py:680-724: the ordered merge of the workers' dicts; the order of the result is the same.) */
+int ecb_export_firsts_device(ecb_handle* h, void* d_firsts);
+int ecb_assemble_ranges_device(ecb_handle* h, uint32_t n_pieces, const void* const* d_indptr, const void* const* d_indices,
+                               const void* const* d_data, const void* const* d_counts, const void* const* d_firsts,
+                               const uint64_t* n_ecs, const uint64_t* nnz, uint64_t total_reads, uint64_t all_alignments,
+                               uint64_t valid_alignments, ecb_sizes* out);
 /* Multisample across GPUs (the shards' handles and the root's adopting handle all carry ECB_F_MULTISAMPLE).  After the ECs
  * were merged and the root finalized: ecb_export_ec_keys_device writes the 8-byte set hash of every EC in rank order
  * (n_ecs * 8 bytes; broadcast it together with the root's CSR A from ecb_export_device).  A shard finds its own ECs in

@@ -155,7 +155,39 @@ class OracleEngine(object):
         self.n_valid += v
         self.n_reads += r
 
+    # finalize per key range
+    def finalize_range(self, n_all, n_valid, n_reads):
+        rows = sorted(self.table.values(), key=lambda v: v[1])
+        assert all(0 <= r[1] < n_reads for r in rows)
+        c = self.csr()
+        n_ecs, nnz = len(rows), len(c["indices"])
+        if not n_ecs:
+            return torch.zeros(1, dtype=torch.int32), 0, 0
+        packed = torch.empty(ecdist.piece_words(n_ecs, nnz), dtype=torch.int32)
+        ip, cn, fi, ix, da = ecdist.unpack_piece(packed, n_ecs, nnz)
+        ip[:] = torch.tensor(c["indptr"], dtype=torch.int32)
+        cn[:] = torch.tensor(c["count"], dtype=torch.int32)
+        fi[:] = torch.tensor([r[1] for r in rows], dtype=torch.int64).to(torch.int32)
+        ix[:] = torch.tensor(c["indices"], dtype=torch.int32)
+        da[:] = torch.tensor(c["data"], dtype=torch.int32)
+        return packed, n_ecs, nnz
+
+    def assemble_ranges(self, pieces, n_all, n_valid, n_reads):
+        assert not self.table
+        rows = []
+        for packed, n_ecs, nnz in pieces:
+            ip, cn, fi, ix, da = (t.tolist() for t in ecdist.unpack_piece(packed, n_ecs, nnz))
+            rows += [(fi[e] & 0xFFFFFFFF, cn[e], ix[ip[e]:ip[e + 1]], da[ip[e]:ip[e + 1]]) for e in range(n_ecs)]
+        rows.sort(key=lambda r: r[0])
+        assert len(set(r[0] for r in rows)) == len(rows), "two ECs with one first read"
+        indptr = np.cumsum([0] + [len(r[2]) for r in rows])
+        self.assembled = dict(indptr=indptr, indices=np.array([x for r in rows for x in r[2]]),
+                              data=np.array([x for r in rows for x in r[3]]), count=np.array([r[1] for r in rows]))
+        self.add_counters(n_all, n_valid, n_reads)
+
     def csr(self):
+        if getattr(self, "assembled", None) is not None:
+            return self.assembled
         rows = sorted(self.table.values(), key=lambda v: v[1])
         indptr, indices, data = [0], [], []
         for count, first, pairs in rows:
@@ -184,6 +216,8 @@ def _worker(rank, world, port, spec_args, out_path, protocol):
     fresh = lambda: OracleEngine(spec.n_haps)
     if protocol == "ranges":
         merged = ecdist.exchange_and_merge(eng, fresh, fresh, root=0)
+    elif protocol == "finalize_ranges":
+        merged = ecdist.exchange_and_merge(eng, fresh, fresh, root=0, finalize_ranges=True)
     else:
         merged = ecdist.exchange_and_merge_on_root(eng, fresh, root=0)
     if rank == 0:
@@ -195,7 +229,8 @@ def _worker(rank, world, port, spec_args, out_path, protocol):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,paired,protocol", [(2, False, "ranges"), (2, True, "ranges"), (3, True, "ranges"), (4, True, "ranges"), (2, True, "root"), (4, False, "root")])
+@pytest.mark.parametrize("world,paired,protocol", [(2, False, "ranges"), (2, True, "ranges"), (3, True, "ranges"), (4, True, "ranges"), (2, True, "root"), (4, False, "root"),
+                                                   (2, False, "finalize_ranges"), (3, True, "finalize_ranges"), (4, True, "finalize_ranges")])
 def test_multi_rank_merge_equals_single_process(tmp_path, world, paired, protocol):
     spec_args = dict(n_reads=3000, n_loci=300, n_haps=4, paired=paired)
     out = str(tmp_path / "merged.npz")

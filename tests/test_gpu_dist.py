@@ -105,3 +105,103 @@ def test_convert_over_several_ranks_writes_the_reference_bytes(tmp_path, monkeyp
         if os.path.exists(exp_rng):
             assert open(rng).read() == open(exp_rng).read(), name
         assert sizes["n_ecs"] > 0
+
+
+def _pieces_of(spec, world, dev):
+    """The multi-rank protocol by hand in one process: ``world`` shard handles, cut into ``world`` key ranges, range q merged
+    on its own handle and finalized there -> ([(packed, n_ecs, nnz)], totals)."""
+    from alntools_amd import dist as ecdist
+    from alntools_amd import ecb, synth
+    R = spec.n_reads
+    shards, base, cuts, totals = [], 0, [], [0, 0, 0]
+    for r in range(world):
+        t = synth.generate(spec, r * R // world, (r + 1) * R // world, device=dev)
+        b = ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=1 << 12)
+        b.push_device(t["read_id"], t["locus"], t["hapflag"])
+        eng = ecdist.GpuEngine(b, dev)
+        cuts.append(eng.table_export_parts(base, world))
+        a, v, n = eng.counters()
+        totals = [totals[0] + a, totals[1] + v, totals[2] + n]
+        base += n
+        shards.append(b)
+    pieces = []
+    for q in range(world):
+        part = ecdist.GpuEngine(ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=1 << 12), dev)
+        part.table_merge_many([(ent[eo[q] * 4:], eo[q + 1] - eo[q], prs[po[q]:], po[q + 1] - po[q]) for ent, prs, eo, po in cuts if eo[q + 1] > eo[q]])
+        pieces.append(part.finalize_range(*totals))
+        part.b.close()
+    for b in shards:
+        b.close()
+    return [p for p in pieces if p[1]], totals
+
+
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_ranges_finalized_apart_assemble_to_the_result_of_one_handle(world):
+    """Finalize per key range (ecb_export_firsts_device / ecb_assemble_ranges_device): every range ranked and emitted on its
+    own handle, the pieces placed by first read on an empty one == one handle over the whole stream, bit for bit."""
+    from alntools_amd import dist as ecdist
+    from alntools_amd import ecb, synth
+    dev = torch.device("cuda:0")
+    spec = synth.SynthSpec(80000, 3000, 8, paired=True)
+    pieces, totals = _pieces_of(spec, world, dev)
+    root = ecdist.GpuEngine(ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=1 << 10), dev)
+    s = root.assemble_ranges(pieces, *totals)
+    assert root.b.finalize() == s                       # (idempotent: reports the assembled sizes)
+    got = root.b.export()
+    whole = synth.generate(spec, 0, spec.n_reads, device=dev)
+    with ecb.EcBuilder(spec.n_loci, spec.n_haps) as one:
+        one.push_device(whole["read_id"], whole["locus"], whole["hapflag"])
+        exp_s = one.finalize()
+        exp = one.export()
+    assert s == exp_s
+    for k in exp:
+        assert np.array_equal(got[k], exp[k]), k
+    with pytest.raises(ecb.EcbError):                   # no table behind an assembled result
+        root.b.export_read_ec()
+    with pytest.raises(ecb.EcbError):
+        root.b.export_ec_keys_device(torch.empty(s["n_ecs"], dtype=torch.int64, device=dev))
+    root.b.reset()                                      # and the handle is as good as new
+    root.b.push_device(whole["read_id"], whole["locus"], whole["hapflag"])
+    assert root.b.finalize() == exp_s
+    again = root.b.export()
+    for k in exp:
+        assert np.array_equal(again[k], exp[k]), k
+    root.b.close()
+
+
+def test_assembling_refuses_overlapping_or_malformed_pieces():
+    from alntools_amd import dist as ecdist
+    from alntools_amd import ecb, synth
+    dev = torch.device("cuda:0")
+    spec = synth.SynthSpec(20000, 500, 4, paired=False)
+    pieces, totals = _pieces_of(spec, 2, dev)
+    fresh = lambda: ecdist.GpuEngine(ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=1 << 10), dev)
+    e = fresh()
+    with pytest.raises(ecb.EcbError) as ei:             # the same range twice: two ECs per first read
+        e.assemble_ranges([pieces[0], pieces[0]], *totals)
+    assert ei.value.code == -5
+    e.b.close()
+    e = fresh()
+    with pytest.raises(ecb.EcbError) as ei:             # a first read the run does not have
+        e.assemble_ranges(pieces, totals[0], totals[1], 10)
+    assert ei.value.code == -5
+    e.b.close()
+    e = fresh()
+    bad = pieces[1][0].clone()
+    bad[1] = 1 << 30                                    # a row that ends beyond the piece
+    with pytest.raises(ecb.EcbError) as ei:
+        e.assemble_ranges([pieces[0], (bad, pieces[1][1], pieces[1][2])], *totals)
+    assert ei.value.code == -5
+    e.b.close()
+    e = fresh()                                         # a handle that already holds reads does not assemble
+    t = synth.generate(spec, 0, 100, device=dev)
+    e.b.push_device(t["read_id"], t["locus"], t["hapflag"])
+    with pytest.raises(ecb.EcbError) as ei:
+        e.assemble_ranges(pieces, *totals)
+    assert ei.value.code == -6
+    e.b.close()
+    e = ecdist.GpuEngine(ecb.EcBuilder(spec.n_loci, spec.n_haps, multisample=True), dev)
+    with pytest.raises(ecb.EcbError) as ei:
+        e.assemble_ranges(pieces, *totals)
+    assert ei.value.code == -6
+    e.b.close()
