@@ -63,7 +63,13 @@ class _PysamReader(object):
 
 def iter_tuple_batches(reader, enc):
     """Tuples of the whole file, a batch of records at a time, from either kind of reader (``open_bam``)."""
-    if hasattr(reader, "read_decoded"):            # native decoder: no names, no per-record Python
+    if hasattr(reader, "read_tuples") and type(enc) is TupleEncoder and enc.trim == bool(reader.trim):
+        while True:                                 # native decoder: the tuples come out of the C loop over the records
+            t = reader.read_tuples(BATCH_RECORDS, enc)
+            if t is None:
+                return
+            yield t
+    if hasattr(reader, "read_decoded"):            # (an encoder of another kind: the decoded fields, then its own arithmetic)
         while True:
             d = reader.read_decoded(BATCH_RECORDS)
             if d is None:

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbamdec.so")
 SRC = os.path.join(_HERE, "csrc", "bamdec.c")
 SYMBOLS = ("bd_abi_version", "bd_open", "bd_close", "bd_last_error", "bd_n_references", "bd_reference_name",
-           "bd_reference_length", "bd_header_text", "bd_read", "bd_read_ms", "bd_ms_cells")
+           "bd_reference_length", "bd_header_text", "bd_references", "bd_read", "bd_read_tuples", "bd_read_ms", "bd_ms_cells")
 _lib = None
 
 
@@ -51,7 +51,10 @@ def lib():
         l.bd_reference_length.argtypes = [C.c_void_p, C.c_int32]
         l.bd_header_text.argtypes = [C.c_void_p]
         l.bd_header_text.restype = C.c_char_p
+        l.bd_references.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.POINTER(C.c_int32))]
         l.bd_read.argtypes = [C.c_void_p, C.c_size_t, C.c_int] + [C.c_void_p] * 7 + [C.POINTER(C.c_size_t)]
+        l.bd_read_tuples.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_uint32)] + \
+            [C.c_void_p] * 4 + [C.POINTER(C.c_size_t)] * 2
         l.bd_read_ms.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 7 + [C.POINTER(C.c_size_t)]
         l.bd_ms_cells.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_size_t)]
         _lib = l
@@ -70,8 +73,12 @@ class NativeBamReader(object):
         if rc != 0:
             raise (IOError if rc == -1 else ValueError)("%s: cannot read as BAM (bamdec error %d)" % (path, rc))
         n = self._l.bd_n_references(self._h)
-        self.references = tuple(self._l.bd_reference_name(self._h, i).decode("utf-8") for i in range(n))
-        self.lengths = tuple(self._l.bd_reference_length(self._h, i) for i in range(n))
+        blob, blob_len, lens = C.c_void_p(), C.c_size_t(0), C.POINTER(C.c_int32)()
+        if self._l.bd_references(self._h, C.byref(blob), C.byref(blob_len), C.byref(lens)) != 0:
+            raise MemoryError("bamdec: %s" % self._l.bd_last_error(self._h).decode())
+        # (one call and one split instead of two ctypes calls per reference: a transcriptome header has 10^5 .. 10^6 of them)
+        self.references = tuple(C.string_at(blob, blob_len.value).decode("utf-8").split("\0")[:n]) if n else ()
+        self.lengths = tuple(np.ctypeslib.as_array(lens, shape=(n,)).tolist()) if n else ()
         self.text = (self._l.bd_header_text(self._h) or b"").decode("utf-8", "replace")
         self.trim = 1 if trim else 0
         self._cap = 0
@@ -98,6 +105,31 @@ class NativeBamReader(object):
             return None
         return dict(flag=self._flag[:k], tid=self._i32[0][:k], pos=self._i32[1][:k], next_tid=self._i32[2][:k],
                     next_pos=self._i32[3][:k], valid=self._u8[0][:k], head=self._u8[1][:k])
+
+    def read_tuples(self, max_records, enc):
+        """-> the tuples ``enc.encode_decoded(**self.read_decoded(max_records))`` would return (fresh arrays), made by the decoder
+        itself (``bd_read_tuples``), or ``None`` at the end of the file.  ``enc``: the :class:`tuples.TupleEncoder` whose maps
+        are used and whose read counter is carried on."""
+        m = enc.maps
+        if getattr(self, "_maps_of", None) is not m:        # (contiguous uint32 tables, made once per encoder)
+            self._t2l = np.ascontiguousarray(m.tid2locus, dtype=np.uint32)
+            self._t2h = np.ascontiguousarray(m.tid2hap, dtype=np.uint32)
+            self._maps_of = m
+        out = dict(read_id=np.empty(max_records, np.uint32), locus=np.empty(max_records, np.uint32),
+                   hapflag=np.empty(max_records, np.uint32), pos=np.empty(max_records, np.int32))
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        cur, n, nv = C.c_uint32(enc.cur), C.c_size_t(0), C.c_size_t(0)
+        rc = self._l.bd_read_tuples(self._h, max_records, self.trim, p(self._t2l), p(self._t2h), len(self._t2l), C.byref(cur),
+                                    p(out["read_id"]), p(out["locus"]), p(out["hapflag"]), p(out["pos"]), C.byref(n), C.byref(nv))
+        if rc != 0:
+            raise ValueError("BAM decode failed: %s" % self._l.bd_last_error(self._h).decode())
+        k = n.value
+        if k == 0:
+            return None
+        enc.cur = cur.value
+        out = {key: a[:k] for key, a in out.items()}
+        out["n_valid"] = nv.value
+        return out
 
     def read_ms(self, max_records):
         """The multisample path's scan (``bam_utils_multisample.py:257-300``): as ``read_decoded`` with ``newrun`` (that path's run

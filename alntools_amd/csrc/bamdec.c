@@ -39,6 +39,8 @@ typedef struct bd_handle {
     int eof;
     /* header */
     char* text; int32_t l_text; int32_t n_ref; char** names; int32_t* lens;
+    char* ref_blob; size_t ref_blob_len;
+    void* scratch; size_t scratch_cap;          /* bd_read_tuples: the decoded fields of one chunk of records */       /* every name with its NUL, back to back (bd_references; made on demand) */
     /* the (trimmed) name of the latest record that passed the filter */
     uint8_t* last; size_t last_cap; int32_t last_len; int has_last;
     /* multisample (bd_read_ms): the cell ids of the runs the last call started, back to back, and where each begins */
@@ -157,14 +159,14 @@ static int need(bd_handle* h, size_t n) {
 static inline int32_t rd_i32(const uint8_t* p) { int32_t v; memcpy(&v, p, 4); return v; }   /* (little-endian hosts only, like the rest of the repo) */
 
 /* ---- API ------------------------------------------------------------------------------------------------------- */
-int bd_abi_version(void) { return 1; }
+int bd_abi_version(void) { return 2; }
 
 void bd_close(bd_handle* h) {
     if (!h) return;
     if (h->f) fclose(h->f);
     free(h->raw); free(h->buf); free(h->text); free(h->last); free(h->cells); free(h->cell_off);
     if (h->names) { for (int32_t i = 0; i < h->n_ref; ++i) free(h->names[i]); free(h->names); }
-    free(h->lens);
+    free(h->lens); free(h->ref_blob); free(h->scratch);
     free(h);
 }
 
@@ -210,6 +212,21 @@ int32_t bd_n_references(const bd_handle* h) { return h ? h->n_ref : 0; }
 const char* bd_reference_name(const bd_handle* h, int32_t i) { return (h && i >= 0 && i < h->n_ref) ? h->names[i] : NULL; }
 int32_t bd_reference_length(const bd_handle* h, int32_t i) { return (h && i >= 0 && i < h->n_ref) ? h->lens[i] : 0; }
 const char* bd_header_text(const bd_handle* h) { return h ? h->text : NULL; }
+
+int bd_references(bd_handle* h, const char** blob, size_t* blob_len, const int32_t** lens) {
+    if (!h || !blob || !blob_len || !lens) return BD_ERR_ARG;
+    if (!h->ref_blob) {
+        size_t total = 1;
+        for (int32_t i = 0; i < h->n_ref; ++i) total += strlen(h->names[i]) + 1;
+        char* b = (char*)malloc(total);
+        if (!b) return fail(h, BD_ERR_MEM, "out of memory");
+        size_t at = 0;
+        for (int32_t i = 0; i < h->n_ref; ++i) { const size_t l = strlen(h->names[i]) + 1; memcpy(b + at, h->names[i], l); at += l; }
+        h->ref_blob = b; h->ref_blob_len = at;
+    }
+    *blob = h->ref_blob; *blob_len = h->ref_blob_len; *lens = h->lens;
+    return BD_OK;
+}
 
 /* Up to max_records records.  Arrays of max_records elements each; *n_out = records written (0 = end of file).
  * valid[i] = the record passes bam_utils.py:264-270; head[i] = it is valid and its (trimmed, if trim != 0) name differs from
@@ -264,6 +281,53 @@ int bd_read(bd_handle* h, size_t max_records, int trim, uint16_t* flag, int32_t*
         ++n;
     }
     *n_out = n;
+    return BD_OK;
+}
+
+/* The record tuples of include/ecb.h straight from the file (what tuples.TupleEncoder.encode_decoded makes of bd_read's arrays):
+ * read_id = running count of read heads (*cur carries it across calls; 0xFFFFFFFF = no read yet, which is also what records
+ * before the first head get), locus / haplotype looked up from the reference id of VALID records (others: reference 0),
+ * hapflag = the 12 BAM flag bits | ECB_FLAG_MATE_OTHER_REF | ECB_FLAG_NEXT_POS_NEG | haplotype << 16, pos as it is. */
+#define TUPLE_CHUNK 65536
+int bd_read_tuples(bd_handle* h, size_t max_records, int trim, const uint32_t* tid2locus, const uint32_t* tid2hap, int32_t n_ref,
+                   uint32_t* cur, uint32_t* read_id, uint32_t* locus, uint32_t* hapflag, int32_t* pos, size_t* n_out, size_t* n_valid) {
+    if (!h || !cur || !read_id || !locus || !hapflag || !pos || !n_out || !n_valid || n_ref < 0 || (n_ref && (!tid2locus || !tid2hap))) return BD_ERR_ARG;
+    const size_t per = sizeof(uint16_t) + 3 * sizeof(int32_t) + 2;           /* flag, tid, next_tid, next_pos, valid, head */
+    if (h->scratch_cap < TUPLE_CHUNK * per) {
+        void* ns = realloc(h->scratch, TUPLE_CHUNK * per);
+        if (!ns) return fail(h, BD_ERR_MEM, "out of memory");
+        h->scratch = ns; h->scratch_cap = TUPLE_CHUNK * per;
+    }
+    int32_t* tid = (int32_t*)h->scratch;
+    int32_t* ntid = tid + TUPLE_CHUNK;
+    int32_t* npos = ntid + TUPLE_CHUNK;
+    uint16_t* flag = (uint16_t*)(npos + TUPLE_CHUNK);
+    uint8_t* valid = (uint8_t*)(flag + TUPLE_CHUNK);
+    uint8_t* head = valid + TUPLE_CHUNK;
+    size_t n = 0, nv = 0;
+    uint32_t c = *cur;
+    while (n < max_records) {
+        const size_t want = max_records - n < TUPLE_CHUNK ? max_records - n : TUPLE_CHUNK;
+        size_t got = 0;
+        const int rc = bd_read(h, want, trim, flag, tid, pos + n, ntid, npos, valid, head, &got);
+        if (rc != BD_OK) return rc;
+        if (got == 0) break;
+        for (size_t i = 0; i < got; ++i) {
+            c += head[i];                                                    /* (0xFFFFFFFF + 1 = 0: the first read) */
+            uint32_t l = 0, hp = 0;
+            if (n_ref) {
+                const int32_t t = valid[i] ? tid[i] : 0;
+                if (t < 0 || t >= n_ref) return fail(h, BD_ERR_FORMAT, "a mapped record names a reference the header does not have");
+                l = tid2locus[t]; hp = tid2hap[t];
+            } else if (valid[i]) return fail(h, BD_ERR_FORMAT, "a mapped record in a file without references");
+            read_id[n + i] = c; locus[n + i] = l;
+            hapflag[n + i] = (flag[i] & 0xFFFu) | (tid[i] != ntid[i] ? 0x1000u : 0u) | (npos[i] < 0 ? 0x2000u : 0u) | (hp << 16);
+            nv += valid[i];
+        }
+        n += got;
+        if (got < want) break;
+    }
+    *cur = c; *n_out = n; *n_valid = nv;
     return BD_OK;
 }
 

@@ -30,6 +30,9 @@ int32_t bd_n_references(const bd_handle* h);
 const char* bd_reference_name(const bd_handle* h, int32_t i);
 int32_t bd_reference_length(const bd_handle* h, int32_t i);
 const char* bd_header_text(const bd_handle* h);
+/* All references in one call (a transcriptome BAM has hundreds of thousands): the names back to back, each with its NUL
+ * (*blob_len bytes in all), and the lengths; both owned by the handle. */
+int bd_references(bd_handle* h, const char** blob, size_t* blob_len, const int32_t** lens);
 /* Up to max_records records in file order into caller-owned arrays of max_records elements; *n_out = 0 at the end of the file.
  * flag, tid (refID), pos, next_tid, next_pos: the raw BAM fields (alignment.flag, reference_id, reference_start,
  * next_reference_id, next_reference_start).  valid[i] = 1 if the record passes the reference's filter (bam_utils.py:264-270).
@@ -38,6 +41,13 @@ const char* bd_header_text(const bd_handle* h);
  * (bam_utils.py:289-320).  The previous name is kept across calls. */
 int bd_read(bd_handle* h, size_t max_records, int trim, uint16_t* flag, int32_t* tid, int32_t* pos, int32_t* next_tid,
             int32_t* next_pos, uint8_t* valid, uint8_t* head, size_t* n_out);
+/* The same records as the tuples ecb_push takes (include/ecb.h), without a pass through host arrays of BAM fields: read_id
+ * counts the read heads (*cur: the id of the latest read started, 0xFFFFFFFF before the first; carried across calls by the
+ * caller), locus / haplotype come from tid2locus / tid2hap (n_ref entries: the header maps of bam_utils.py:561-633) for valid
+ * records and from reference 0 for the others, hapflag = flag & 0xFFF | ECB_FLAG_MATE_OTHER_REF | ECB_FLAG_NEXT_POS_NEG |
+ * haplotype << 16, pos = reference_start.  *n_valid = valid records among the *n_out written. */
+int bd_read_tuples(bd_handle* h, size_t max_records, int trim, const uint32_t* tid2locus, const uint32_t* tid2hap, int32_t n_ref,
+                   uint32_t* cur, uint32_t* read_id, uint32_t* locus, uint32_t* hapflag, int32_t* pos, size_t* n_out, size_t* n_valid);
 
 /* The multisample path's scan (alntools/bam_utils_multisample.py:257-300): as bd_read, but newrun[i] follows that path's run rule
  * -- the tracked name starts cut at its first space and becomes the WHOLE name of every record that starts a later run (:288-292)

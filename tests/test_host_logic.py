@@ -109,7 +109,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     assert declared == set(bamdec.SYMBOLS), declared ^ set(bamdec.SYMBOLS)
     for s in declared:
         assert hasattr(bamdec.lib(), s), s
-    assert bamdec.lib().bd_abi_version() == 1
+    assert bamdec.lib().bd_abi_version() == 2
 
 
 def test_plain_c_program_links_against_the_abi(tmp_path):
@@ -261,10 +261,21 @@ def test_native_bam_decoder_yields_the_tuples_of_the_python_reader(golden_dir, t
         finally:
             bam_utils.BATCH_RECORDS = old
         py.close(); nat.close()
+        # ... and through the decoded BAM fields + the encoder's own arithmetic (read_decoded / encode_decoded), the route of
+        # encoders that are not the plain TupleEncoder
+        nat = bamdec.NativeBamReader(bam, threads=2)
+        enc2, fields = TupleEncoder(m), []
+        while True:
+            d = nat.read_decoded(batch)
+            if d is None:
+                break
+            fields.append({k: np.array(v) for k, v in enc2.encode_decoded(**d).items()})
+        nat.close()
         for k in ("read_id", "locus", "hapflag", "pos"):
-            a = np.concatenate([t[k] for t in want]); b = np.concatenate([t[k] for t in got])
-            assert len(a) == len(recs) and np.array_equal(a, b), (name, k)
-        assert sum(t["n_valid"] for t in want) == sum(t["n_valid"] for t in got)
+            a = np.concatenate([t[k] for t in want]); b = np.concatenate([t[k] for t in got]); c = np.concatenate([t[k] for t in fields])
+            assert len(a) == len(recs) and np.array_equal(a, b) and np.array_equal(a, c), (name, k)
+            assert all(t[k].dtype == w[k].dtype for t, w in zip(got, want)), k
+        assert sum(t["n_valid"] for t in want) == sum(t["n_valid"] for t in got) == sum(t["n_valid"] for t in fields)
     with pytest.raises((IOError, ValueError)):
         bamdec.NativeBamReader(os.path.join(golden_dir, "g1_edge.json"))
 
