@@ -2874,6 +2874,15 @@ int ms_reduce(ecb_handle* h, const u32* ec_of_slot) {
     return ECB_OK;
 }
 
+// exported entries number their first reads from the shard's own 0 (or from the read_base given at export): move them on by `base`
+__global__ void k_rebase(Entry* e, u64 n, u32 base, u32 limit, Counters* ctr) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 first = ~e[i].first_inv;
+    if (first >= limit) { atomicOr(&ctr->err, ERR_CONTRACT); return; }     // (would run past 2^32 - 2 reads)
+    e[i].first_inv = ~(first + base);
+}
+
 // ---- finalize per key range (multi-GPU): every rank ranks and emits the ECs of its own key range, the root only puts the pieces
 // in the order of first appearance.  The rank of an EC = the number of ECs whose first read comes before its own
 // (bam_utils.py:682-698): a bitmap over the reads, marked from every piece's first reads, and its prefix popcount.
@@ -3451,6 +3460,18 @@ int ecb_table_merge_batch_device(ecb_handle* h, uint32_t n_tables, const void* c
     rc = sync_counters(h);
     if (rc != ECB_OK) return rc;
     if (h->hctr.n_queue) return fail(h, ECB_ERR_TABLE_FULL, "internal: merge found no slot in a half-empty table");
+    return ECB_OK;
+}
+
+int ecb_table_rebase_device(ecb_handle* h, void* d_entries, uint64_t n_entries, uint64_t read_base) {
+    if (!h || (n_entries && !d_entries)) return ECB_ERR_ARG;
+    if (read_base >= (1ull << 32) - 1) return fail(h, ECB_ERR_LIMIT, "more than 2^32-2 reads in total");
+    if (!n_entries || !read_base) return ECB_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    // (no wait: ordered on the handle's stream, ahead of a merge or adopt on this handle; an entry that would pass the limit is
+    //  reported by the next call that reads the device counters, as ECB_ERR_CONTRACT)
+    k_rebase<<<nblk(n_entries, TPB), TPB, 0, h->stream>>>((Entry*)d_entries, n_entries, (u32)read_base, (u32)((1ull << 32) - 1 - read_base), h->ctr);
+    h->ctr_synced = false;
     return ECB_OK;
 }
 

@@ -18,7 +18,7 @@ export), then
    without hashing (``ecb_table_adopt_device``) and finalizes.
 
 The functions only need an *engine* with ``table_sizes/counters/table_export/table_export_parts/table_merge(_many)/
-table_adopt(_many)/add_counters/finalize_range/assemble_ranges`` -- :class:`GpuEngine` wraps an :class:`alntools_amd.ecb.EcBuilder`; the CPU ``gloo`` tests
+table_adopt(_many)/table_rebase/add_counters/finalize_range/assemble_ranges`` -- :class:`GpuEngine` wraps an :class:`alntools_amd.ecb.EcBuilder`; the CPU ``gloo`` tests
 plug in an oracle-backed engine.
 """
 from __future__ import annotations
@@ -96,6 +96,11 @@ class GpuEngine(object):
 
     def table_adopt(self, ent, n_entries, prs, n_pairs):
         self.b.table_adopt_device(ent, n_entries, prs, n_pairs)
+
+    def table_rebase(self, ent, n_entries, read_base):
+        """First reads of exported entries moved on by ``read_base`` (in place, ahead of a merge on this engine) -> ``ent``."""
+        self.b.table_rebase_device(ent, n_entries, read_base)
+        return ent
 
     # multisample across GPUs
     def ec_keys(self, n_ecs):
@@ -190,6 +195,9 @@ class HostStagedEngine(object):
     def table_merge(self, ent, n, prs, m):
         self.e.table_merge(self._up(ent), n, self._up(prs), m)
 
+    def table_rebase(self, ent, n, read_base):
+        return self.e.table_rebase(self._up(ent), n, read_base) if read_base and n else ent     # (stays on the device: _up is a no-op then)
+
     def table_merge_many(self, tables):
         self.e.table_merge_many([(self._up(a), n, self._up(b), m) for a, n, b, m in tables])
 
@@ -225,27 +233,26 @@ def _p2p(ops):
 def exchange_and_merge(engine, make_part_engine, make_root_engine, group=None, root=0, finalize_ranges=False):
     """All ranks call this after pushing their shard.  Returns the merged engine on ``root`` (ready to finalize; already
     finalized with ``finalize_ranges``, where ``finalize()`` only reports the sizes), ``None`` elsewhere.  Two small
-    all-gathers (sizes) and two rounds of point-to-point messages; see the module text."""
+    all-gathers (the cuts and read counts before the first exchange, the sizes of the merged ranges before the second) and two
+    rounds of point-to-point messages; see the module text."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = engine.device
-    ne, npairs, nreads = engine.table_sizes()
-    n_all, n_valid, _ = engine.counters()
-    mine = torch.tensor([ne, npairs, nreads, n_all, n_valid], dtype=torch.int64, device=dev)
-    sizes = torch.empty(world * 5, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(sizes, mine, group=group)
-    sizes = sizes.view(world, 5).cpu().tolist()
-    read_base = sum(s[2] for s in sizes[:rank])
 
-    # 1. cut by key range, range q -> rank q
-    ent, prs, eoff, poff = engine.table_export_parts(read_base, world)
-    cuts = torch.tensor([eoff[q + 1] - eoff[q] for q in range(world)] + [poff[q + 1] - poff[q] for q in range(world)],
-                        dtype=torch.int64, device=dev)
-    allcuts = torch.empty(world * 2 * world, dtype=torch.int64, device=dev)
+    # 1. cut by key range, range q -> rank q.  First reads are numbered from the shard's own 0: where a shard starts in the run
+    # is only known after the exchange of sizes, which is the same one that announces the cuts (one all-gather, not two).
+    ent, prs, eoff, poff = engine.table_export_parts(0, world)
+    n_all, n_valid, nreads = engine.counters()
+    cuts = torch.tensor([eoff[q + 1] - eoff[q] for q in range(world)] + [poff[q + 1] - poff[q] for q in range(world)] +
+                        [nreads, n_all, n_valid], dtype=torch.int64, device=dev)
+    width = 2 * world + 3
+    allcuts = torch.empty(world * width, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(allcuts, cuts, group=group)
-    allcuts = allcuts.view(world, 2 * world).cpu().tolist()
+    allcuts = allcuts.view(world, width).cpu().tolist()
     in_e = [allcuts[r][rank] for r in range(world)]
     in_p = [allcuts[r][world + rank] for r in range(world)]
+    read_base = [sum(allcuts[x][2 * world] for x in range(r)) for r in range(world)]
+    totals = (sum(c[2 * world + 1] for c in allcuts), sum(c[2 * world + 2] for c in allcuts), sum(c[2 * world] for c in allcuts))
     piece_e = [None] * world
     piece_p = [None] * world
     ops = []
@@ -268,12 +275,11 @@ def exchange_and_merge(engine, make_part_engine, make_root_engine, group=None, r
     if dev.type == "cuda":
         torch.cuda.current_stream(dev).synchronize()
 
-    # 2. merge my key range, in rank order (= stream order)
+    # 2. merge my key range, in rank order (= stream order), first reads moved to the run's numbering
     part = make_part_engine()
-    part.table_merge_many([(piece_e[r], in_e[r], piece_p[r], in_p[r]) for r in range(world) if in_e[r]])
+    part.table_merge_many([(part.table_rebase(piece_e[r], in_e[r], read_base[r]), in_e[r], piece_p[r], in_p[r]) for r in range(world) if in_e[r]])
     del piece_e, piece_p, ent, prs
 
-    totals = (sum(s[3] for s in sizes), sum(s[4] for s in sizes), sum(s[2] for s in sizes))
     if finalize_ranges:
         return _finalize_ranges(part, make_root_engine, totals, world, rank, dev, group, root)
 

@@ -30,7 +30,7 @@ SYMBOLS = ("ecb_abi_version", "ecb_device_count", "ecb_create", "ecb_destroy", "
            "ecb_export_read_ec", "ecb_table_sizes",
            "ecb_table_export_device", "ecb_table_merge_device", "ecb_table_export_parts_device",
            "ecb_table_adopt_device", "ecb_table_merge_batch_device", "ecb_table_adopt_batch_device",
-           "ecb_export_firsts_device", "ecb_assemble_ranges_device",
+           "ecb_export_firsts_device", "ecb_assemble_ranges_device", "ecb_table_rebase_device",
            "ecb_export_ec_keys_device", "ecb_ms_local_triples_device", "ecb_ms_adopt_triples_device", "ecb_counters", "ecb_add_counters", "ecb_profile",
            "ecb_profile_read", "ecb_csr_to_hapcsc_device", "ecb_hapcsc_to_csr_device")
 
@@ -105,6 +105,7 @@ def load():
     lib.ecb_table_merge_device.argtypes = [vp, vp, u64, vp, u64]
     lib.ecb_table_export_parts_device.argtypes = [vp, vp, vp, u64, C.c_uint32, C.POINTER(u64), C.POINTER(u64)]
     lib.ecb_table_adopt_device.argtypes = [vp, vp, u64, vp, u64]
+    lib.ecb_table_rebase_device.argtypes = [vp, vp, u64, u64]
     for f in (lib.ecb_table_merge_batch_device, lib.ecb_table_adopt_batch_device):
         f.argtypes = [vp, C.c_uint32, C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(u64)]
     lib.ecb_export_ec_keys_device.argtypes = [vp, vp]
@@ -335,6 +336,10 @@ class EcBuilder(object):
 
     def table_adopt_batch_device(self, tables):
         self._batch(self._lib.ecb_table_adopt_batch_device, tables)
+
+    def table_rebase_device(self, entries, n_entries, read_base):
+        """Exported entries (device tensor), in place: first reads moved on by ``read_base``; ordered ahead of a merge on this handle."""
+        self._chk(self._lib.ecb_table_rebase_device(self._h, _dev_ptr(entries), n_entries, read_base))
 
     def table_adopt_device(self, entries, n_entries, pairs, n_pairs):
         self._chk(self._lib.ecb_table_adopt_device(self._h, _dev_ptr(entries), n_entries, _dev_ptr(pairs), n_pairs))

@@ -190,6 +190,10 @@ int ecb_table_export_parts_device(ecb_handle* h, void* d_entries, void* d_pairs,
                                   uint64_t* entry_offsets, uint64_t* pair_offsets);
 int ecb_table_adopt_device(ecb_handle* h, const void* d_entries, uint64_t n_entries,
                            const void* d_pairs, uint64_t n_pairs);
+/* Exported entries carry first-read indices counted from read_base of their export; when the shard's place in the run is only
+ * known later (after the one exchange of sizes), the receiver moves them on: first += read_base for n_entries entries, in
+ * place, ordered on h's stream (no wait) ahead of ecb_table_merge_device / ecb_table_adopt_device on the same handle. */
+int ecb_table_rebase_device(ecb_handle* h, void* d_entries, uint64_t n_entries, uint64_t read_base);
 /* Several tables in one call, in the order given (arrays of n_tables device pointers / sizes): the kernels queue up
  * behind each other and the host waits once, not once per table. */
 int ecb_table_merge_batch_device(ecb_handle* h, uint32_t n_tables, const void* const* d_entries, const uint64_t* n_entries,

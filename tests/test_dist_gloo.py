@@ -91,6 +91,13 @@ class OracleEngine(object):
             poff.append(len(prs))
         return (torch.tensor(ent or [0] * 4, dtype=torch.int64), torch.tensor(prs or [0], dtype=torch.int64), eoff, poff)
 
+    def table_rebase(self, ent, n_entries, read_base):
+        e = ent.numpy().view(np.uint64).reshape(-1, 4)[:n_entries]        # (in place: a view of the tensor's memory)
+        first = (~(e[:, 2] >> np.uint64(32))) & np.uint64(0xFFFFFFFF)
+        assert int(first.max(initial=0)) + read_base < 0xFFFFFFFF
+        e[:, 2] = (e[:, 2] & np.uint64(0xFFFFFFFF)) | (((~(first + np.uint64(read_base))) & np.uint64(0xFFFFFFFF)) << np.uint64(32))
+        return ent
+
     def table_adopt(self, ent, n_entries, prs, n_pairs):
         before = len(self.table)
         self.table_merge(ent, n_entries, prs, n_pairs)

@@ -113,13 +113,14 @@ def _pieces_of(spec, world, dev):
     from alntools_amd import dist as ecdist
     from alntools_amd import ecb, synth
     R = spec.n_reads
-    shards, base, cuts, totals = [], 0, [], [0, 0, 0]
+    shards, base, bases, cuts, totals = [], 0, [], [], [0, 0, 0]
     for r in range(world):
         t = synth.generate(spec, r * R // world, (r + 1) * R // world, device=dev)
         b = ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=1 << 12)
         b.push_device(t["read_id"], t["locus"], t["hapflag"])
         eng = ecdist.GpuEngine(b, dev)
-        cuts.append(eng.table_export_parts(base, world))
+        cuts.append(eng.table_export_parts(0, world))           # first reads from the shard's own 0, moved on by the receiver
+        bases.append(base)
         a, v, n = eng.counters()
         totals = [totals[0] + a, totals[1] + v, totals[2] + n]
         base += n
@@ -127,7 +128,8 @@ def _pieces_of(spec, world, dev):
     pieces = []
     for q in range(world):
         part = ecdist.GpuEngine(ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=1 << 12), dev)
-        part.table_merge_many([(ent[eo[q] * 4:], eo[q + 1] - eo[q], prs[po[q]:], po[q + 1] - po[q]) for ent, prs, eo, po in cuts if eo[q + 1] > eo[q]])
+        part.table_merge_many([(part.table_rebase(ent[eo[q] * 4:eo[q + 1] * 4], eo[q + 1] - eo[q], base), eo[q + 1] - eo[q], prs[po[q]:], po[q + 1] - po[q])
+                               for (ent, prs, eo, po), base in zip(cuts, bases) if eo[q + 1] > eo[q]])
         pieces.append(part.finalize_range(*totals))
         part.b.close()
     for b in shards:
@@ -205,3 +207,17 @@ def test_assembling_refuses_overlapping_or_malformed_pieces():
         e.assemble_ranges(pieces, *totals)
     assert ei.value.code == -6
     e.b.close()
+    # moving first reads on: not past 2^32 - 2 reads
+    src = ecdist.GpuEngine(ecb.EcBuilder(spec.n_loci, spec.n_haps), dev)
+    src.b.push_device(t["read_id"], t["locus"], t["hapflag"])
+    ent, prs = src.table_export(0)
+    ne, npairs, _ = src.table_sizes()
+    e = fresh()
+    with pytest.raises(ecb.EcbError) as ei:
+        e.table_rebase(ent, ne, (1 << 32) - 1)
+    assert ei.value.code == -8
+    e.table_rebase(ent, ne, (1 << 32) - 20)                 # (queued; some first reads of the 100 are beyond 18)
+    with pytest.raises(ecb.EcbError) as ei:
+        e.table_merge(ent, ne, prs, npairs)
+    assert ei.value.code == -5
+    e.b.close(); src.b.close()
