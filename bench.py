@@ -355,7 +355,7 @@ def main():
             "config": {"workload": desc, "reads": R, "loci": T, "haplotypes": H, "paired_end": paired,
                        "records": total_records, "valid_alignments": total_valid, "reads_with_alignments": total_reads,
                        "ecs": sizes.get("n_ecs"), "nnz_a": sizes.get("nnz_a"),
-                       "sharding": "contiguous reads over %d GPU(s)%s" % (world, ", per-rank EC tables cut into key ranges, exchanged point-to-point over RCCL, merged per range, gathered on rank 0" if world > 1 else ""),
+                       "sharding": "contiguous reads over %d GPU(s)%s" % (world, ", per-rank EC tables cut into key ranges, exchanged point-to-point over RCCL, merged and finalized per range, rows assembled on rank 0" if world > 1 else ""),
                        "generate_s": round(t_gen, 2), "exactness_pass": exact},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
