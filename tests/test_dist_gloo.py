@@ -252,6 +252,21 @@ def test_multi_rank_merge_equals_single_process(tmp_path, world, paired, protoco
     assert int(got["n_reads"]) == t["n_reads"]
 
 
+@pytest.mark.parametrize("protocol", ["ranges", "finalize_ranges"])
+def test_more_ranks_than_reads(tmp_path, protocol):
+    """Shards without a read and key ranges without an EC: 4 ranks, 3 reads."""
+    spec_args = dict(n_reads=3, n_loci=50, n_haps=2, paired=False)
+    out = str(tmp_path / "merged.npz")
+    mp.spawn(_worker, args=(4, _free_port(), spec_args, out, protocol), nprocs=4, join=True)
+    got = np.load(out)
+    spec = synth.SynthSpec(**spec_args)
+    t = synth.generate(spec, 0, spec.n_reads)
+    exp = orc.ec_from_tuples(t["read_id"], t["locus"], t["hapflag"], spec.n_loci, spec.n_haps)
+    for k in ("indptr", "indices", "data", "count"):
+        assert np.array_equal(got[k], exp[k]), k
+    assert int(got["n_reads"]) == t["n_reads"]
+
+
 def _range_worker(rank, world, port, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -171,6 +171,27 @@ def test_ranges_finalized_apart_assemble_to_the_result_of_one_handle(world):
     root.b.close()
 
 
+def test_ranges_assemble_with_empty_shards_and_empty_ranges():
+    """4 ranks, 3 reads: shards that hold nothing, key ranges that receive nothing."""
+    from alntools_amd import dist as ecdist
+    from alntools_amd import ecb, synth
+    dev = torch.device("cuda:0")
+    spec = synth.SynthSpec(3, 50, 2, paired=False)
+    pieces, totals = _pieces_of(spec, 4, dev)
+    assert 0 < len(pieces) <= 3
+    root = ecdist.GpuEngine(ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=1 << 10), dev)
+    s = root.assemble_ranges(pieces, *totals)
+    whole = synth.generate(spec, 0, spec.n_reads, device=dev)
+    with ecb.EcBuilder(spec.n_loci, spec.n_haps) as one:
+        one.push_device(whole["read_id"], whole["locus"], whole["hapflag"])
+        assert one.finalize() == s
+        exp = one.export()
+    got = root.b.export()
+    for k in exp:
+        assert np.array_equal(got[k], exp[k]), k
+    root.b.close()
+
+
 def test_assembling_refuses_overlapping_or_malformed_pieces():
     from alntools_amd import dist as ecdist
     from alntools_amd import ecb, synth
