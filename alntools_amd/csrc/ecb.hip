@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cstddef>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -38,6 +39,7 @@ namespace {
 
 typedef unsigned long long u64;
 typedef unsigned int u32;
+typedef unsigned short u16;
 
 constexpr int TPB = 256;             // threads per workgroup (4 waves of 64)
 constexpr u32 MAX_PROBE = 256;       // EC-table probes before a read is deferred to k_slow
@@ -76,6 +78,8 @@ struct alignas(64) Slot {
     uint2 pair[INL];                 // key pairs 0 .. min(n, INL): (locus, haplotype mask), in no particular order
 };
 static_assert(sizeof(Slot) == 64, "one EC per 64-byte line");
+static_assert(offsetof(Slot, n1) == 8 && offsetof(Slot, off) == 12 && offsetof(Slot, count) == 16 && offsetof(Slot, first_inv) == 20,
+              "k_count_bins reads {n1, off} and {count, first_inv} as 8-byte words");
 // what ranks exchange (ecb_table_export_* / merge / adopt): 32 bytes per EC, its key pairs packed in a list of their own
 struct Entry {
     u64 lo, reserved;
@@ -1052,7 +1056,8 @@ __global__ __launch_bounds__(1024) void k_sum_counts(const u32* wave_counts, u64
 // ---------------------------------------------------------------------------------------------
 constexpr u32 BIN_BITS = 13;                   // slots per range = LDS bins of one k_count_bins workgroup: 2^13 up to a table of
 constexpr u32 MAX_BIN_BITS = 15;               // 2^26 slots, 2^14 and 2^15 (128 KB of LDS) beyond -- a run-time argument `bb`
-constexpr u32 MAX_BUCKETS = 8192;              // LDS histogram of the partition passes  (=> at most 2^28 slots)
+constexpr u32 MAX_BUCKETS = 8192;
+static_assert(MAX_BIN_BITS <= 16, "a slot's index within its range is kept in 16 bits (k_part_scatter*, k_count_bins)");              // LDS histogram of the partition passes  (=> at most 2^28 slots)
 
 // Partition passes: few, fat workgroups.  Every workgroup keeps one open line per range in flight (2 048 of them at C3); with
 // 512 workgroups of 1 024 threads those lines stay in L2 until they are full far more often than with 1 024 x 256
@@ -1074,7 +1079,7 @@ __global__ __launch_bounds__(TPB_PART) void k_part_hist(const u32* read_slot, u6
 }
 
 __global__ __launch_bounds__(TPB_PART) void k_part_scatter(const u32* read_slot, u64 n_reads, u32 n_buckets, u32 bb, const u32* offs,
-                                                      u32* pairs) {
+                                                      u16* pairs) {
     extern __shared__ u32 sh[];
     const u64 G = gridDim.x, g = blockIdx.x, per = (n_reads + G - 1) / G;
     const u64 r0 = g * per, r1 = min(r0 + per, n_reads);
@@ -1092,19 +1097,21 @@ __global__ __launch_bounds__(TPB_PART) void k_part_scatter(const u32* read_slot,
 #pragma unroll
         for (int k = 0; k < 4; ++k) if (s[k] != PENDING) pos[k] = atomicAdd(&sh[s[k] >> bb], 1u);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) if (s[k] != PENDING) pairs[pos[k]] = s[k];
+        for (int k = 0; k < 4; ++k) if (s[k] != PENDING) pairs[pos[k]] = (u16)(s[k] & ((1u << bb) - 1u));
     }
 }
 
 // (Elements are slot ids alone: the first read of an EC is kept current by k_stream itself -- the lookup has the slot's line in
-//  hand and adds an atomicMax only when its read is earlier than what the line shows -- so nothing but counts is left here.)
+//  hand and adds an atomicMax only when its read is earlier than what the line shows -- so nothing but counts is left here.
+//  And within its range a slot id is its low `bb` <= 15 bits: the partitioned elements are 2 bytes each, half the bytes to
+//  write here and to read in k_count_bins.)
 // The scatter with its elements sorted by range in LDS first: a workgroup takes STAGE reads at a time, ranks them within their
 // range (LDS counters), lays them out range by range in LDS and writes them from there -- elements of one range leave in
 // runs of consecutive addresses (STAGE / n_buckets of them on average) instead of one 8-byte store per lane and range.
 constexpr u32 STAGE = 8 * TPB_PART;            // 8 192 elements = 32 KB of LDS
 constexpr u32 STAGE_MAX_BUCKETS = 4096;        // 3 x 16 KB of counters / starts / cursors beside the stage
 __global__ __launch_bounds__(TPB_PART) void k_part_scatter_staged(const u32* read_slot, u64 n_reads, u32 n_buckets, u32 bb, const u32* offs,
-                                                             u32* pairs) {
+                                                             u16* pairs) {
     extern __shared__ u32 sh[];                   // cnt[nb] | start[nb] | gcur[nb] | stage[STAGE]
     u32 *cnt = sh, *start = sh + n_buckets, *gcur = sh + 2 * n_buckets;
     u32* stage = sh + 3 * n_buckets;
@@ -1145,7 +1152,7 @@ __global__ __launch_bounds__(TPB_PART) void k_part_scatter_staged(const u32* rea
         for (u32 i = tid; i < n_here; i += TPB_PART) {
             const u32 e = stage[i];
             const u32 b = e >> bb;
-            pairs[gcur[b] + (i - start[b])] = e;
+            pairs[gcur[b] + (i - start[b])] = (u16)(e & ((1u << bb) - 1u));
         }
         __syncthreads();
         for (u32 b = tid; b < n_buckets; b += TPB_PART) gcur[b] += cnt[b];
@@ -1192,7 +1199,7 @@ __global__ __launch_bounds__(1024) void k_build_work(const u32* starts, u32 n_bu
 }
 // sink (optional): what finalize's k_compact would otherwise find by scanning the whole table -- see the end of the kernel
 struct CompactSink { u32* list; u64 max_list; u64* n_list; u32* bitmap; u64 n_bits; uint2* list_fn; };
-__global__ __launch_bounds__(TPB_COUNT) void k_count_bins(const u32* pairs, const CountWork* work, const u32* n_work, u32 bb, Slot* table, CompactSink sink) {
+__global__ __launch_bounds__(TPB_COUNT) void k_count_bins(const u16* pairs, const CountWork* work, const u32* n_work, u32 bb, Slot* table, CompactSink sink) {
     extern __shared__ u32 cnt[];                           // 2^bb counters
     const u32 N_BINS = 1u << bb;
     if (blockIdx.x >= *n_work) return;                     // (the grid is the list's upper bound: its length never visits the host)
@@ -1204,9 +1211,9 @@ __global__ __launch_bounds__(TPB_COUNT) void k_count_bins(const u32* pairs, cons
     for (u32 i0 = start; i0 < end; i0 += 4 * TPB_COUNT) {
         u32 pr[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {                       // four independent loads in flight per thread
+        for (int k = 0; k < 4; ++k) {                       // four independent loads in flight per thread (eight: no faster)
             const u32 i = i0 + k * TPB_COUNT + threadIdx.x;
-            pr[k] = i < end ? pairs[i] : 0xFFFFFFFFu;
+            pr[k] = i < end ? (u32)pairs[i] : 0xFFFFFFFFu;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1231,16 +1238,22 @@ __global__ __launch_bounds__(TPB_COUNT) void k_count_bins(const u32* pairs, cons
     // exactly the occupied slots of its range, and the first to add to a slot (counts start at zero) puts it on the list of
     // occupied slots, with its first read and key length, and marks that read in the first-appearance bitmap -- the slot's line
     // is in hand here.  finalize then needs no pass over the table (1 GB at 2^24 slots) to find 3.7 M entries.
+    // A whole range with a sink (the usual case) visits every occupied slot's line ONCE: how many there are is known from the LDS
+    // counters alone, so the list positions are handed out first, and then one look at the slot's line (n1, off, count,
+    // first_inv) serves the count update, the list entry and the bitmap -- eight slots' loads in flight per thread.
+    const bool once = sink.list && !wk.shared;
     u32 mine = 0;
     for (u32 q = threadIdx.x; q < N_BINS; q += TPB_COUNT) {
         const u32 c = cnt[q];
         u32 first = 0;
-        if (c) {
+        if (once) first = c != 0u;
+        else if (c) {
             Slot* s = table + (((u64)b << bb) | q);
             if (wk.shared) first = atomicAdd(&s->count, c) == 0u;
             else { s->count += c; first = 1u; }             // the only writer of its slots
         }
-        if (sink.list) { cnt[q] = first; mine += first; }
+        if (sink.list && !once) cnt[q] = first;
+        mine += first;
     }
     if (!sink.list) return;
     __shared__ u32 s_wtot[TPB_COUNT / 64];
@@ -1255,6 +1268,36 @@ __global__ __launch_bounds__(TPB_COUNT) void k_count_bins(const u32* pairs, cons
     }
     __syncthreads();
     u64 at = s_base + s_wtot[threadIdx.x >> 6] + (incl - mine);
+    if (once) {
+        for (u32 q0 = threadIdx.x; q0 < N_BINS; q0 += 8 * TPB_COUNT) {
+            u32 c[8];
+            uint2 vk[8], vc[8];                              // {n1, off} and {count, first_inv}: two 8-byte words of the slot's line
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const u32 q = q0 + k * TPB_COUNT; c[k] = q < N_BINS ? cnt[q] : 0u; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (c[k]) {
+                    const Slot* sl = table + (((u64)b << bb) | (q0 + k * TPB_COUNT));
+                    vk[k] = *reinterpret_cast<const uint2*>(&sl->n1); vc[k] = *reinterpret_cast<const uint2*>(&sl->count);
+                }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (!c[k]) continue;
+                const u64 i = ((u64)b << bb) | (q0 + k * TPB_COUNT);
+                table[i].count = vc[k].x + c[k];
+                if (at < sink.max_list) {
+                    sink.list[at] = (u32)i;
+                    if (sink.list_fn) {
+                        const u32 f = ~vc[k].y;
+                        sink.list_fn[at] = make_uint2(f, vk[k].x - 1u);
+                        if (f < sink.n_bits) atomicOr(&sink.bitmap[f >> 5], 1u << (f & 31u));
+                    }
+                }
+                ++at;
+            }
+        }
+        return;
+    }
     for (u32 q = threadIdx.x; q < N_BINS; q += TPB_COUNT) {
         if (!cnt[q]) continue;
         const u64 i = ((u64)b << bb) | q;
@@ -2783,7 +2826,7 @@ int ensure_counts(ecb_handle* h, const CompactSink* sink = nullptr) {
         }
         const u32 G = (u32)std::min<u64>(PART_G, (R + 4095) / 4096);
         u32 *hist = nullptr, *offs = nullptr;
-        u32* pairs = nullptr;
+        u16* pairs = nullptr;
         u64* d_tot = nullptr;
         POOL(h, P_HIST, hist, (u64)nb * G); POOL(h, P_OFFS, offs, (u64)nb * G);
         POOL(h, P_PAIRS, pairs, R);
