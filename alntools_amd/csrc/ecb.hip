@@ -1828,10 +1828,11 @@ __device__ __forceinline__ u32 block_excl_scan(u32 v, u32* total) {   // over TP
     *total = tot;
     return add + incl - v;
 }
-__global__ __launch_bounds__(TPB) void k_scan_sums(const u32* in, u64 n, u32* sums) {
+// (stride: the input may be one member of an array of small structs -- element i is in[i * stride])
+__global__ __launch_bounds__(TPB) void k_scan_sums(const u32* in, u64 n, u32* sums, u32 stride = 1) {
     const u64 b0 = (u64)blockIdx.x * SCAN_BLOCK;
     u32 s = 0;
-    for (int k = 0; k < SCAN_ITEMS; ++k) { const u64 i = b0 + (u64)threadIdx.x * SCAN_ITEMS + k; if (i < n) s += in[i]; }
+    for (int k = 0; k < SCAN_ITEMS; ++k) { const u64 i = b0 + (u64)threadIdx.x * SCAN_ITEMS + k; if (i < n) s += in[i * stride]; }
     u32 tot; block_excl_scan(s, &tot);
     if (threadIdx.x == 0) sums[blockIdx.x] = tot;
 }
@@ -1846,16 +1847,18 @@ __global__ __launch_bounds__(TPB) void k_scan_top(u32* sums, u64 nb, u64* grand)
     }
     if (threadIdx.x == 0) *grand = carry;
 }
-__global__ __launch_bounds__(TPB) void k_scan_apply(const u32* in, u64 n, const u32* sums, u32* out) {
+__global__ __launch_bounds__(TPB) void k_scan_apply(const u32* in, u64 n, const u32* sums, u32* out, u32 stride = 1) {
     const u64 b0 = (u64)blockIdx.x * SCAN_BLOCK;
     u32 v[SCAN_ITEMS], s = 0;
-    for (int k = 0; k < SCAN_ITEMS; ++k) { const u64 i = b0 + (u64)threadIdx.x * SCAN_ITEMS + k; v[k] = i < n ? in[i] : 0u; s += v[k]; }
+    for (int k = 0; k < SCAN_ITEMS; ++k) { const u64 i = b0 + (u64)threadIdx.x * SCAN_ITEMS + k; v[k] = i < n ? in[i * stride] : 0u; s += v[k]; }
     u32 tot; u32 ex = block_excl_scan(s, &tot) + sums[blockIdx.x];
     for (int k = 0; k < SCAN_ITEMS; ++k) { const u64 i = b0 + (u64)threadIdx.x * SCAN_ITEMS + k; if (i < n) out[i] = ex; ex += v[k]; }
 }
 
+// (slot and row length of rank r go out as one 8-byte word: the scatter is what this kernel costs, and two 4-byte stores to
+//  two arrays were twice the partial lines; k_emit_small, which walks the ranks in order, writes `order` for the later readers)
 __global__ void k_rank(const u32* list, const uint2* list_fn, u64 n, u64 n_bits, const u32* bitmap, const u32* wprefix,
-                       u32* order, u32* rowlen) {
+                       uint2* ord2) {
     const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (e >= n) return;
     const u32 si = list[e];
@@ -1864,8 +1867,7 @@ __global__ void k_rank(const u32* list, const uint2* list_fn, u64 n, u64 n_bits,
     if (f >= n_bits) return;                       // (an EC without a first read: finalize's count check reports it)
     const u32 r = wprefix[f >> 5] + __popc(bitmap[f >> 5] & ((1u << (f & 31u)) - 1u));
     if (r >= n) return;
-    order[r] = si;
-    rowlen[r] = fn.y;
+    ord2[r] = make_uint2(si, fn.y);
 }
 // EC rank of every occupied slot: only the per-read EC ids need it (multisample, ecb_export_read_ec) -- a scatter over the
 // whole table's index space that the single-sample result never reads
@@ -1878,12 +1880,14 @@ __global__ void k_slot_ranks(const u32* order, u64 n, u32* rank_of_slot) {
 // csc -> csr leaves them: bin_utils.py:211).  Short rows: one thread each.  Long rows: queued, one wave each.
 // The indices the host supplied are validated here, once per EC instead of once per record.
 constexpr u32 EMIT_SMALL = 16;
-__global__ __launch_bounds__(TPB) void k_emit_small(const Slot* table, const u32* order, u64 n, const uint2* arena,
+__global__ __launch_bounds__(TPB) void k_emit_small(const Slot* table, const uint2* ord2, u32* order, u64 n, const uint2* arena,
                                                      const u32* indptr, int* indices, int* data, int* counts,
                                                      u32 n_loci, u32 n_haps, u32* big, u32* n_big, Counters* ctr) {
     const u64 e = (u64)blockIdx.x * TPB + threadIdx.x;
     if (e >= n) return;
-    const Slot s = table[order[e]];
+    const u32 si = ord2[e].x;
+    order[e] = si;
+    const Slot s = table[si];
     const u32 sn = s.n1 - 1u;
     counts[e] = (int)s.count;
     if (sn > EMIT_SMALL) { big[atomicAdd(n_big, 1u)] = (u32)e; return; }
@@ -2730,13 +2734,13 @@ void free_results(ecb_handle* h) {   // result buffers live in the pool: nothing
 
 // exclusive scan of u32 values, queued on the handle's stream; the sum (64 bits) is left in *d_total on the device
 // (a sum of 2^32 or more: the caller's limit check, `out` wrapped)
-int excl_scan_dev(ecb_handle* h, const u32* in, u64 n, u32* out, u64* d_total) {
+int excl_scan_dev(ecb_handle* h, const u32* in, u64 n, u32* out, u64* d_total, u32 stride = 1) {
     const u64 nb = std::max<u64>(1, (n + SCAN_BLOCK - 1) / SCAN_BLOCK);
     u32* sums = nullptr;
     POOL(h, P_SUMS, sums, nb);
-    k_scan_sums<<<(unsigned)nb, TPB, 0, h->stream>>>(in, n, sums);
+    k_scan_sums<<<(unsigned)nb, TPB, 0, h->stream>>>(in, n, sums, stride);
     k_scan_top<<<1, TPB, 0, h->stream>>>(sums, nb, d_total);
-    k_scan_apply<<<(unsigned)nb, TPB, 0, h->stream>>>(in, n, sums, out);
+    k_scan_apply<<<(unsigned)nb, TPB, 0, h->stream>>>(in, n, sums, out, stride);
     return ECB_OK;
 }
 // ... and with the sum brought to the host (one wait)
@@ -2943,8 +2947,8 @@ __global__ void k_mark_bits(const PieceDesc* P, u64 n_bits, u32* bitmap, Counter
     if (f >= n_bits) { atomicOr(&ctr->err, ERR_CONTRACT); return; }
     atomicOr(&bitmap[f >> 5], 1u << (f & 31u));
 }
-__global__ void k_piece_place(const PieceDesc* P, u64 n_total, u64 n_bits, const u32* bitmap, const u32* wprefix, u32* src_of, u32* rowlen,
-                              int* counts, Counters* ctr) {
+// (what is known of rank r goes out as ONE 16-byte word {source + 1, row length, count, -}: the scatter is this kernel's cost)
+__global__ void k_piece_place(const PieceDesc* P, u64 n_total, u64 n_bits, const u32* bitmap, const u32* wprefix, uint4* place, Counters* ctr) {
     const PieceDesc d = P[blockIdx.y];
     const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (e >= d.n) return;
@@ -2954,24 +2958,24 @@ __global__ void k_piece_place(const PieceDesc* P, u64 n_total, u64 n_bits, const
     if (s0 < 0 || s1 < s0 || (u64)s1 > d.nnz) { atomicOr(&ctr->err, ERR_CONTRACT); return; }
     const u32 r = wprefix[f >> 5] + __popc(bitmap[f >> 5] & ((1u << (f & 31u)) - 1u));
     if (r >= n_total) return;
-    src_of[r] = (u32)(d.at + e);                         // (two pieces claiming one first read: either; the caller reports it)
-    rowlen[r] = (u32)(s1 - s0);
-    counts[r] = d.counts[e];
+    place[r] = make_uint4((u32)(d.at + e) + 1u, (u32)(s1 - s0), (u32)d.counts[e], 0u);   // (two pieces claiming one first read: either, whole; the caller reports it)
 }
 // One thread per row of the result: neighbours write neighbouring rows, and read rows that follow each other within their piece
 // (a piece is in first-read order itself).
-__global__ void k_piece_rows(const PieceDesc* P, u32 n_pieces, const u32* src_of, u64 n_total, const u32* indptr, int* indices, int* data) {
+__global__ void k_piece_rows(const PieceDesc* P, u32 n_pieces, const uint4* place, u64 n_total, const u32* indptr, int* indices, int* data, int* counts) {
     const u64 r = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (r >= n_total) return;
-    const u32 g = src_of[r];
-    if (g == 0xFFFFFFFFu) return;
+    const uint4 pl = place[r];
+    counts[r] = (int)pl.z;
+    if (pl.x == 0u) return;                             // (no piece claimed this rank: the caller reports it)
+    const u32 g = pl.x - 1u;
     u32 q = 0;
     while (q + 1 < n_pieces && P[q + 1].at <= g) ++q;
     const u64 e = g - P[q].at;
     const int* ip = P[q].indptr;
     const int s0 = ip[e], s1 = ip[e + 1];
     const u32 d0 = indptr[r];
-    if (indptr[r + 1] - d0 != (u32)(s1 - s0)) return;   // (a row length from another claimant: nothing is written past a row)
+    if (indptr[r + 1] - d0 != (u32)(s1 - s0) || pl.y != (u32)(s1 - s0)) return;   // (nothing is ever written past a row)
     const int *sj = P[q].indices, *sd = P[q].data;
     for (int i = s0; i < s1; ++i) { indices[d0 + (u32)(i - s0)] = sj[i]; data[d0 + (u32)(i - s0)] = sd[i]; }
 }
@@ -3204,11 +3208,12 @@ int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
     const u64 total_reads = h->n_reads + h->extra_reads;
     const u64 words = (total_reads + 31) / 32 + 1;
     const u64 nnz_max = std::min<u64>(E * INL + arena_used(h), (1ull << 32) - 1);     // every key pair there can be
-    u32 *bitmap = nullptr, *wpop = nullptr, *wprefix = nullptr, *rowlen = nullptr;
+    u32 *bitmap = nullptr, *wpop = nullptr, *wprefix = nullptr, *ord2_raw = nullptr;
     uint2* list_fn = nullptr;
     u64* d_tot = nullptr;                            // [0] occupied slots, [1] distinct first reads, [2] nnz, [3] long rows (u32)
     POOL(h, P_BITMAP, bitmap, words); POOL(h, P_WPOP, wpop, words); POOL(h, P_WPREFIX, wprefix, words);
-    POOL(h, P_ROWLEN, rowlen, E); POOL(h, P_LISTFN, list_fn, E);
+    POOL(h, P_ROWLEN, ord2_raw, 2 * E); POOL(h, P_LISTFN, list_fn, E);
+    uint2* ord2 = reinterpret_cast<uint2*>(ord2_raw);           // (slot, row length) by rank
     POOL(h, P_ORDER, h->order, E);
     h->rank_of_slot = nullptr;                       // (made on demand: ensure_slot_ranks)
     POOL(h, P_INDPTR, h->indptr, E + 1); POOL(h, P_COUNTS, h->counts, E);
@@ -3237,11 +3242,11 @@ int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
     k_popc<<<nblk(words, TPB), TPB, 0, h->stream>>>(bitmap, words, wpop);
     rc = excl_scan_dev(h, wpop, words, wprefix, d_tot + 1);
     if (rc != ECB_OK) return rc;
-    k_rank<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->list, list_fn, E, total_reads, bitmap, wprefix, h->order, rowlen);
-    rc = excl_scan_dev(h, rowlen, E, h->indptr, d_tot + 2);
+    k_rank<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->list, list_fn, E, total_reads, bitmap, wprefix, ord2);
+    rc = excl_scan_dev(h, ord2_raw + 1, E, h->indptr, d_tot + 2, 2);
     if (rc != ECB_OK) return rc;
     k_set_last<<<1, 1, 0, h->stream>>>(h->indptr + E, d_tot + 2);
-    k_emit_small<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->table, h->order, E, h->arena, h->indptr, h->indices, h->data,
+    k_emit_small<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->table, ord2, h->order, E, h->arena, h->indptr, h->indices, h->data,
                                                        h->counts, h->cfg.n_loci, h->cfg.n_haplotypes, big, d_nbig, h->ctr);
     // long rows, one wave each: a fixed launch that walks the queue (its length stays on the device)
     k_emit_big<<<(unsigned)std::min<u64>(nblk(E * 64, TPB), 2048), TPB, 0, h->stream>>>(h->table, h->order, big, d_nbig, h->arena, h->indptr,
@@ -3307,17 +3312,17 @@ int ecb_assemble_ranges_device(ecb_handle* h, uint32_t n_pieces, const void* con
     HIPCHK(h, hipSetDevice(h->device));
     free_results(h);
     const u64 words = (total_reads + 31) / 32 + 1;
-    u32 *bitmap = nullptr, *wpop = nullptr, *wprefix = nullptr, *rowlen = nullptr, *rank_q = nullptr;
+    u32 *bitmap = nullptr, *wpop = nullptr, *wprefix = nullptr, *place_raw = nullptr;
     u64* d_tot = nullptr;
     POOL(h, P_BITMAP, bitmap, words); POOL(h, P_WPOP, wpop, words); POOL(h, P_WPREFIX, wprefix, words);
-    POOL(h, P_ROWLEN, rowlen, E); POOL(h, P_ORDER, rank_q, E);
+    POOL(h, P_ROWLEN, place_raw, 4 * E);
+    uint4* place = reinterpret_cast<uint4*>(place_raw);         // {source + 1, row length, count, -} by rank
     POOL(h, P_INDPTR, h->indptr, E + 1); POOL(h, P_COUNTS, h->counts, E);
     POOL(h, P_INDICES, h->indices, std::max<u64>(NNZ, 1)); POOL(h, P_DATA, h->data, std::max<u64>(NNZ, 1));
     POOL(h, P_TOTALS, d_tot, 8);
     HIPCHK(h, hipMemsetAsync(bitmap, 0, words * 4, h->stream));
     HIPCHK(h, hipMemsetAsync(d_tot, 0, 8 * sizeof(u64), h->stream));
-    HIPCHK(h, hipMemsetAsync(rowlen, 0, E * 4, h->stream));
-    HIPCHK(h, hipMemsetAsync(rank_q, 0xFF, E * 4, h->stream));       // (source of every row: piece-major EC index)
+    HIPCHK(h, hipMemsetAsync(place_raw, 0, E * 16, h->stream));
     int rc = clear_counters(h);
     if (rc != ECB_OK) return rc;
     std::vector<PieceDesc> desc;
@@ -3337,11 +3342,11 @@ int ecb_assemble_ranges_device(ecb_handle* h, uint32_t n_pieces, const void* con
     k_popc<<<nblk(words, TPB), TPB, 0, h->stream>>>(bitmap, words, wpop);
     rc = excl_scan_dev(h, wpop, words, wprefix, d_tot + 1);
     if (rc != ECB_OK) return rc;
-    k_piece_place<<<grid, TPB, 0, h->stream>>>(d_desc, E, total_reads, bitmap, wprefix, rank_q, rowlen, h->counts, h->ctr);
-    rc = excl_scan_dev(h, rowlen, E, h->indptr, d_tot + 2);
+    k_piece_place<<<grid, TPB, 0, h->stream>>>(d_desc, E, total_reads, bitmap, wprefix, place, h->ctr);
+    rc = excl_scan_dev(h, place_raw + 1, E, h->indptr, d_tot + 2, 4);
     if (rc != ECB_OK) return rc;
     k_set_last<<<1, 1, 0, h->stream>>>(h->indptr + E, d_tot + 2);
-    k_piece_rows<<<nblk(E, TPB), TPB, 0, h->stream>>>(d_desc, (u32)desc.size(), rank_q, E, h->indptr, h->indices, h->data);
+    k_piece_rows<<<nblk(E, TPB), TPB, 0, h->stream>>>(d_desc, (u32)desc.size(), place, E, h->indptr, h->indices, h->data, h->counts);
     u64 tot[8];
     HIPCHK(h, hipMemcpyAsync(tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, h->stream));
     h->ctr_synced = false;
