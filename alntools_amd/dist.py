@@ -223,6 +223,22 @@ class HostStagedEngine(object):
         return self.e.ms_adopt_triples([(self._up(k), self._up(c), self._up(f), n) for k, c, f, n in tables])
 
 
+SECTIONS = None          # measurement only (tools/dist_sections.py): a dict that collects seconds per section of the exchange
+
+
+def _mark(name, dev, t0):
+    """-> now; with SECTIONS set, waits for the device and adds the time since ``t0`` to ``SECTIONS[name]``."""
+    if SECTIONS is None:
+        return 0.0
+    import time
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    t = time.perf_counter()
+    if name is not None:
+        SECTIONS[name] = SECTIONS.get(name, 0.0) + (t - t0)
+    return t
+
+
 def _p2p(ops):
     if not ops:
         return
@@ -241,8 +257,10 @@ def exchange_and_merge(engine, make_part_engine, make_root_engine, group=None, r
 
     # 1. cut by key range, range q -> rank q.  First reads are numbered from the shard's own 0: where a shard starts in the run
     # is only known after the exchange of sizes, which is the same one that announces the cuts (one all-gather, not two).
+    t = _mark(None, dev, 0.0)
     ent, prs, eoff, poff = engine.table_export_parts(0, world)
     n_all, n_valid, nreads = engine.counters()
+    t = _mark("counts + cut by key range", dev, t)
     cuts = torch.tensor([eoff[q + 1] - eoff[q] for q in range(world)] + [poff[q + 1] - poff[q] for q in range(world)] +
                         [nreads, n_all, n_valid], dtype=torch.int64, device=dev)
     width = 2 * world + 3
@@ -253,6 +271,7 @@ def exchange_and_merge(engine, make_part_engine, make_root_engine, group=None, r
     in_p = [allcuts[r][world + rank] for r in range(world)]
     read_base = [sum(allcuts[x][2 * world] for x in range(r)) for r in range(world)]
     totals = (sum(c[2 * world + 1] for c in allcuts), sum(c[2 * world + 2] for c in allcuts), sum(c[2 * world] for c in allcuts))
+    t = _mark("all-gather of cuts", dev, t)
     piece_e = [None] * world
     piece_p = [None] * world
     ops = []
@@ -275,10 +294,13 @@ def exchange_and_merge(engine, make_part_engine, make_root_engine, group=None, r
     if dev.type == "cuda":
         torch.cuda.current_stream(dev).synchronize()
 
+    t = _mark("exchange of key ranges", dev, t)
+
     # 2. merge my key range, in rank order (= stream order), first reads moved to the run's numbering
     part = make_part_engine()
     part.table_merge_many([(part.table_rebase(piece_e[r], in_e[r], read_base[r]), in_e[r], piece_p[r], in_p[r]) for r in range(world) if in_e[r]])
     del piece_e, piece_p, ent, prs
+    t = _mark("merge of my range (incl. the range handle's reset)", dev, t)
 
     if finalize_ranges:
         return _finalize_ranges(part, make_root_engine, totals, world, rank, dev, group, root)
@@ -323,11 +345,14 @@ def exchange_and_merge(engine, make_part_engine, make_root_engine, group=None, r
 def _finalize_ranges(part, make_root_engine, totals, world, rank, dev, group, root):
     """Step 3 of :func:`exchange_and_merge` for single-sample runs: every rank finalizes the key range it merged, the root
     places the finished rows.  One message of ``piece_words`` int32 per rank."""
+    t = _mark(None, dev, 0.0)
     packed, n_ecs, nnz = part.finalize_range(*totals)
+    t = _mark("finalize of my range", dev, t)
     mine = torch.tensor([n_ecs, nnz], dtype=torch.int64, device=dev)
     sz = torch.empty(world * 2, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(sz, mine, group=group)
     sz = sz.view(world, 2).cpu().tolist()
+    t = _mark("all-gather of piece sizes", dev, t)
     if rank != root:
         if n_ecs:
             _p2p([dist.P2POp(dist.isend, packed, root, group)])
@@ -343,8 +368,10 @@ def _finalize_ranges(part, make_root_engine, totals, world, rank, dev, group, ro
     _p2p(ops)
     if dev.type == "cuda":
         torch.cuda.current_stream(dev).synchronize()
+    t = _mark("pieces to the root", dev, t)
     merged = make_root_engine()
     merged.assemble_ranges([(packed if r == root else bufs[r], sz[r][0], sz[r][1]) for r in range(world) if sz[r][0]], *totals)
+    _mark("assembly on the root (incl. its handle's reset)", dev, t)
     return merged
 
 
