@@ -1735,8 +1735,15 @@ struct ListCmp {                                   // incoming key = a sorted pa
 };
 constexpr u32 MERGE_PER_BLOCK = 2 * TPB;      // entries per workgroup: a piece of one key range is a few hundred thousand entries, and with 16 x TPB
                                               // each it occupied 71 of the 256 CUs (one EC-count atomic per workgroup, fire and forget)
-__global__ __launch_bounds__(TPB) void k_merge(const Entry* ent, u64 n, const uint2* pairs, u64 n_pairs, Slot* table, u64 cap_mask,
-                                               uint2* arena, u64 arena_cap, Counters* ctr) {
+// All tables of a call in ONE launch (blockIdx.y = table): counts add and first reads minimise in any order, and a key that
+// two tables bring at the same moment is settled by the publication protocol like two waves of k_stream founding one EC --
+// eight pieces of a key range one after the other were eight launches of 0.04 ms that each left most of the chip idle.
+struct MergeDesc { const Entry* ent; const uint2* pairs; u64 n, n_pairs; };
+__global__ __launch_bounds__(TPB) void k_merge(const MergeDesc* D, Slot* table, u64 cap_mask, uint2* arena, u64 arena_cap, Counters* ctr) {
+    const MergeDesc d = D[blockIdx.y];
+    const Entry* const ent = d.ent; const uint2* const pairs = d.pairs;
+    const u64 n = d.n, n_pairs = d.n_pairs;
+    if (blockIdx.x * (u64)MERGE_PER_BLOCK >= n) return;       // (the grid is as wide as the longest table)
     __shared__ u32 s_new;
     if (threadIdx.x == 0) s_new = 0;
     __syncthreads();
@@ -1765,7 +1772,7 @@ __global__ __launch_bounds__(TPB) void k_merge(const Entry* ent, u64 n, const ui
                 if (__ballot(want != 0u)) {                                 // key arena: one reservation per wave, not per created EC
                     const u32 incl = wave_incl_scan(want);
                     const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
-                    if (lane == 0) at = arena_alloc(ctr, arena_cap, total, blockIdx.x * (TPB / 64) + (threadIdx.x >> 6));
+                    if (lane == 0) at = arena_alloc(ctr, arena_cap, total, (blockIdx.y * gridDim.x + blockIdx.x) * (TPB / 64) + (threadIdx.x >> 6));
                     at = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(at >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)at);
                     if (at == ~0ull) { if (lane == 0) atomicOr(&ctr->err, ERR_ARENA); }
                     else at += incl - want;
@@ -3501,10 +3508,16 @@ int ecb_table_merge_batch_device(ecb_handle* h, uint32_t n_tables, const void* c
     while ((h->n_ecs() + total) * 2 > h->cap) { rc = grow_table(h, h->cap * 4); if (rc != ECB_OK) return rc; }
     HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));
     h->list_counted = false;                     // (new ECs may join)
+    std::vector<MergeDesc> desc;
+    u64 most = 0;
     for (u32 t = 0; t < n_tables; ++t)
-        if (n_entries[t])
-            k_merge<<<nblk(n_entries[t], MERGE_PER_BLOCK), TPB, 0, h->stream>>>((const Entry*)d_entries[t], n_entries[t], (const uint2*)d_pairs[t],
-                                                                              n_pairs[t], h->table, h->cap - 1, h->arena, h->arena_cap, h->ctr);
+        if (n_entries[t]) { desc.push_back(MergeDesc{(const Entry*)d_entries[t], (const uint2*)d_pairs[t], n_entries[t], n_pairs[t]}); most = std::max<u64>(most, n_entries[t]); }
+    if (desc.size() > 65535u) return fail(h, ECB_ERR_LIMIT, "at most 65535 tables per call");
+    u64* d_desc = nullptr;
+    POOL(h, P_PARTS, d_desc, desc.size() * sizeof(MergeDesc) / sizeof(u64));
+    HIPCHK(h, hipMemcpyAsync(d_desc, desc.data(), desc.size() * sizeof(MergeDesc), hipMemcpyHostToDevice, h->stream));
+    k_merge<<<dim3((unsigned)nblk(most, MERGE_PER_BLOCK), (unsigned)desc.size()), TPB, 0, h->stream>>>(reinterpret_cast<const MergeDesc*>(d_desc), h->table, h->cap - 1,
+                                                                                                        h->arena, h->arena_cap, h->ctr);
     rc = sync_counters(h);
     if (rc != ECB_OK) return rc;
     if (h->hctr.n_queue) return fail(h, ECB_ERR_TABLE_FULL, "internal: merge found no slot in a half-empty table");
