@@ -1594,6 +1594,18 @@ __global__ __launch_bounds__(TPB_COMPACT) void k_compact(const Slot* table, u64 
     }
 }
 
+// ... and with the list already there (a merged table that kept it): what k_compact writes next to the list, from the list
+__global__ void k_list_fn(const Slot* table, const u32* list, u64 max_list, const u64* n_list, u64* n_out, u32* bitmap, u64 n_bits, uint2* list_fn) {
+    const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    const u64 n = *n_list;
+    if (e == 0) *n_out = n;
+    if (e >= n || e >= max_list) return;
+    const Slot* s = table + list[e];
+    const u32 f = ~s->first_inv;
+    list_fn[e] = make_uint2(f, s->n1 - 1u);
+    if (f < n_bits) atomicOr(&bitmap[f >> 5], 1u << (f & 31u));
+}
+
 // Partitioned export (multi-GPU merge by key range): part of an EC = a few high bits of its key, so every rank sends
 // part p of its table to rank p, rank p merges what it gets, and no EC is ever merged on two ranks.
 constexpr u32 MAX_PARTS = 64;
@@ -1739,13 +1751,19 @@ constexpr u32 MERGE_PER_BLOCK = 2 * TPB;      // entries per workgroup: a piece 
 // two tables bring at the same moment is settled by the publication protocol like two waves of k_stream founding one EC --
 // eight pieces of a key range one after the other were eight launches of 0.04 ms that each left most of the chip idle.
 struct MergeDesc { const Entry* ent; const uint2* pairs; u64 n, n_pairs; };
-__global__ __launch_bounds__(TPB) void k_merge(const MergeDesc* D, Slot* table, u64 cap_mask, uint2* arena, u64 arena_cap, Counters* ctr) {
+// (list / n_list, optional: every slot this launch founds is appended -- a table that started empty, or whose list of occupied
+//  slots was current, keeps a current list, and neither an export nor finalize has to scan it for its few occupied slots)
+__global__ __launch_bounds__(TPB) void k_merge(const MergeDesc* D, Slot* table, u64 cap_mask, uint2* arena, u64 arena_cap, Counters* ctr,
+                                               u32* list, u64 list_cap, u64* n_list) {
     const MergeDesc d = D[blockIdx.y];
     const Entry* const ent = d.ent; const uint2* const pairs = d.pairs;
     const u64 n = d.n, n_pairs = d.n_pairs;
     if (blockIdx.x * (u64)MERGE_PER_BLOCK >= n) return;       // (the grid is as wide as the longest table)
     __shared__ u32 s_new;
-    if (threadIdx.x == 0) s_new = 0;
+    __shared__ u32 s_found[MERGE_PER_BLOCK];                  // the slots this workgroup founds (for `list`: one reservation per workgroup)
+    __shared__ u32 s_nfound;
+    __shared__ u64 s_lbase;
+    if (threadIdx.x == 0) { s_new = 0; s_nfound = 0; }
     __syncthreads();
     const u32 lane = threadIdx.x & 63u;
     const u64 e0 = blockIdx.x * (u64)MERGE_PER_BLOCK, e1 = min(e0 + MERGE_PER_BLOCK, n);
@@ -1778,6 +1796,13 @@ __global__ __launch_bounds__(TPB) void k_merge(const MergeDesc* D, Slot* table, 
                     else at += incl - want;
                 }
                 my_new += (u32)__popcll(cm);
+                if (list) {                                                 // (uniform; every entry founds at most one slot)
+                    const int first = __ffsll((long long)cm) - 1;
+                    u32 lb = 0;
+                    if ((int)lane == first) lb = atomicAdd(&s_nfound, (u32)__popcll(cm));
+                    lb = (u32)__builtin_amdgcn_readlane((int)lb, first);
+                    if (cr) s_found[lb + __builtin_amdgcn_mbcnt_hi((u32)(cm >> 32), __builtin_amdgcn_mbcnt_lo((u32)cm, 0u))] = (u32)j;
+                }
                 if (cr) {
                     const bool dead = at == ~0ull;
                     if (!dead)
@@ -1808,6 +1833,11 @@ __global__ __launch_bounds__(TPB) void k_merge(const MergeDesc* D, Slot* table, 
     if (lane == 0 && my_new) atomicAdd(&s_new, my_new);
     __syncthreads();
     if (threadIdx.x == 0 && s_new) atomicAdd(&ctr->n_ecs, (u64)s_new);
+    if (list) {
+        if (threadIdx.x == 0) s_lbase = s_nfound ? atomicAdd(n_list, (u64)s_nfound) : 0ull;
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < s_nfound; i += TPB) if (s_lbase + i < list_cap) list[s_lbase + i] = s_found[i];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3243,8 +3273,13 @@ int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
         if (rc != ECB_OK) return rc;
     }
     if (!h->list_from_counts) {                        // (counts were made earlier -- a table export, a merge -- or there were none to make)
-        rc = compact_table_dev(h, d_tot, bitmap, total_reads, list_fn);
-        if (rc != ECB_OK) return rc;
+        if (!h->finalized && h->list_counted) {        // ... and the list with them (a merged key range): no scan of the table
+            POOL(h, P_LIST, h->list, E);               // (the pool's buffer, contents and all)
+            k_list_fn<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->table, h->list, E, h->d_list_n, d_tot, bitmap, total_reads, list_fn);
+        } else {
+            rc = compact_table_dev(h, d_tot, bitmap, total_reads, list_fn);
+            if (rc != ECB_OK) return rc;
+        }
     }
     k_popc<<<nblk(words, TPB), TPB, 0, h->stream>>>(bitmap, words, wpop);
     rc = excl_scan_dev(h, wpop, words, wprefix, d_tot + 1);
@@ -3507,7 +3542,17 @@ int ecb_table_merge_batch_device(ecb_handle* h, uint32_t n_tables, const void* c
     // room for every entry being new: one growth up front, then the merges queue up behind each other with one sync at the end
     while ((h->n_ecs() + total) * 2 > h->cap) { rc = grow_table(h, h->cap * 4); if (rc != ECB_OK) return rc; }
     HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));
-    h->list_counted = false;                     // (new ECs may join)
+    // New ECs may join.  The list of occupied slots is carried along when it can be: the table is empty (the handle that merges one
+    // key range), or its list is current and has room (a buffer that had to grow would lose what it holds).
+    u32* mlist = nullptr;
+    const u64 list_need = h->n_ecs() + total;
+    if (h->n_ecs() == 0 || (h->list_counted && h->pool_bytes[ecb_handle::P_LIST] >= list_need * sizeof(u32))) {
+        const bool fresh = h->n_ecs() == 0;
+        POOL(h, P_LIST, h->list, list_need);
+        if (fresh) { POOL(h, P_CNT, h->d_list_n, 1); HIPCHK(h, hipMemsetAsync(h->d_list_n, 0, sizeof(u64), h->stream)); }
+        mlist = h->list;
+    }
+    h->list_counted = mlist != nullptr;
     std::vector<MergeDesc> desc;
     u64 most = 0;
     for (u32 t = 0; t < n_tables; ++t)
@@ -3517,7 +3562,8 @@ int ecb_table_merge_batch_device(ecb_handle* h, uint32_t n_tables, const void* c
     POOL(h, P_PARTS, d_desc, desc.size() * sizeof(MergeDesc) / sizeof(u64));
     HIPCHK(h, hipMemcpyAsync(d_desc, desc.data(), desc.size() * sizeof(MergeDesc), hipMemcpyHostToDevice, h->stream));
     k_merge<<<dim3((unsigned)nblk(most, MERGE_PER_BLOCK), (unsigned)desc.size()), TPB, 0, h->stream>>>(reinterpret_cast<const MergeDesc*>(d_desc), h->table, h->cap - 1,
-                                                                                                        h->arena, h->arena_cap, h->ctr);
+                                                                                                        h->arena, h->arena_cap, h->ctr,
+                                                                                                        mlist, list_need, mlist ? h->d_list_n : nullptr);
     rc = sync_counters(h);
     if (rc != ECB_OK) return rc;
     if (h->hctr.n_queue) return fail(h, ECB_ERR_TABLE_FULL, "internal: merge found no slot in a half-empty table");
