@@ -2984,7 +2984,7 @@ __global__ void k_mark_bits(const PieceDesc* P, u64 n_bits, u32* bitmap, Counter
     if (f >= n_bits) { atomicOr(&ctr->err, ERR_CONTRACT); return; }
     atomicOr(&bitmap[f >> 5], 1u << (f & 31u));
 }
-// (what is known of rank r goes out as ONE 16-byte word {source + 1, row length, count, -}: the scatter is this kernel's cost)
+// (what is known of rank r goes out as ONE 16-byte word {EC within its piece + 1, row length, count, piece}: the scatter is this kernel's cost)
 __global__ void k_piece_place(const PieceDesc* P, u64 n_total, u64 n_bits, const u32* bitmap, const u32* wprefix, uint4* place, Counters* ctr) {
     const PieceDesc d = P[blockIdx.y];
     const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
@@ -2995,7 +2995,7 @@ __global__ void k_piece_place(const PieceDesc* P, u64 n_total, u64 n_bits, const
     if (s0 < 0 || s1 < s0 || (u64)s1 > d.nnz) { atomicOr(&ctr->err, ERR_CONTRACT); return; }
     const u32 r = wprefix[f >> 5] + __popc(bitmap[f >> 5] & ((1u << (f & 31u)) - 1u));
     if (r >= n_total) return;
-    place[r] = make_uint4((u32)(d.at + e) + 1u, (u32)(s1 - s0), (u32)d.counts[e], 0u);   // (two pieces claiming one first read: either, whole; the caller reports it)
+    place[r] = make_uint4((u32)e + 1u, (u32)(s1 - s0), (u32)d.counts[e], blockIdx.y);    // (two pieces claiming one first read: either, whole; the caller reports it)
 }
 // One thread per row of the result: neighbours write neighbouring rows, and read rows that follow each other within their piece
 // (a piece is in first-read order itself).
@@ -3004,11 +3004,9 @@ __global__ void k_piece_rows(const PieceDesc* P, u32 n_pieces, const uint4* plac
     if (r >= n_total) return;
     const uint4 pl = place[r];
     counts[r] = (int)pl.z;
-    if (pl.x == 0u) return;                             // (no piece claimed this rank: the caller reports it)
-    const u32 g = pl.x - 1u;
-    u32 q = 0;
-    while (q + 1 < n_pieces && P[q + 1].at <= g) ++q;
-    const u64 e = g - P[q].at;
+    if (pl.x == 0u || pl.w >= n_pieces) return;         // (no piece claimed this rank: the caller reports it)
+    const u32 q = pl.w;
+    const u64 e = pl.x - 1u;
     const int* ip = P[q].indptr;
     const int s0 = ip[e], s1 = ip[e + 1];
     const u32 d0 = indptr[r];
@@ -3358,7 +3356,7 @@ int ecb_assemble_ranges_device(ecb_handle* h, uint32_t n_pieces, const void* con
     u64* d_tot = nullptr;
     POOL(h, P_BITMAP, bitmap, words); POOL(h, P_WPOP, wpop, words); POOL(h, P_WPREFIX, wprefix, words);
     POOL(h, P_ROWLEN, place_raw, 4 * E);
-    uint4* place = reinterpret_cast<uint4*>(place_raw);         // {source + 1, row length, count, -} by rank
+    uint4* place = reinterpret_cast<uint4*>(place_raw);         // {EC within its piece + 1, row length, count, piece} by rank
     POOL(h, P_INDPTR, h->indptr, E + 1); POOL(h, P_COUNTS, h->counts, E);
     POOL(h, P_INDICES, h->indices, std::max<u64>(NNZ, 1)); POOL(h, P_DATA, h->data, std::max<u64>(NNZ, 1));
     POOL(h, P_TOTALS, d_tot, 8);
