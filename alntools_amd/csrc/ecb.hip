@@ -1070,10 +1070,17 @@ __global__ __launch_bounds__(TPB_PART) void k_part_hist(const u32* read_slot, u6
     const u64 r0 = g * per, r1 = min(r0 + per, n_reads);
     for (u32 b = threadIdx.x; b < n_buckets; b += TPB_PART) sh[b] = 0;
     __syncthreads();
-    for (u64 r = r0 + threadIdx.x; r < r1; r += TPB_PART) {
-        const u32 s = read_slot[r];
-        if (s != PENDING) atomicAdd(&sh[s >> bb], 1u);
+    // 16 bytes per lane where the range allows (which element a thread counts does not matter); the ragged ends one by one
+    const u64 a0 = min((r0 + 3) & ~3ull, r1), a1 = max(r1 & ~3ull, a0);
+    for (u64 r = r0 + threadIdx.x; r < a0; r += TPB_PART) { const u32 s = read_slot[r]; if (s != PENDING) atomicAdd(&sh[s >> bb], 1u); }
+    for (u64 r = a0 + 4ull * threadIdx.x; r < a1; r += 4ull * TPB_PART) {
+        const uint4 v = *reinterpret_cast<const uint4*>(read_slot + r);
+        if (v.x != PENDING) atomicAdd(&sh[v.x >> bb], 1u);
+        if (v.y != PENDING) atomicAdd(&sh[v.y >> bb], 1u);
+        if (v.z != PENDING) atomicAdd(&sh[v.z >> bb], 1u);
+        if (v.w != PENDING) atomicAdd(&sh[v.w >> bb], 1u);
     }
+    for (u64 r = a1 + threadIdx.x; r < r1; r += TPB_PART) { const u32 s = read_slot[r]; if (s != PENDING) atomicAdd(&sh[s >> bb], 1u); }
     __syncthreads();
     for (u32 b = threadIdx.x; b < n_buckets; b += TPB_PART) hist[(u64)b * G + g] = sh[b];
 }
