@@ -1215,29 +1215,38 @@ __global__ __launch_bounds__(TPB_COUNT) void k_count_bins(const u16* pairs, cons
     const u32 start = wk.start, end = wk.end;
     for (u32 q = threadIdx.x; q < N_BINS; q += TPB_COUNT) cnt[q] = 0;
     __syncthreads();
-    for (u32 i0 = start; i0 < end; i0 += 4 * TPB_COUNT) {
-        u32 pr[4];
+    // one element for every lane of the wave (wave-uniform call: the ballots).  A hot EC fills most lanes of a wave: it is added
+    // once per wave, the rest go one by one.
+    auto add = [&](u32 bin, bool have) {
+        const u64 hm = __ballot(have);
+        if (!hm) return;
+        const u32 v = __shfl(bin, __ffsll((long long)hm) - 1);
+        const bool same = have && bin == v;
+        const u64 m = __ballot(same);
+        if (__popcll(m) >= 8) {
+            if (lane == (u32)(__ffsll((long long)m) - 1)) atomicAdd(&cnt[v], (u32)__popcll(m));
+            if (have && !same) atomicAdd(&cnt[bin], 1u);
+        } else if (have) {
+            atomicAdd(&cnt[bin], 1u);
+        }
+    };
+    // 16 bytes = 8 elements per lane and load where the piece allows, four loads in flight; its ragged ends one element per thread
+    const u32 a0 = min((start + 7u) & ~7u, end), a1 = max(end & ~7u, a0);
+    { const u32 i = start + threadIdx.x; const bool have = i < a0; add(have ? (u32)pairs[i] : 0u, have); }
+    { const u32 i = a1 + threadIdx.x; const bool have = i < end; add(have ? (u32)pairs[i] : 0u, have); }
+    for (u32 i0 = a0; i0 < a1; i0 += 32 * TPB_COUNT) {
+        uint4 pv[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {                       // four independent loads in flight per thread (eight: no faster)
-            const u32 i = i0 + k * TPB_COUNT + threadIdx.x;
-            pr[k] = i < end ? (u32)pairs[i] : 0xFFFFFFFFu;
+        for (int k = 0; k < 4; ++k) {
+            const u32 i = i0 + (k * TPB_COUNT + threadIdx.x) * 8u;
+            pv[k] = i < a1 ? *reinterpret_cast<const uint4*>(pairs + i) : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const bool have = pr[k] != 0xFFFFFFFFu;
-            const u32 bin = pr[k] & (N_BINS - 1);
-            const u64 hm = __ballot(have);
-            if (!hm) continue;
-            // a hot EC fills most lanes of a wave: add it once per wave, the rest go one by one
-            const u32 v = __shfl(bin, __ffsll((long long)hm) - 1);
-            const bool same = have && bin == v;
-            const u64 m = __ballot(same);
-            if (__popcll(m) >= 8) {
-                if (lane == (u32)(__ffsll((long long)m) - 1)) atomicAdd(&cnt[v], (u32)__popcll(m));
-                if (have && !same) atomicAdd(&cnt[bin], 1u);
-            } else if (have) {
-                atomicAdd(&cnt[bin], 1u);
-            }
+            const bool have = i0 + (k * TPB_COUNT + threadIdx.x) * 8u < a1;
+            const u32 w[4] = {pv[k].x, pv[k].y, pv[k].z, pv[k].w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) add((w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu, have);
         }
     }
     __syncthreads();
