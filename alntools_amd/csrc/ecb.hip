@@ -1064,10 +1064,12 @@ static_assert(MAX_BIN_BITS <= 16, "a slot's index within its range is kept in 16
 // (measured: -0.25 ms of 1.4 at C3; non-temporal stores, which skip that write-combining, cost +3.5 ms).
 constexpr int TPB_PART = 1024;
 constexpr u32 PART_G = 512;
+// reads per workgroup of the partition passes (the same cut in all of them): a multiple of 4, so that a workgroup's first read sits on a 16-byte boundary
+__device__ __forceinline__ u64 part_per(u64 n_reads, u64 G) { return (((n_reads + G - 1) / G) + 3ull) & ~3ull; }
 __global__ __launch_bounds__(TPB_PART) void k_part_hist(const u32* read_slot, u64 n_reads, u32 n_buckets, u32 bb, u32* hist) {
     extern __shared__ u32 sh[];
-    const u64 G = gridDim.x, g = blockIdx.x, per = (n_reads + G - 1) / G;
-    const u64 r0 = g * per, r1 = min(r0 + per, n_reads);
+    const u64 G = gridDim.x, g = blockIdx.x, per = part_per(n_reads, G);
+    const u64 r0 = min(g * per, n_reads), r1 = min(r0 + per, n_reads);
     for (u32 b = threadIdx.x; b < n_buckets; b += TPB_PART) sh[b] = 0;
     __syncthreads();
     // 16 bytes per lane where the range allows (which element a thread counts does not matter); the ragged ends one by one
@@ -1088,8 +1090,8 @@ __global__ __launch_bounds__(TPB_PART) void k_part_hist(const u32* read_slot, u6
 __global__ __launch_bounds__(TPB_PART) void k_part_scatter(const u32* read_slot, u64 n_reads, u32 n_buckets, u32 bb, const u32* offs,
                                                       u16* pairs) {
     extern __shared__ u32 sh[];
-    const u64 G = gridDim.x, g = blockIdx.x, per = (n_reads + G - 1) / G;
-    const u64 r0 = g * per, r1 = min(r0 + per, n_reads);
+    const u64 G = gridDim.x, g = blockIdx.x, per = part_per(n_reads, G);
+    const u64 r0 = min(g * per, n_reads), r1 = min(r0 + per, n_reads);
     for (u32 b = threadIdx.x; b < n_buckets; b += TPB_PART) sh[b] = offs[(u64)b * G + g];
     __syncthreads();
     // four reads per thread and trip: their LDS cursor bumps are independent, so the round trips overlap
@@ -1123,8 +1125,8 @@ __global__ __launch_bounds__(TPB_PART) void k_part_scatter_staged(const u32* rea
     u32 *cnt = sh, *start = sh + n_buckets, *gcur = sh + 2 * n_buckets;
     u32* stage = sh + 3 * n_buckets;
     __shared__ u32 s_wave[TPB_PART / 64];
-    const u64 G = gridDim.x, g = blockIdx.x, per = (n_reads + G - 1) / G;
-    const u64 r0 = g * per, r1 = min(r0 + per, n_reads);
+    const u64 G = gridDim.x, g = blockIdx.x, per = part_per(n_reads, G);
+    const u64 r0 = min(g * per, n_reads), r1 = min(r0 + per, n_reads);
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     const u32 bpt = (n_buckets + TPB_PART - 1) / TPB_PART;            // ranges per thread in the scan (1 .. 4)
     for (u32 b = tid; b < n_buckets; b += TPB_PART) gcur[b] = offs[(u64)b * G + g];
@@ -1133,9 +1135,15 @@ __global__ __launch_bounds__(TPB_PART) void k_part_scatter_staged(const u32* rea
         __syncthreads();
         u32 s[8], lr[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const u64 r = rb + (u64)k * TPB_PART + tid;
-            s[k] = r < r1 ? read_slot[r] : PENDING;
+        for (int k4 = 0; k4 < 2; ++k4) {                  // 16 bytes per lane and load (which element a thread takes does not matter)
+            const u64 r = rb + ((u64)k4 * TPB_PART + tid) * 4u;
+            if (r + 4 <= r1) {
+                const uint4 v = *reinterpret_cast<const uint4*>(read_slot + r);
+                s[4 * k4] = v.x; s[4 * k4 + 1] = v.y; s[4 * k4 + 2] = v.z; s[4 * k4 + 3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[4 * k4 + j] = r + j < r1 ? read_slot[r + j] : PENDING;
+            }
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) if (s[k] != PENDING) lr[k] = atomicAdd(&cnt[s[k] >> bb], 1u);
