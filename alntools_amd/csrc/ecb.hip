@@ -1054,8 +1054,9 @@ __global__ __launch_bounds__(1024) void k_sum_counts(const u32* wave_counts, u64
 // per-read slot ids without global atomics: partition the (slot, read) pairs by slot range (LDS
 // histogram, scan, scatter), then one workgroup per range counts in LDS and owns its slots' counters.
 // ---------------------------------------------------------------------------------------------
-constexpr u32 BIN_BITS = 13;                   // slots per range = LDS bins of one k_count_bins workgroup: 2^13 up to a table of
-constexpr u32 MAX_BIN_BITS = 15;               // 2^26 slots, 2^14 and 2^15 (128 KB of LDS) beyond -- a run-time argument `bb`
+constexpr u32 BIN_BITS = 14;                   // slots per range = LDS bins of one k_count_bins workgroup: 2^14 (64 KB of LDS, two workgroups per CU;
+                                               // 2^13 made the partition's runs half as long: +0.08 ms at C3) up to a table of 2^27 slots,
+constexpr u32 MAX_BIN_BITS = 15;               // 2^15 (128 KB) beyond -- a run-time argument `bb`
 constexpr u32 MAX_BUCKETS = 8192;
 static_assert(MAX_BIN_BITS <= 16, "a slot's index within its range is kept in 16 bits (k_part_scatter*, k_count_bins)");              // LDS histogram of the partition passes  (=> at most 2^28 slots)
 
@@ -2882,6 +2883,7 @@ int ensure_counts(ecb_handle* h, const CompactSink* sink = nullptr) {
     }
     if (R) {
         u32 bb = BIN_BITS;
+        if (const char* e = getenv("ECB_BIN_BITS")) bb = (u32)std::min<long>(std::max<long>(atol(e), BIN_BITS), MAX_BIN_BITS);   // (measurement knob)
         while (bb < MAX_BIN_BITS && (h->cap >> bb) > MAX_BUCKETS) ++bb;
         const u32 nb = (u32)std::max<u64>(1, h->cap >> bb);
         if (nb > MAX_BUCKETS) return fail(h, ECB_ERR_LIMIT, "EC table larger than 2^28 slots is not supported");
