@@ -2883,7 +2883,7 @@ int ensure_counts(ecb_handle* h, const CompactSink* sink = nullptr) {
     }
     if (R) {
         u32 bb = BIN_BITS;
-        if (const char* e = getenv("ECB_BIN_BITS")) bb = (u32)std::min<long>(std::max<long>(atol(e), BIN_BITS), MAX_BIN_BITS);   // (measurement knob)
+        if (const char* e = getenv("ECB_BIN_BITS")) bb = (u32)std::min<long>(std::max<long>(atol(e), 13), MAX_BIN_BITS);   // (measurement knob: tools/tools_env.sh)
         while (bb < MAX_BIN_BITS && (h->cap >> bb) > MAX_BUCKETS) ++bb;
         const u32 nb = (u32)std::max<u64>(1, h->cap >> bb);
         if (nb > MAX_BUCKETS) return fail(h, ECB_ERR_LIMIT, "EC table larger than 2^28 slots is not supported");
