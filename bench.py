@@ -236,9 +236,10 @@ def main():
         eng = ecdist.HostStagedEngine(eng)
     root_eng = part_eng = None
     if use_dist:        # the key range this rank merges (1/world of the ECs), and on rank 0 the table that adopts all ranges
-        # (sized for the workload like the shard's table: a key range holds 1/world of the ECs; the adopting table only needs a
-        #  slot per EC -- both grow by themselves if the guess is short, and the smaller they are the less there is to clear and scan)
-        part_cap = max(1 << 20, (2 * ec_cap) // world)
+        # (the merging table is sized for the entries that ARRIVE -- 1/world of every shard's ECs, i.e. about one shard's worth, all of which
+        #  the merge must be able to seat before it knows how many of them are the same EC -- so that no timed step grows it; a table that
+        #  is merged into keeps a list of its occupied slots, so its size costs nothing per step.  The root's handle only assembles.)
+        part_cap = ec_cap
         part_eng = ecdist.GpuEngine(ecb.EcBuilder(T, H, device=local, ec_capacity=part_cap, arena_capacity=1 << 26), device)
         if rank == 0:
             root_eng = ecdist.GpuEngine(ecb.EcBuilder(T, H, device=local, ec_capacity=(1 << 22) if args.workload in ("c3", "c3h") else 1 << 20,

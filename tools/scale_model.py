@@ -32,8 +32,8 @@ def sync():
 asm = ecb.EcBuilder(T, H, device=0, ec_capacity=1 << 20, arena_capacity=1 << 20)
 aeng = ecdist.GpuEngine(asm, dev)
 for N in NS:
-    # (the handle that merges one key range, sized as bench.py sizes it: 1/N of the ECs at under half full)
-    part = ecb.EcBuilder(T, H, device=0, ec_capacity=max(1 << 20, (2 * (1 << (23 if N >= 4 else 24))) // N), arena_capacity=1 << 26)
+    # (the handle that merges one key range, sized as bench.py sizes it: room for every arriving entry, about one shard's ECs)
+    part = ecb.EcBuilder(T, H, device=0, ec_capacity=1 << (23 if N >= 4 else 24), arena_capacity=1 << 26)
     peng = ecdist.GpuEngine(part, dev)
     for rep in range(2):
         rank_ms, pieces, base, tot = [], [], 0, [0, 0, 0]
