@@ -2420,7 +2420,7 @@ struct ecb_handle {
            P_WCOUNTS, P_RANK, P_INDPTR, P_COUNTS, P_INDICES, P_DATA, P_MS_KEYS, P_MS_KEYS2, P_MS_VALS, P_MS_VALS2, P_MS_TMP,
            P_MS_FLAG, P_MS_POS, P_MS_OKEY, P_MS_OFIRST, P_MS_OSTART, P_MS_X, P_MS_OCOUNT, P_MS_GRANK, P_MS_CIN, P_MS_FIN, P_LISTFN,
            P_REMAP, P_TOTALS, P_SLOW_LEN, P_SLOW_OFF, P_SLOW_NRE, P_SLOW_REQ, P_SLOW_REQ2, P_SLOW_KEY, P_SLOW_MASK, P_BIG, P_RS_HIST, P_RS_OFFS, P_RS_SUMS,
-           P_F_CELLS, P_F_IPA, P_F_IXA, P_F_DAA, P_F_IPN, P_F_IXN, P_F_DAN, P_N };
+           P_F_CELLS, P_F_IPA, P_F_IXA, P_F_DAA, P_F_IPN, P_F_IXN, P_F_DAN, P_EXPORT, P_N };
     void* pool[P_N] = {}; u64 pool_bytes[P_N] = {};
 
     // profiling
@@ -3467,12 +3467,11 @@ int ecb_export_ranges(ecb_handle* h, int64_t* out) {
     if (!(h->cfg.flags & ECB_F_RANGES)) return fail(h, ECB_ERR_STATE, "handle was created without ECB_F_RANGES");
     HIPCHK(h, hipSetDevice(h->device));
     const u64 ns = (u64)h->cfg.n_loci * h->cfg.n_haplotypes;
-    long long* d = nullptr;
-    HIPCHK(h, hipMalloc(&d, ns * 8));
+    long long* d = nullptr;                            // (the handle's pool: nothing to free on an early return)
+    POOL(h, P_EXPORT, d, ns);
     k_range_len<<<nblk(ns, TPB), TPB, 0, h->stream>>>(h->rng, ns, d);
     HIPCHK(h, hipMemcpyAsync(out, d, ns * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipFree(d));
     return ECB_OK;
 }
 
@@ -3482,13 +3481,11 @@ int ecb_export_range_minmax(ecb_handle* h, int32_t* mn, int32_t* mx) {
     HIPCHK(h, hipSetDevice(h->device));
     const u64 ns = (u64)h->cfg.n_loci * h->cfg.n_haplotypes;
     int* d = nullptr;
-    HIPCHK(h, hipMalloc(&d, 2 * ns * sizeof(int)));
+    POOL(h, P_EXPORT, d, 2 * ns);
     k_split_minmax<<<nblk(ns, TPB), TPB, 0, h->stream>>>(h->rng, ns, d, d + ns);
-    hipError_t e = hipMemcpyAsync(mn, d, ns * 4, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(mx, d + ns, ns * 4, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    hipFree(d);
-    if (e != hipSuccess) return fail(h, ECB_ERR_HIP, "range export: %s", hipGetErrorString(e));
+    HIPCHK(h, hipMemcpyAsync(mn, d, ns * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(mx, d + ns, ns * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return ECB_OK;
 }
 
@@ -3515,12 +3512,11 @@ int ecb_export_read_ec(ecb_handle* h, int32_t* out) {
     if (h->extra_reads || h->assembled) return fail(h, ECB_ERR_STATE, "per-read EC ids are not kept across a multi-GPU merge");
     HIPCHK(h, hipSetDevice(h->device));
     int* d = nullptr;
-    HIPCHK(h, hipMalloc(&d, std::max<u64>(h->n_reads, 1) * 4));
-    { const int rc_ = ensure_slot_ranks(h, h->sizes.n_ecs); if (rc_ != ECB_OK) { hipFree(d); return rc_; } }
+    POOL(h, P_EXPORT, d, h->n_reads);
+    { const int rc_ = ensure_slot_ranks(h, h->sizes.n_ecs); if (rc_ != ECB_OK) return rc_; }
     k_read_ec<<<nblk(h->n_reads, TPB), TPB, 0, h->stream>>>(h->read_slot, h->n_reads, h->rank_of_slot, d);
     HIPCHK(h, hipMemcpyAsync(out, d, h->n_reads * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipFree(d));
     return ECB_OK;
 }
 
