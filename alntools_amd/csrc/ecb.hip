@@ -285,8 +285,8 @@ struct alignas(16) WaveLds {
     uint2 carry[CMAX];               // the entries of the read that is still open at the end of a tile (x = locus + 1, y = mask)
     unsigned short ent[WT + CMAX];   // table entries created in this pass: slot | read << SBITS
     unsigned short npair[WMAXR];     // per read: number of (locus, mask) pairs
-    u32 ws[5];                       // wave scalars that are touched once in a while (scalar registers are scarcer than the few LDS reads):
-};                                   //   [0,1] head record of the open read   [2,3] key-arena reservation: next pair   [4] ... pairs left
+    u32 ws[8];                       // wave scalars that are touched once in a while (scalar registers are scarcer than the few LDS reads):
+};                                   //   [0,1] head record of the open read   [2,3] key-arena reservation: next pair   [4] ... pairs left   [5,6] where a park resumes
 static_assert(sizeof(WaveLds) * NWAVE * ECB_WAVES_PER_SIMD <= 160 * 1024, "ECB_WAVES_PER_SIMD workgroups per CU");
 __device__ __forceinline__ u64 ws_get64(const WaveLds& L, int i) {
     const u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)L.ws[i]), hi = (u32)__builtin_amdgcn_readfirstlane((int)L.ws[i + 1]);
@@ -503,10 +503,17 @@ __device__ __forceinline__ void load_pos(const int* pos, u64 tb, u64 te, u32 lan
 // VERIFY = false: the hot kernel.  VERIFY = true: the exactness pass (same tiling, compares instead of inserting).
 //
 // A wave walks its slice in tiles of WT records that start at multiples of WT: every record is loaded exactly once (plus
-// the tail a slice's last read hangs into the next slice).  The read that is still open at the end of a tile is not read
-// again: its {locus -> mask} entries so far (a few) are carried into the next tile, where they are put into that read's
-// table before the tile's own records.  A read that would carry more than CMAX entries goes to k_slow.  A tile with more
-// than WMAXR reads (short reads) is worked off in passes of WMAXR reads; every further pass loads the tile again.
+// the tail a slice's last read hangs into the next slice).  Reads are NOT looked up tile by tile: a *pass* collects the
+// {(read, locus) -> mask} entries of up to 1 << lg reads (at most WMAXR) from as many consecutive tiles as fit, and only then
+// is every entry hashed and every finished read looked up, one lane each -- a *flush*.  (One flush per tile left three
+// quarters of phase (c)'s lanes idle on config 3 -- fifteen reads per tile -- and paid the EC table's round trip, the per-pass
+// LDS clear and the hashing loop's ramp four times as often.)  A pass is flushed behind a tile when, going by that tile, the
+// next one would bring more records than the table has room for entries or more reads than the pass has room for; a tile whose
+// records turn out not to fit after all (every record may make an entry) is held back, still in its registers, until the pass
+// has been flushed.  The read that is open at a flush is not read again: its entries so
+// far are carried in LDS into the next pass and inserted there with the next tile's records.  A read that would carry more
+// than CMAX entries goes to k_slow.  A tile with more reads than the pass has room for (short reads) is worked off in
+// several visits: every further visit loads the tile again.
 // (RANGES: the reference_start ranges of ECB_F_RANGES updated in the same pass -- more registers, four waves per SIMD)
 template <bool VERIFY, bool RANGES = false>
 __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A) {
@@ -528,6 +535,18 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
 #ifdef ECB_TIMING
     u64 tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
 #endif
+    // this wave's per-pass LDS state: table, hash sums, pair counts -- cleared here and behind every flush
+    auto clear_pass = [&](u32 ln) {
+        uint4* z = tab_base(L);
+        u32 zz;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zz));          // (a zero the compiler cannot keep in four registers across the loop)
+        const uint4 zv = make_uint4(zz, zz, zz, zz);
+#pragma unroll
+        for (int t = 0; t < (TSLOTS * 8) / (16 * 64); ++t) z[t * 64 + ln] = zv;
+        *reinterpret_cast<uint2*>(&L.acc[ln]) = make_uint2(zz, zz); L.npair[ln] = (unsigned short)zz;
+    };
+    clear_pass(lane);                             // (every slice leaves the table as it found it: empty)
+    wave_sync();
   for (;;) {
     u32 wid = 0;                                  // the slice (fewer than 2^32 of them: a slice is at least a tile)
     if (lane == 0) wid = (u32)atomicAdd(&A.ctr->next_slice, 1ull);
@@ -547,11 +566,19 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
     const u32 last_rel = (u32)(A.n - ((u64)last_t << 9));         // ... and how many records it holds
     const u32 counted_t = (u32)((counted0 + (u64)(WT - 1)) >> 9); // tiles before this one have been counted (after a park)
     int p_rel = (int)(p - ((u64)tix << 9));       // (only matters in the first tile after a park)
-    // read index of the first head at or after p; records before it that are not heads belong to the read before
-    u32 base = (p == 0 ? C->prev_rid : A.rid[p - 1]) + 1u;
-    bool open = false;                            // a read of mine is still open at the start of the tile (its index is `base`)
-                                                  // (the record index of its head: L.ws[0..1])
-    u32 carry_n = 0;                              // its entries so far, in L.carry
+    // read id of the record before the tile; the first head at or after p starts read prev + 1, and records before it that
+    // are not heads belong to the read before (not mine)
+    u32 prev = p == 0 ? C->prev_rid : A.rid[p - 1];
+    // The pass: reads pb .. pb + npend - 1 are complete and wait for their lookup, read pb + npend is open (if `open`; the
+    // record index of its head: L.ws[0..1]).  Invariant at the start of a tile's first visit: pb + npend + open == prev + 1,
+    // the id of the next read to start.
+    // The record the slice is taken up at after a park: the head of read pb, or a tile boundary before it -- L.ws[5..6].
+    u32 pb = prev + 1u, npend = 0, n_ent = 0;     // n_ent: entries in L.ent (complete reads' and the open read's)
+    ws_put64(L, 5, p, lane);
+    bool open = false;
+    u32 carry_n = 0;                              // entries in L.carry: the open read's, waiting to go into the fresh table
+    u32 lg = 6;                                   // the pass has room for 1 << lg reads (see WaveLds: the table's geometry)
+    bool revisit = false;                         // the tile has been visited before (more reads in it than a pass takes)
     TileRegs R;
     load_tile(A, (u64)tix << 9, min(((u64)tix << 9) + (u64)WT, A.n), lane, R);
     int r_pos[RANGES ? RPL : 1];                  // ECB_F_RANGES: reference_start of the tile's records, prefetched with them
@@ -559,36 +586,48 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
     u32 parked = __hip_atomic_load(&A.ctr->full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("" : "+v"(parked));          // (settled before the loop: otherwise the loop header carries an s_waitcnt vmcnt(0) that every tile pays)
     bool slice_done = false;
-    u32 r_lo = 0;                                 // first read of the tile this pass works on (tiles of short reads take several passes)
 
     while (!slice_done) {
-        if (__builtin_amdgcn_readfirstlane((int)parked)) break;   // the EC table filled up somewhere: the host grows it and relaunches
+        // the EC table filled up somewhere: the host grows it and relaunches.  What the pass holds is dropped: the slice is taken up
+        // again at the head of the pass's first read (L.ws[5..6]), and looking a read up twice changes nothing.
+        if (__builtin_amdgcn_readfirstlane((int)parked)) break;
                                       // (readfirstlane: every lane loaded the same word; said so, the loop is uniform to the compiler --
                                       //  as a per-lane condition it dragged exec-mask bookkeeping through every block of the tile)
         // (opaque per tile: the LDS addresses and constants derived from the lane index are cheap to recompute; hoisted out of
         //  the loop they sat in registers the tile needs, and what did not fit was spilled and re-loaded BEHIND the prefetch)
         u32 ln = lane;
         asm volatile("" : "+v"(ln));
-        r_lo = (u32)__builtin_amdgcn_readfirstlane((int)r_lo);
         tix = (u32)__builtin_amdgcn_readfirstlane((int)tix);
-        base = (u32)__builtin_amdgcn_readfirstlane(base);
+        prev = (u32)__builtin_amdgcn_readfirstlane((int)prev);
+        pb = (u32)__builtin_amdgcn_readfirstlane((int)pb);
+        npend = (u32)__builtin_amdgcn_readfirstlane((int)npend);
+        n_ent = (u32)__builtin_amdgcn_readfirstlane((int)n_ent);
+        lg = (u32)__builtin_amdgcn_readfirstlane((int)lg);
+        // The table's geometry (see WaveLds): two wave-uniform numbers
+        const u32 pm = (512u >> lg) - 1u, gp = (512u >> lg) + (TSLOTS == 896 ? (256u >> lg) : 0u) + (128u >> lg);
+        bool do_flush = false, again = false, more = false;
+        bool preflush = false;                     // this tile's records might not fit the pass's table: flush first, then take the tile again
+        bool taken = false;                        // the prefetched tile has been waited for (on this path)
+        u32 parked_next = parked;
+        u32 last_pos = 0xFFFFFFFFu;                // tile-relative head of the tile's last read, if it started here (it may stay open)
+        u32 last_rid = prev;
+        u32 est = 64;                              // reads a tile brings, going by this one: the next pass's geometry
         const bool ends = tix == last_t;           // batches end on a read boundary
         const bool own = tix < c1t;               // heads in this tile start reads of my slice (tiles do not straddle its end)
         const int te_rel = ends ? (int)last_rel : WT;
         // records offered / valid are counted tile by tile: every tile of my slice once (after a park the tiles before the
         // one that was next have been counted: `counted0` is a tile boundary)
-        const bool count_tile = own && tix >= counted_t && r_lo == 0u;
+        const bool count_tile = own && tix >= counted_t && !revisit;
         const bool plain = p_rel == 0 && te_rel == WT;      // a whole tile, nothing masked: all but the first after a park / the last of the stream
         // ---- (a) filter, heads -------------------------------------------------------------------
         // Written with integer bit arithmetic throughout: every instruction costs an issue slot, and
         // compare -> mask -> select chains were a third of this kernel's instruction count.
         // Per record: its LDS key (locus + 1 | index of its read within the pass << KBITS) and its haplotype bit -- all that
         // phase (b) needs of it; which records phase (b) takes at all (valid, of a read of this pass) is settled here too:
-        // the reads of a tile of mine are numbered base ..., so "one of the pass's WMAXR reads" is one unsigned comparison.
+        // reads are numbered consecutively by the run counter, so "one of the pass's reads" is one unsigned comparison.
         u32 r_key[RPL], r_bit[RPL];
         u32 m_act = 0, m_head = 0;                 // bit k: valid record of a read of this pass / head
-        const u32 base_lo = base + r_lo;
-        const u32 lim = own ? (u32)WMAXR : ((open && r_lo == 0u) ? 1u : 0u);   // (past my slice only the open read is mine)
+        const u32 lim = own ? (1u << lg) : (open ? npend + 1u : 0u);   // (past my slice only the open read is mine)
         {
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
@@ -596,7 +635,7 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
                 // the record before this group's first: the previous ln's last record of the group, or (ln 0) the
                 // previous group's very last record
                 const u32 up = lane_above(R.rr[4 * g + 3]);
-                const u32 wrap = g == 0 ? base - 1u + (open ? 1u : 0u) : (u32)__builtin_amdgcn_readlane((int)R.rr[4 * (g > 0 ? g - 1 : 0) + 3], 63);
+                const u32 wrap = g == 0 ? prev : (u32)__builtin_amdgcn_readlane((int)R.rr[4 * (g > 0 ? g - 1 : 0) + 3], 63);
                 u32 in4 = 0xFu, te4 = 0xFu;                                      // records of the tile / at or after p
                 if (!plain) {
                     te4 = (1u << clamp04(te_rel - i0, 0, 4)) - 1u;
@@ -624,7 +663,7 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
                             const int k = 4 * g + j;
                             const u32 f = R.hh[k];
                             const u32 step = R.rr[k] - (j == 0 ? prev0 : R.rr[k > 0 ? k - 1 : 0]);
-                            const u32 relx = R.rr[k] - base_lo;              // (records before the pass's first read: huge)
+                            const u32 relx = R.rr[k] - pb;                   // (records of reads before the pass's first: huge)
                             const u32 t = R.ll[k] + 1u;
                             r_key[k] = t | (relx << KBITS);
                             r_bit[k] = 1u << ((f >> ECB_HAP_SHIFT) & 31u);
@@ -637,8 +676,8 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
                         if constexpr (RANGES) {
                             // reference_start ranges per target (bam_utils.py:282-286), in the pass that has the record in registers anyway:
                             // the 2 x n_loci x n_haps bounds stay in L2, and a record only issues an atomic when it moves a bound (almost
-                            // none do after the first few thousand).  Re-running a tile (park, further passes) changes nothing: min / max.
-                            if (r_lo == 0u) {
+                            // none do after the first few thousand).  Re-running a tile (park, further visits) changes nothing: min / max.
+                            if (!revisit) {
                                 const u32 nl = C->n_loci, nh = C->n_haps;
                                 int2* const rng = C->rng;
                                 u32 sl[2]; int2 cur[2]; bool go[2];
@@ -678,23 +717,32 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
         }
         TICK(0);
         if (__ballot(bad != 0u)) break;            // never index LDS with a broken run counter
-        const u32 nheads = wave_sum(__popc(m_head));
-        const u32 last_rid = (u32)__builtin_amdgcn_readlane((int)R.rr[RPL - 1], 63);   // (of a full tile; a short one ends the stream)
-        // reads with records in this tile: the open one (index 0) and one per head.  All but the last are complete here; the
-        // last one is too if the stream ends with the tile.  In a tile past my slice only the open read is mine, and it
-        // is complete as soon as a head shows up.
-        const u32 n_in = (open ? 1u : 0u) + nheads;
-        const u32 n_done = own ? (ends ? n_in : (n_in ? n_in - 1u : 0u)) : ((open && (nheads || ends)) ? 1u : 0u);
-        const u32 n_build = own ? n_in : (open ? 1u : 0u);     // reads whose tables are built: the unfinished one too (it is carried on)
-        const bool carry_out = own ? (!ends && n_in != 0u) : (open && !nheads && !ends);
-        const bool more = !ends && (tix + 1u < c1t || carry_out);
-        const bool again = r_lo + (u32)WMAXR < n_build;     // another pass over this tile follows
+        const u32 cnts = wave_sum((u32)__popc(m_head) | ((u32)__popc(m_act) << 16));
+        const u32 nheads = cnts & 0xFFFFu, n_mine = cnts >> 16;   // heads; records that go into the pass's table
+        last_rid = (u32)__builtin_amdgcn_readlane((int)R.rr[RPL - 1], 63);   // (of a full tile; a short one ends the stream)
+        // Reads with records in this tile that are mine: the open one (index npend of the pass) and one per head whose read has not
+        // been dealt with on an earlier visit -- heads number their reads prev + 1 ..., the next read to start is pb + npend + open.
+        // All but the last are complete here; the last one is too if the stream ends with the tile.  In a tile past my slice only
+        // the open read is mine, and it is complete as soon as a head shows up.
+        const u32 o1 = open ? 1u : 0u;
+        const u32 n_new = own ? (prev + 1u + nheads) - (pb + npend + o1) : 0u;
+        const u32 n_in = o1 + n_new;
+        est = n_in;
+        // Every record may make an entry of its own.  Behind a flush a tile always fits (CMAX carried entries + WT records); a pass that
+        // has taken tiles before was judged, after the last of them, to have room for one more like it -- when that turns out wrong
+        // (rare), the pass is flushed with the tile untouched in its registers and the tile is then taken again.
+        if (n_ent + carry_n + n_mine > (u32)(WT + CMAX)) { preflush = true; do_flush = true; }
+        else {
+        if (own) {
+            if (npend + n_in > (1u << lg)) { again = true; npend = 1u << lg; open = false; }      // (the reads that fit are all complete: more follow)
+            else if (n_in) { npend += ends ? n_in : n_in - 1u; open = !ends; }
+        } else if (open && (nheads || ends)) { npend += 1u; open = false; }
+        more = !ends && (tix + 1u < c1t || open);
         TICK(1);
         // ---- prefetch the next tile while this one is hashed and looked up --------------------------
         // Into the SAME registers: phase (a) has turned the tile into keys and bits, nothing reads R again.  The lane offset of
         // the loads is made to depend on phase (a)'s results, so that the scheduler cannot start them while R is still being read
         // (it did, and a second set of 24 registers plus 24 moves per tile was the price).
-        u32 parked_next = 0;
         if (more || again) {
             u32 lp = ln;
 #pragma unroll
@@ -705,134 +753,122 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
             if constexpr (RANGES) load_pos(C->pos, nt, min(nt + (u64)WT, A.n), lp, r_pos);
             parked_next = __hip_atomic_load(&A.ctr->full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        bool taken = false;                        // the prefetched tile has been waited for (on this path)
-        u32 new_carry = 0;
-        bool giant = false;
-        u32 last_pos = 0xFFFFFFFFu;                // tile-relative head of the tile's last read, if it started here (it may stay open)
-
-        if (r_lo < n_build) {
-            const u32 nb = min(n_build - r_lo, (u32)WMAXR);            // tables built in this pass
-            const u32 nproc = r_lo < n_done ? min(n_done - r_lo, (u32)WMAXR) : 0u;   // reads finished in this pass (one ln each in (c))
-            // clear this wave's per-pass LDS state
-            {
-                uint4* z = tab_base(L);
-                u32 zz;
-                asm volatile("v_mov_b32 %0, 0" : "=v"(zz));          // (a zero the compiler cannot keep in four registers across the loop)
-                const uint4 zv = make_uint4(zz, zz, zz, zz);
-#pragma unroll
-                for (int t = 0; t < (TSLOTS * 8) / (16 * 64); ++t) z[t * 64 + ln] = zv;
-                *reinterpret_cast<uint2*>(&L.acc[ln]) = make_uint2(zz, zz); L.npair[ln] = (unsigned short)zz;
+        if (!again) {                                               // head of the tile's last read (kept if it stays open): the tile's last head
+            const u64 h1 = __ballot((m_head >> 4) != 0u), h0 = __ballot((m_head & 15u) != 0u);
+            if (h1 | h0) {
+                const u32 l = 63u - (u32)__builtin_clzll(h1 ? h1 : h0);
+                const u32 bits = (u32)__builtin_amdgcn_readlane((int)m_head, (int)l);
+                const u32 k = 31u - (u32)__builtin_clz(h1 ? bits & 0xF0u : bits & 0xFu);
+                last_pos = (k & 3u) + (k >> 2) * 256u + 4u * l;
             }
-            // The table's geometry (see WaveLds): two wave-uniform numbers
-            const u32 lg = nb > 1u ? 32u - (u32)__builtin_clz(nb - 1u) : 0u;       // ceil(log2 nb)
-            const u32 pm = (512u >> lg) - 1u, gp = (512u >> lg) + (TSLOTS == 896 ? (256u >> lg) : 0u) + (128u >> lg);
-            if (r_lo + nb == n_build) {                                 // head of the tile's last read (kept if it stays open): the tile's last head
-                const u64 h1 = __ballot((m_head >> 4) != 0u), h0 = __ballot((m_head & 15u) != 0u);
-                if (h1 | h0) {
-                    const u32 l = 63u - (u32)__builtin_clzll(h1 ? h1 : h0);
-                    const u32 bits = (u32)__builtin_amdgcn_readlane((int)m_head, (int)l);
-                    const u32 k = 31u - (u32)__builtin_clz(h1 ? bits & 0xF0u : bits & 0xFu);
-                    last_pos = (k & 3u) + (k >> 2) * 256u + 4u * l;
+            if (open && last_pos != 0xFFFFFFFFu) ws_put64(L, 0, ((u64)tix << 9) + last_pos, ln);   // (else: the open read stays the open read)
+        }
+
+        // ---- (b) the pass's {(read, locus) -> haplotype mask} table in LDS ------------------------------------
+        // Staged so that the 8 records' LDS round trips overlap: compare-and-swap on the key, OR of the bit.
+        // A ln whose CAS created an entry queues it; every entry is hashed once, at the flush, when all masks are final.
+        TICK(2);
+        if (!ABL(A, 1u)) {
+            // What the open read brought along from the pass before goes in WITH the records, as one more compare-and-swap per lane in the same
+            // round (a chain of LDS round trips of its own cost a fifth of the tile): entry c of the carry list is lane c's
+            // ninth "record" -- its haplotype "bit" is the whole mask so far.  (More than 64 of them: a second such round.)
+            const bool cin = carry_n != 0u;                      // (only right behind a flush: the open read is read 0 of the pass, tag 0)
+            u32 q[RPL + 1], old[RPL + 1], act = m_act;
+            bool anyc = false;                                   // some lane found its first slot taken by another (read, locus)
+            u32 c_key = 0, c_bit = 0;
+            if (cin && ln < carry_n) { const uint2 cv = L.carry[ln]; c_key = cv.x; c_bit = cv.y; act |= 1u << RPL; }
+            // Two rounds: the even record positions (and the carried entry), then the odd ones -- nine compare-and-swap
+            // results in flight at once are more registers than the kernel has, and in a paired-end stream the odd (or the
+            // even) positions are the mate records, which the filter drops: a round no lane has a record in is skipped.
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const u32 hmask = h ? 0x0AAu : 0x155u;           // positions of this round (bit RPL: the carried entry)
+                if (__ballot((act & hmask) != 0u) == 0ull) continue;
+#pragma unroll
+                for (int k = h; k <= RPL; k += 2) {  // (lanes without a record here swap nothing: they expect a value no slot ever holds, at a slot of their own)
+                    const u32 key = k < RPL ? r_key[k < RPL ? k : 0] : c_key;
+                    q[k] = (act >> k & 1u) ? (key >> KBITS) * gp + (key & pm) : ln;
+                }
+#pragma unroll
+                for (int k = h; k <= RPL; k += 2)
+                    old[k] = atomicCAS(tab_key(L, q[k]), (act >> k & 1u) ? 0u : 0xFFFFFFFFu, k < RPL ? r_key[k < RPL ? k : 0] : c_key);
+#pragma unroll
+                for (int k = h; k <= RPL; k += 2) {
+                    const u32 key = k < RPL ? r_key[k < RPL ? k : 0] : c_key, bit = k < RPL ? r_bit[k < RPL ? k : 0] : c_bit;
+                    const bool on = act >> k & 1u;
+                    const bool made = on && old[k] == 0u;                // this lane created the (read, locus) entry
+                    const bool hit = made || (on && old[k] == key);
+                    anyc |= on && !hit;
+                    atomicOr(tab_mask(L, q[k]), hit ? bit : 0u);         // duplicate (read, target) records vanish here: bam_utils.py:322-325
+                    const u64 mm = __ballot(made);
+                    if (made) L.ent[n_ent + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u))] =
+                        (unsigned short)(q[k] | ((key >> KBITS) << SBITS));
+                    n_ent += (u32)__popcll(mm);
                 }
             }
-            wave_sync();
-
-            // ---- (b) per-read {locus -> haplotype mask} tables in LDS ------------------------------------
-            // Staged so that the 8 records' LDS round trips overlap: segment reads, CAS on the locus, OR of the bit.
-            // A ln whose CAS created an entry queues it; every entry is hashed once when all masks are final.
-            TICK(2);
-            u32 n_ent = 0;
-            const u32 rl_last = nb - 1u;                             // the pass's last read: if it stays open, its entries are kept
-            const bool keep = carry_out && r_lo + nb == n_build;
-            if (!ABL(A, 1u)) {
-                // What the open read brought along goes in WITH the records, as one more compare-and-swap per lane in the same
-                // round (a chain of LDS round trips of its own cost a fifth of the tile): entry c of the carry list is lane c's
-                // ninth "record" -- its haplotype "bit" is the whole mask so far.  (More than 64 of them: a second such round.)
-                const bool cin = open && r_lo == 0u && carry_n != 0u;
-                u32 q[RPL + 1], old[RPL + 1], act = m_act;
-                bool anyc = false;                                   // some lane found its first slot taken by another (read, locus)
-                u32 c_key = 0, c_bit = 0;
-                if (cin && ln < carry_n) { const uint2 cv = L.carry[ln]; c_key = cv.x; c_bit = cv.y; act |= 1u << RPL; }
-                // Two rounds: the even record positions (and the carried entry), then the odd ones -- nine compare-and-swap
-                // results in flight at once are more registers than the kernel has, and in a paired-end stream the odd (or the
-                // even) positions are the mate records, which the filter drops: a round no lane has a record in is skipped.
+            if (__ballot(anyc) || (cin && carry_n > 64u)) {
+                // Rare: probe on.  Every record goes through the whole protocol once more (its first slot again, then the ones
+                // behind it): the lanes the rounds above served find their own entry and OR the same bit into it.
+                if (__ballot(anyc)) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const u32 hmask = h ? 0x0AAu : 0x155u;           // positions of this round (bit RPL: the carried entry)
-                    if (__ballot((act & hmask) != 0u) == 0ull) continue;
-#pragma unroll
-                    for (int k = h; k <= RPL; k += 2) {  // (lanes without a record here swap nothing: they expect a value no slot ever holds, at a slot of their own)
-                        const u32 key = k < RPL ? r_key[k < RPL ? k : 0] : c_key;
-                        q[k] = (act >> k & 1u) ? (key >> KBITS) * gp + (key & pm) : ln;
-                    }
-#pragma unroll
-                    for (int k = h; k <= RPL; k += 2)
-                        old[k] = atomicCAS(tab_key(L, q[k]), (act >> k & 1u) ? 0u : 0xFFFFFFFFu, k < RPL ? r_key[k < RPL ? k : 0] : c_key);
-#pragma unroll
-                    for (int k = h; k <= RPL; k += 2) {
+                    for (int k = 0; k <= RPL; ++k) {
                         const u32 key = k < RPL ? r_key[k < RPL ? k : 0] : c_key, bit = k < RPL ? r_bit[k < RPL ? k : 0] : c_bit;
-                        const bool on = act >> k & 1u;
-                        const bool made = on && old[k] == 0u;                // this lane created the (read, locus) entry
-                        const bool hit = made || (on && old[k] == key);
-                        anyc |= on && !hit;
-                        atomicOr(tab_mask(L, q[k]), hit ? bit : 0u);         // duplicate (read, target) records vanish here: bam_utils.py:322-325
+                        u32 qq = (key >> KBITS) * gp + (key & pm);
+                        bool made = false;
+                        if (act >> k & 1u) {
+                            u32 o, it = 0;                       // (the table always has a free slot: the bound only keeps corrupted
+                            for (;;) {                           //  state from spinning a wave for ever)
+                                o = atomicCAS(tab_key(L, qq), 0u, key);
+                                if (o == 0u || o == key || it >= (u32)TSLOTS) break;
+                                qq = next_slot(key, qq, it); ++it;
+                            }
+                            if (o != 0u && o != key) bad |= ERR_INTERNAL;
+                            else { made = (o == 0u); atomicOr(tab_mask(L, qq), bit); }
+                        }
                         const u64 mm = __ballot(made);
                         if (made) L.ent[n_ent + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u))] =
-                            (unsigned short)(q[k] | ((key >> KBITS) << SBITS));
+                            (unsigned short)(qq | ((key >> KBITS) << SBITS));
                         n_ent += (u32)__popcll(mm);
                     }
                 }
-                if (__ballot(anyc) || (cin && carry_n > 64u)) {
-                    // Rare: probe on.  Every record goes through the whole protocol once more (its first slot again, then the ones
-                    // behind it): the lanes the rounds above served find their own entry and OR the same bit into it.
-                    if (__ballot(anyc)) {
-#pragma unroll
-                        for (int k = 0; k <= RPL; ++k) {
-                            const u32 key = k < RPL ? r_key[k < RPL ? k : 0] : c_key, bit = k < RPL ? r_bit[k < RPL ? k : 0] : c_bit;
-                            u32 qq = (key >> KBITS) * gp + (key & pm);
-                            bool made = false;
-                            if (act >> k & 1u) {
-                                u32 o, it = 0;                       // (the table always has a free slot: the bound only keeps corrupted
-                                for (;;) {                           //  state from spinning a wave for ever)
-                                    o = atomicCAS(tab_key(L, qq), 0u, key);
-                                    if (o == 0u || o == key || it >= (u32)TSLOTS) break;
-                                    qq = next_slot(key, qq, it); ++it;
-                                }
-                                if (o != 0u && o != key) bad |= ERR_INTERNAL;
-                                else { made = (o == 0u); atomicOr(tab_mask(L, qq), bit); }
-                            }
-                            const u64 mm = __ballot(made);
-                            if (made) L.ent[n_ent + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u))] =
-                                (unsigned short)(qq | ((key >> KBITS) << SBITS));
-                            n_ent += (u32)__popcll(mm);
+                if (cin && carry_n > 64u) {                          // carried entries 64 .. CMAX - 1: a (rare) round of their own
+                    const bool go = ln + 64u < carry_n;
+                    const uint2 cv = L.carry[go ? ln + 64u : 0u];
+                    u32 qq = cv.x & pm;
+                    bool made = false;
+                    if (go) {
+                        u32 o, it = 0;
+                        for (;;) {
+                            o = atomicCAS(tab_key(L, qq), 0u, cv.x);
+                            if (o == 0u || o == cv.x || it >= (u32)TSLOTS) break;
+                            qq = next_slot(cv.x, qq, it); ++it;
                         }
+                        if (o != 0u && o != cv.x) bad |= ERR_INTERNAL;
+                        else { made = (o == 0u); atomicOr(tab_mask(L, qq), cv.y); }
                     }
-                    if (cin && carry_n > 64u) {                          // carried entries 64 .. CMAX - 1: a (rare) round of their own
-                        const bool go = ln + 64u < carry_n;
-                        const uint2 cv = L.carry[go ? ln + 64u : 0u];
-                        u32 qq = cv.x & pm;
-                        bool made = false;
-                        if (go) {
-                            u32 o, it = 0;
-                            for (;;) {
-                                o = atomicCAS(tab_key(L, qq), 0u, cv.x);
-                                if (o == 0u || o == cv.x || it >= (u32)TSLOTS) break;
-                                qq = next_slot(cv.x, qq, it); ++it;
-                            }
-                            if (o != 0u && o != cv.x) bad |= ERR_INTERNAL;
-                            else { made = (o == 0u); atomicOr(tab_mask(L, qq), cv.y); }
-                        }
-                        const u64 mm = __ballot(made);
-                        if (made) L.ent[n_ent + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u))] = (unsigned short)qq;
-                        n_ent += (u32)__popcll(mm);
-                    }
+                    const u64 mm = __ballot(made);
+                    if (made) L.ent[n_ent + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u))] = (unsigned short)qq;
+                    n_ent += (u32)__popcll(mm);
                 }
             }
+            carry_n = 0;
+        }
+        TICK(3);
+        // Flush now?  The stream or my slice ends here; the tile is not done (more reads in it than the pass had room for); or, going
+        // by this tile, the next one would bring more records than the table has room for entries, or more reads than the pass has room for.
+        do_flush = (npend != 0u || open) &&
+                   (!more || again || n_ent + n_mine > (u32)(WT + CMAX) || npend + (open ? 1u : 0u) + n_new > (1u << lg));
+        }
+
+        bool giant = false;
+        u32 new_carry = 0;
+        if (do_flush) {
             wave_sync();
-            TICK(3);
             // every entry is hashed once, now that its mask is final; the entries of a read that stays open are not: they go to
             // the carry list instead (same pass over the queue, no LDS round trips of their own)
             u32 cn = 0;
+            const u32 rl_last = npend;                               // the open read's index in the pass: its entries are kept
+            const bool keep = open;
             for (u32 e0 = 0; e0 < n_ent; e0 += 64) {
                 const u32 e = e0 + ln;
                 const bool have = e < n_ent;
@@ -854,12 +890,12 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
             wave_sync();
 
             TICK(4);
-            // ---- (c) one ln per read: EC lookup with exact key compare; a new EC gets its key from the read's LDS table ---------
+            // ---- (c) one ln per read: EC lookup with exact key compare; a new EC gets its key from the pass's LDS table ---------
             u64 j = 0;
             u32 st = ST_NONE, probes = 0, np = 0, fseen = 0;       // fseen: ~(first read) as the slot's line showed it (0 = nothing yet)
             u64 lo = 0;
-            const bool on = ln < nproc && !ABL(A, 3u);
-            const u32 rd = base + r_lo + ln;
+            const bool on = ln < npend && !ABL(A, 3u);
+            const u32 rd = pb + ln;
             LdsSetCmp cmp;
             cmp.L = &L; cmp.cold = C; cmp.home = ln * gp; cmp.pm = pm; cmp.tag = ln << KBITS; cmp.np = 0;
             if (on) {
@@ -888,7 +924,7 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
                 parked = parked_next; taken = true;
             } else {
                 // Lookup; founders publish their keys; THEN lanes whose slot was claimed but not (visibly) complete settle it --
-                // the founder such a ln waits for may be a ln of this very wave.  One round in all but a handful of tiles.
+                // the founder such a ln waits for may be a ln of this very wave.  One round in all but a handful of flushes.
                 for (u32 round = 0;; ++round) {
                     if (st == ST_LOOK) {
                         if (ABL(A, 64u)) { st = ST_HIT; fseen = 0xFFFFFFFFu; }   // (profiling: no table access at all, no first-read atomic)
@@ -897,7 +933,7 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
                     }
                     if (round == 0u) {
                         TICK(5);
-                        // Take over the prefetched tile HERE, right behind the lookup's own wait and before this tile issues any store.
+                        // Take over the prefetched tile HERE, right behind the lookup's own wait and before this flush issues any store.
                         // vmcnt counts in order: wherever the compiler first touches these registers it waits for everything issued before
                         // that point, and at the end of the tile (where the moves sink to if left alone) or at the top of the next one
                         // (the parked flag) that meant sitting out the round trips of the founders' stores -- ~3000 clocks per tile on C3.
@@ -967,7 +1003,8 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
                 if (st == ST_FULL) {                                    // table too full here: defer the read, park
                     atomicExch(&A.ctr->full, 1u);
                     const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
-                    const u64 head = (open && r_lo == 0u && ln == 0u) ? ws_get64(L, 0) : tile_head(A.rid, (u64)tix << 9, min(((u64)tix << 9) + (u64)WT, A.n), rd);
+                    // (its head: the first record of the read among those of my slice up to the tile in hand -- the run counter never decreases)
+                    const u64 head = tile_head(A.rid, (u64)wid * C->chunk, min(((u64)tix << 9) + (u64)WT, A.n), rd);
                     if (qi < C->queue_cap) C->queue[qi] = head; else atomicOr(&A.ctr->err, ERR_QUEUE);
                 } else if (st == ST_HIT) {
                     A.read_slot[rd] = (u32)j;
@@ -977,9 +1014,28 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
                 }
             }
             wave_sync();
+            // the next pass: an empty table, its read 0 the read after the ones just looked up (the open one, if there is one)
+            clear_pass(ln);
+            pb += npend; npend = 0; n_ent = 0;
+            const u32 e4 = est < 16u ? est * 4u : 64u;
+            lg = e4 > 1u ? 32u - (u32)__builtin_clz(e4 - 1u) : 0u;    // room for four tiles like this one, 64 reads at most
+            if (open) {
+                if (!giant) carry_n = new_carry;
+                else {                                               // more entries than a pass carries over: one workgroup for this read (k_slow)
+                    if (ln == 0) {
+                        const u64 head = ws_get64(L, 0);
+                        const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
+                        if (qi < C->queue_cap) C->queue[qi] = head; else atomicOr(&A.ctr->err, ERR_QUEUE);
+                    }
+                    open = false; pb += 1u;                           // (the rest of a giant read is skipped: not a head, not open, not mine)
+                }
+            }
+            ws_put64(L, 5, open ? ws_get64(L, 0) : (u64)((preflush || again) ? tix : tix + 1u) << 9, ln);
+            wave_sync();
             TICK(6);
         }
-        if (!taken) {                                                // a tile without a read of mine (leading records of the slice)
+        if (preflush) { revisit = true; continue; }                  // (the tile is still in its registers: nothing was prefetched over it)
+        if (!taken) {                                                // no flush behind this tile: the prefetched one is waited for here
             parked = parked_next;
 #pragma unroll
             for (int k = 0; k < RPL; ++k) {
@@ -988,33 +1044,20 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
             }
             asm volatile("" : "+v"(parked));
         }
-        if (again) { r_lo += (u32)WMAXR; continue; }                 // same tile, next WMAXR reads (p_rel stays: the tile is loaded again)
-        r_lo = 0; p_rel = 0;
-        // state for the next tile
-        if (carry_out && !giant) {
-            if (last_pos != 0xFFFFFFFFu) ws_put64(L, 0, ((u64)tix << 9) + last_pos, ln);   // (else: the open read stays the open read)
-            open = true; carry_n = new_carry; base = last_rid;
-        } else {
-            if (carry_out && giant) {                                // more entries than a tile's pad takes: one workgroup for this read (k_slow)
-                const u64 head = last_pos != 0xFFFFFFFFu ? ((u64)tix << 9) + last_pos : ws_get64(L, 0);
-                if (ln == 0) {
-                    const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
-                    if (qi < C->queue_cap) C->queue[qi] = head; else atomicOr(&A.ctr->err, ERR_QUEUE);
-                }
-            }
-            open = false; carry_n = 0; base = last_rid + 1u;          // (the rest of a giant read is skipped: not a head, not open)
-        }
+        if (again) { revisit = true; continue; }                     // same tile, the reads after the ones just looked up (p_rel stays: the tile is loaded again)
+        revisit = false; p_rel = 0;
+        prev = last_rid;
         slice_done = !more;
         tix += 1u;
     }
-    // where a relaunch takes this slice up: at the head of the read that is open, else at the tile that comes next
-    u64 p_out = open ? ws_get64(L, 0) : (u64)tix << 9;
-    const u64 counted = max(counted0, min((u64)(r_lo ? tix + 1u : tix) << 9, c1));   // (every tile before tix has been counted; tix itself once its first pass is through)
-    const bool stop = __ballot(bad != 0u) || __builtin_amdgcn_readfirstlane((int)parked);
+    // where a relaunch takes this slice up: at the head of the first read that has not been looked up
+    u64 p_out = ws_get64(L, 5);
+    const u64 counted = max(counted0, min((u64)(revisit ? tix + 1u : tix) << 9, c1));   // (every tile before tix has been counted; tix itself once its first visit is through)
+    const bool stopped = __ballot(bad != 0u) || __builtin_amdgcn_readfirstlane((int)parked);
     if (__ballot(bad != 0u)) { if (bad) atomicOr(&A.ctr->err, bad); p_out = ~0ull; }
     else if (slice_done) p_out = ~0ull;
     if (lane == 0) { u64* rs = C->resume; rs[2 * (u64)wid] = p_out; rs[2 * (u64)wid + 1] = counted; }
-    if (stop) break;
+    if (stopped) break;
   }
     // records offered / valid: one atomic pair per wave
     const u32 wa = 0u, wv = wave_sum(my_valid);
