@@ -32,7 +32,10 @@ def open_bam(filename, names=True, ms=False):
     if not names and os.environ.get("ALNTOOLS_DECODER", "c") != "py":
         from . import bamdec
         if bamdec.available():
-            return bamdec.NativeBamReader(filename)
+            try:
+                return bamdec.NativeBamReader(filename)
+            except ValueError:                       # not BGZF / not BAM (SAM, CRAM ...): what pysam, the reference's reader, may still open
+                pass
     try:
         import pysam
     except ImportError:
@@ -111,7 +114,7 @@ def stream_bam_to_builder(bam_filename, builder, maps=None, target_filename=None
             reader.close()
 
 
-def _write_outputs(maps, sample, sizes, out, range_len, ec_filename, emase_filename, range_filename):
+def _write_outputs(maps, sample, sizes, out, range_len, ec_filename, emase_filename, range_filename, device=None):
     if range_filename:
         write_range_file(range_filename, maps, range_len)
     m = ECMatrices(maps.haplotypes, maps.main_targets, maps.lengths, [sample], out["indptrA"], out["indicesA"],
@@ -123,7 +126,7 @@ def _write_outputs(maps, sample, sizes, out, range_len, ec_filename, emase_filen
             os.remove(emase_filename)
         except OSError:
             pass
-        emase_h5.save(emase_filename, m, title='bam2ec', incidence_only=True, count_2d=True)     # bam_utils.py:845, 861: count is a csc column
+        emase_h5.save(emase_filename, m, title='bam2ec', incidence_only=True, count_2d=True, device=device)     # bam_utils.py:845, 861: count is a csc column
     if ec_filename:
         LOG.info("Saving to {}...".format(ec_filename))
         try:
@@ -199,7 +202,7 @@ def _rank_convert(rank, world, port, backend, devices, bam_filename, ec_filename
         sizes = mb.finalize()
         out = mb.export()
         _log_summary(maps, sizes)
-        _write_outputs(maps, sample, sizes, out, range_len, ec_filename, emase_filename, range_filename)
+        _write_outputs(maps, sample, sizes, out, range_len, ec_filename, emase_filename, range_filename, device=dev_index)
         with open(result_path, "w") as f:
             json.dump(sizes, f)
     tdist.barrier()
@@ -263,6 +266,6 @@ def convert(bam_filename, ec_filename, emase_filename, num_chunks=0, number_proc
                                                                      utils.format_time(start_time, time.time())))
         _log_summary(maps, sizes)
         range_len = b.export_ranges() if range_filename else None
-    _write_outputs(maps, sample, sizes, out, range_len, ec_filename, emase_filename, range_filename)
+    _write_outputs(maps, sample, sizes, out, range_len, ec_filename, emase_filename, range_filename, device=device)
     LOG.info("Done, total time: {}".format(utils.format_time(start_time, time.time())))
     return sizes

@@ -169,7 +169,7 @@ def convert_files(bam_files, ec_filename, emase_filename, minimum_count=-1, rang
                    f["indptrA"], f["indicesA"], f["dataA"], f["indptrN"], f["indicesN"], f["dataN"])
     if emase_filename:
         from . import emase_h5
-        emase_h5.save(emase_filename, m, title='Multisample APM', incidence_only=False, count_2d=True)   # :806; N is a csc matrix whatever S is (:783-791)
+        emase_h5.save(emase_filename, m, title='Multisample APM', incidence_only=False, count_2d=True, device=device)   # :806; N is a csc matrix whatever S is (:783-791)
     if ec_filename:
         try:
             os.remove(ec_filename)

@@ -20,6 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libbamdec.so")
 SRC = os.path.join(_HERE, "csrc", "bamdec.c")
 SYMBOLS = ("bd_abi_version", "bd_open", "bd_close", "bd_last_error", "bd_n_references", "bd_reference_name",
            "bd_reference_length", "bd_header_text", "bd_references", "bd_read", "bd_read_tuples", "bd_read_ms", "bd_ms_cells")
+ABI_VERSION = 2            # include/bamdec.h: bd_abi_version()
 _lib = None
 
 
@@ -39,7 +40,13 @@ def available():
 def lib():
     global _lib
     if _lib is None:
+        if os.path.exists(SRC) and os.path.getmtime(LIB_PATH) < os.path.getmtime(SRC):
+            build()                                  # (a library older than its source: the argument lists below may not be its own)
         l = C.CDLL(LIB_PATH)
+        l.bd_abi_version.restype = C.c_int
+        if l.bd_abi_version() != ABI_VERSION:
+            raise ImportError("%s has ABI %d, this binding is for ABI %d: rebuild it (python -m alntools_amd.build)"
+                              % (LIB_PATH, l.bd_abi_version(), ABI_VERSION))
         l.bd_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
         l.bd_close.argtypes = [C.c_void_p]
         l.bd_close.restype = None

@@ -24,7 +24,11 @@ def needs_build():
 def build(force=False, verbose=False):
     """Compile the HIP extension; returns the path of the shared library."""
     from . import bamdec
-    bamdec.build(force=force)                    # the host side's BAM decoder (plain C + zlib): a library of its own
+    try:
+        bamdec.build(force=force)                # the host side's BAM decoder (plain C + zlib): a library of its own, and optional --
+    except (OSError, subprocess.CalledProcessError) as e:             # without it the pure-Python reader (or pysam) decodes
+        print("warning: libbamdec.so not built (%s): BAM files will be decoded by the Python reader" % e, file=sys.stderr)
+    build_tools(force=force)
     if not force and not needs_build():
         return OUT
     cmd = [HIPCC] + FLAGS + ["-o", OUT, SRC]
@@ -32,6 +36,17 @@ def build(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     return OUT
+
+
+def build_tools(force=False):
+    """Measurement helpers that bench.py loads when they are there (never the product): tools/micro/copy_peak.hip."""
+    src = os.path.join(HERE, "..", "tools", "micro", "copy_peak.hip")
+    out = os.path.join(HERE, "..", "tools", "micro", "bin", "libcopy_peak.so")
+    if not os.path.exists(src) or (not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src)):
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-o", out, src])
+    return out
 
 
 def build_sanitized(out=None, verbose=False):

@@ -258,6 +258,13 @@ constexpr int NWAVE = TPB / 64;
 #ifndef ECB_WAVES_PER_SIMD
 #define ECB_WAVES_PER_SIMD 5   // 96 VGPRs, 7.4 KB of LDS per wave: five workgroups per CU (measured against four with 128 / 9.4 KB: -7.5 % on C3)
 #endif
+#ifndef ECB_LGMAX
+#define ECB_LGMAX 6            // a pass takes at most 1 << ECB_LGMAX reads (one lane each in phase (c): 6 at most)
+#endif
+#ifndef ECB_EST_MUL
+#define ECB_EST_MUL 4          // ... and is laid out for this many tiles like the one that ended the pass before
+#endif
+static_assert(ECB_LGMAX >= 0 && ECB_LGMAX <= 6, "one lane per read in phase (c)");
 constexpr int CMAX = 80;                              // (locus, mask) entries an unfinished read may carry into the next tile
 #ifndef ECB_TSLOTS
 #define ECB_TSLOTS (ECB_WAVES_PER_SIMD > 4 ? 640 : 896)
@@ -577,7 +584,7 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
     ws_put64(L, 5, p, lane);
     bool open = false;
     u32 carry_n = 0;                              // entries in L.carry: the open read's, waiting to go into the fresh table
-    u32 lg = 6;                                   // the pass has room for 1 << lg reads (see WaveLds: the table's geometry)
+    u32 lg = ECB_LGMAX;                           // the pass has room for 1 << lg reads (see WaveLds: the table's geometry)
     bool revisit = false;                         // the tile has been visited before (more reads in it than a pass takes)
     TileRegs R;
     load_tile(A, (u64)tix << 9, min(((u64)tix << 9) + (u64)WT, A.n), lane, R);
@@ -1017,7 +1024,7 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
             // the next pass: an empty table, its read 0 the read after the ones just looked up (the open one, if there is one)
             clear_pass(ln);
             pb += npend; npend = 0; n_ent = 0;
-            const u32 e4 = est < 16u ? est * 4u : 64u;
+            const u32 e4 = min(est * (u32)ECB_EST_MUL, 1u << ECB_LGMAX);
             lg = e4 > 1u ? 32u - (u32)__builtin_clz(e4 - 1u) : 0u;    // room for four tiles like this one, 64 reads at most
             if (open) {
                 if (!giant) carry_n = new_carry;

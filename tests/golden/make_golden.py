@@ -18,6 +18,7 @@ Fixtures:
   g3_mid.*       8 haplotypes x 2k transcripts, 60k reads (md5 + counters only)
   g3_pe.*        paired-end 8 x 500, 8k reads
   g4_multi.*     multisample directory (3 files, cells in '|||' field 14, min-count edge)
+  g4b_multi.*    multisample at some size: 6 files, 21 000 reads, 260 cells (records regenerated from tests/golden/g4b_gen.py)
   g5_binwalk.*   tiny APM -> reference ecsave2 bytes and reference ecload arrays
   g6_utils.json  utils.partition / int_to_list / list_to_int truth tables
 """
@@ -37,6 +38,7 @@ REPO = os.path.abspath(os.path.join(HERE, "..", ".."))
 sys.path.insert(0, "/root/reference")
 sys.path.insert(0, os.path.join(HERE, "_standins"))
 sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
 
 import numpy as np  # noqa: E402
 
@@ -238,6 +240,34 @@ def g4_multi():
     print("g4:", {k: v[2] for k, v in out.items()}, "glob order", order)
 
 
+def g4b_multi():
+    """A multisample case of some size (6 files, 21 000 reads, 260 cells): pins the oracle -- and through it the numpy checker the
+    full-size GPU tests use (tests/ms_checker.py) -- where g4's 360 reads and 8 cells cannot: hundreds of cells, most below any
+    threshold, ECs that lose all their cells, cells that only appear in later files."""
+    import g4b_gen
+    refs = g4b_gen.references()
+    files = g4b_gen.files()
+    work = tempfile.mkdtemp(prefix="g4b_")
+    out = {}
+    try:
+        d = os.path.join(work, "bams")
+        os.mkdir(d)
+        for fname, recs in files.items():
+            bamio.write_bam(os.path.join(d, fname), refs, recs)
+        order = [os.path.basename(p) for p in glob.glob(os.path.join(d, "*.bam"))]
+        for mc in g4b_gen.MINCOUNTS:
+            b, r, c, lines = run_reference(d, None, multisample=True, minimum_count=mc)
+            out[mc] = (b, r, c)
+            open(os.path.join(HERE, "g4b_multi_min%s.bin" % (mc if mc > 0 else "0")), "wb").write(b)
+        open(os.path.join(HERE, "g4b_multi.range.txt"), "w").write(out[-1][1])
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    dump_json("g4b_multi.json", dict(generator="tests/golden/g4b_gen.py", seed=20260104, glob_order=order,
+                                     counters={str(k): v[2] for k, v in out.items()},
+                                     bin_md5={str(k): md5(v[0]) for k, v in out.items()}))
+    print("g4b:", {k: v[2] for k, v in out.items()}, "glob order", order)
+
+
 def g5_binwalk():
     from scipy.sparse import coo_matrix, csc_matrix
     apm = RefAPM(shape=(3, 2, 4), haplotype_names=["A", "B"], locus_names=["L0", "L1", "L2"],
@@ -279,7 +309,7 @@ def g6_utils():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
-    fns = dict(g1=g1_edge, g2=g2_c1, g3=g3_mid, g4=g4_multi, g5=g5_binwalk, g6=g6_utils)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g4b", "g5", "g6"]
+    fns = dict(g1=g1_edge, g2=g2_c1, g3=g3_mid, g4=g4_multi, g4b=g4b_multi, g5=g5_binwalk, g6=g6_utils)
     for w in which:
         fns[w]()

@@ -371,6 +371,7 @@ def test_full_size_config3_properties():
         s = b.finalize()
         whole = b.export()
     assert s["all_alignments"] == st["records"] and s["valid_alignments"] == st["valid"] and s["n_reads"] == st["reads"]
+    _assert_equals_oracle(rid, loc, hf, H, whole, s)              # 3.7 M ECs in the reference's order, every row, every count
     assert int(whole["dataN"].astype(np.int64).sum()) == st["reads"]
     with ecb.EcBuilder(T, H, ec_capacity=1 << 24) as b:          # exact grouping at full size: 0 of 96 M reads differ
         b.push_device(rid, loc, hf)
@@ -425,6 +426,18 @@ def test_full_size_config3_properties():
     root.b.close()
 
 
+def _assert_equals_oracle(rid, loc, hf, n_haps, out, s):
+    """The whole stream through the oracle's C restatement (oracle/ec_oracle.c, all host threads) and the device's CSR A, counts and
+    counters against it, bit for bit -- EC order (bam_utils.py:680-698) included, at BASELINE's full sizes."""
+    from oracle import c_oracle
+    host = [t.cpu().numpy().view(np.uint32) for t in (rid, loc, hf)]
+    exp = c_oracle.ec_from_tuples(host[0], host[1], host[2], n_haps, threads=os.cpu_count() or 1)
+    del host
+    assert (s["all_alignments"], s["valid_alignments"], s["n_reads"], s["n_ecs"]) == (exp["n_all"], exp["n_valid"], exp["n_reads"], len(exp["count"]))
+    for a, k in (("indptrA", "indptr"), ("indicesA", "indices"), ("dataA", "data"), ("dataN", "count")):
+        assert np.array_equal(out[a], exp[k]), a
+
+
 def _mix64(x, seed):
     with np.errstate(over="ignore"):
         x = x + np.uint64(seed)
@@ -463,6 +476,7 @@ def test_full_size_config2_properties():
         s = b.finalize()
         out = b.export()
     assert s["all_alignments"] == st["records"] and s["valid_alignments"] == st["valid"] and s["n_reads"] == st["reads"]
+    _assert_equals_oracle(rid, loc, hf, H, out, s)
     assert int(out["dataN"].astype(np.int64).sum()) == st["reads"] and out["dataN"].min() >= 1
     assert np.all(np.diff(out["indptrA"]) > 0) and out["indptrA"][-1] == s["nnz_a"]
     assert out["indicesA"].min() >= 0 and out["indicesA"].max() < T and out["dataA"].min() >= 1 and out["dataA"].max() < (1 << H)
@@ -500,7 +514,18 @@ def test_full_size_config4_multisample_triples():
         s = b.finalize()
         pr = b.export_pairs()
         rec = torch.from_numpy(b.export_read_ec()).to(dev)
+        a = b.export()
+        f = b.ms_filter(5000, 1000)                                               # config 4's minimum count
     assert s["n_reads"] == n_reads and int(pr["count"].sum()) == n_reads
+    # cell order, filter, EC re-rank, CSC N and the surviving rows of A at config 4's size, against the numpy restatement that
+    # tests/test_oracle_golden.py holds to the reference's bytes
+    from ms_checker import reduce_triples, select_rows
+    kept, ec_keep, (n_ptr, n_idx, n_dat) = reduce_triples(pr, s["n_ecs"], 5000, 1000)
+    a_ptr, a_idx, a_dat = select_rows(a["indptrA"], a["indicesA"], a["dataA"], ec_keep)
+    assert f["kept_cells"].tolist() == kept and 0 < len(kept) <= 5000
+    for k, exp in (("indptrA", a_ptr), ("indicesA", a_idx), ("dataA", a_dat), ("indptrN", n_ptr), ("indicesN", n_idx), ("dataN", n_dat)):
+        assert np.array_equal(f[k], exp), k
+    del a, f, kept, ec_keep, n_ptr, n_idx, n_dat, a_ptr, a_idx, a_dat
     key = (rec.to(torch.int64) << 32) | (meta.to(torch.int64) & 0xFFFFFFFF)
     order = torch.argsort(key, stable=True)
     ks = key[order]

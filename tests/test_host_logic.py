@@ -234,6 +234,70 @@ def test_emase_h5_structure_matches_the_documented_layout(golden_dir, tmp_path):
         assert np.array_equal(back.dataN, m.dataN) and back.sname == m.sname and back.lname == m.lname
 
 
+def test_emase_h5_pickled_attributes_unpickle_to_shape_and_haplotype_names(golden_dir, tmp_path):
+    """The two attributes PyTables stores as pickled Python objects -- ``shape`` = (T, H, E) (Sparse3DMatrix.py:329) and ``hname`` =
+    the haplotype list (AlignmentPropertyMatrix.py:511) -- read back as RAW bytes by an independent tool (h5dump) and un-pickled
+    here: what the loader of the reference gets from ``get_node_attr`` (Sparse3DMatrix.py:36, AlignmentPropertyMatrix.py:124)."""
+    import pickle
+    import re
+    import subprocess
+    from alntools_amd import emase_h5
+    try:
+        emase_h5._backend()
+    except RuntimeError:
+        pytest.skip("no HDF5 library in this environment")
+    exe = os.path.join(os.environ.get("CONDA_PREFIX", "/opt/conda"), "bin", "h5dump")
+    if not os.path.exists(exe):
+        pytest.skip("no h5dump in this environment")
+    m = bin_utils.ecload(os.path.join(golden_dir, "g2_c1.bin"))
+    path = str(tmp_path / "a.h5")
+    emase_h5.save(path, m, title="t", incidence_only=True, count_2d=True, hapcsc=emase_h5.scipy_hapcsc)
+
+    def raw_attr(name):
+        out = subprocess.run([exe, "-e", "-a", "/" + name, path], capture_output=True, text=True)      # (-e: escapes, not raw newlines)
+        assert out.returncode == 0, out.stderr
+        data = out.stdout[out.stdout.index("DATA {"):]
+        pieces = re.findall(r'"((?:[^"\\]|\\.)*)"', data)           # h5dump prints a long string in quoted pieces
+        txt = "".join(pieces)
+        return txt.encode("latin-1").decode("unicode_escape").encode("latin-1")
+
+    assert tuple(int(x) for x in pickle.loads(raw_attr("shape"))) == m.shape
+    hname = pickle.loads(raw_attr("hname"))
+    assert [h.decode() if isinstance(h, bytes) else str(h) for h in hname] == list(m.hname)
+    assert raw_attr("mtype") .rstrip(b"\0") == b"csc_matrix"        # (a plain string: the loader calls .decode('utf-8') on it, Sparse3DMatrix.py:54)
+
+
+def test_open_bam_leaves_a_file_the_native_decoder_refuses_to_the_reference_reader(tmp_path, monkeypatch):
+    """A SAM text file is not BGZF: ``bd_open`` refuses it (BD_ERR_FORMAT -> ValueError).  ``open_bam`` then falls through to
+    pysam -- the reference's own reader (bam_utils.py:561), which opens SAM and CRAM too -- instead of failing on a file the reference takes."""
+    import sys
+    import types
+    from alntools_amd import bam_utils, bamdec
+    if not bamdec.available():
+        pytest.skip("libbamdec.so not built")
+    sam = tmp_path / "x.sam"
+    sam.write_text("@HD\tVN:1.0\n@SQ\tSN:t1_A\tLN:100\nr1\t0\tt1_A\t1\t255\t4M\t*\t0\t0\tACGT\tIIII\n")
+    with pytest.raises(ValueError):
+        bamdec.NativeBamReader(str(sam))
+    opened = []
+
+    class FakeAlignmentFile(object):
+        references, lengths = ("t1_A",), (100,)
+
+        def __init__(self, name, check_sq=True):
+            opened.append(name)
+
+        def fetch(self, until_eof=False):
+            return iter(())
+
+        def close(self):
+            pass
+
+    monkeypatch.setitem(sys.modules, "pysam", types.SimpleNamespace(AlignmentFile=FakeAlignmentFile))
+    rd = bam_utils.open_bam(str(sam), names=False)
+    assert opened == [str(sam)] and type(rd).__name__ == "_PysamReader" and rd.references == ("t1_A",)
+
+
 @pytest.mark.parametrize("batch", [1, 7, 100000])
 def test_native_bam_decoder_yields_the_tuples_of_the_python_reader(golden_dir, tmp_path, batch):
     """csrc/bamdec.c (BGZF inflate on threads, record parse, filter verdict, read heads by name runs) against bamio.BamReader +

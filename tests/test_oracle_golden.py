@@ -105,6 +105,81 @@ def test_g4_multisample(golden_dir):
     assert out["range"] == open(os.path.join(golden_dir, "g4_multi.range.txt")).read()
 
 
+def _g4b(golden_dir):
+    import sys
+    sys.path.insert(0, golden_dir)
+    import g4b_gen
+    g = _load(golden_dir, "g4b_multi.json")
+    refs = g4b_gen.references()
+    recs = g4b_gen.files(g["seed"])
+    return g, [r[0] for r in refs], [r[1] for r in refs], [recs[f] for f in g["glob_order"]], g4b_gen.MINCOUNTS
+
+
+def test_g4b_multisample_at_some_size(golden_dir):
+    """6 files, 21 000 reads, 338 cell names (260 barcodes + the ones the untrimmed-name quirk makes): the oracle against the bytes
+    the reference wrote at three thresholds (all cells / 80 / 34 kept; ECs that lose every cell dropped and the rest re-ranked)."""
+    g, refs, lens, files, mcs = _g4b(golden_dir)
+    for mc in mcs:
+        out = orc.convert_multisample(refs, lens, files, mc, None, want_range=True)
+        assert out["bin"] == _bytes(golden_dir, "g4b_multi_min%s.bin" % (mc if mc > 0 else "0")), mc
+        c = g["counters"][str(mc)]
+        assert out["counters"]["valid"] == c["Number of alignments"]
+        assert out["counters"]["ecs"] == c["Number of ECs after filtering"] and out["counters"]["ecs_before"] == c["Number of ECs"]
+        assert out["counters"]["cells"] == c["Number of cells after filtering"] and out["counters"]["cells_before"] == c["Number of cells"]
+    assert out["range"] == open(os.path.join(golden_dir, "g4b_multi.range.txt")).read()
+
+
+def _triples_from_scans(files):
+    """(EC, cell, file) triples as libecb exports them -- EC ids by first appearance over the files in order, cell ids by first
+    appearance, ``first`` = a stand-in for the first read index that orders like it (ECs within a file by first appearance, cells
+    within an EC by first appearance: the insertion orders of the reference's dicts, bam_utils_multisample.py:288-290) -- plus the
+    EC keys and cell names."""
+    ec_id, cell_id = {}, {}
+    rows, at = [], 0
+    for fi, recs in enumerate(files):
+        r = orc.scan_multisample(recs)
+        n_keys = len(r["ec"])
+        for ki, (key, cells) in enumerate(r["ec"].items()):
+            e = ec_id.setdefault(key, len(ec_id))
+            for ci, (cell, cnt) in enumerate(cells.items()):
+                c = cell_id.setdefault(cell, len(cell_id))
+                # first read of (EC, cell) in this file: after the EC's own first read, before the next EC's
+                rows.append((e, c, fi, cnt, at + ki * 100000 + ci))
+        at += (n_keys + 1) * 100000
+    a = np.asarray(rows, dtype=np.int64)
+    tr = dict(ec=a[:, 0], cell=a[:, 1], file=a[:, 2], count=a[:, 3], first=a[:, 4])
+    return tr, list(ec_id.keys()), list(cell_id.keys())
+
+
+@pytest.mark.parametrize("case", ["g4", "g4b"])
+def test_numpy_multisample_checker_is_held_to_the_oracle(golden_dir, case):
+    """tests/ms_checker.reduce_triples -- what the full-size GPU tests trust for ecb_ms_filter -- against the reference's bytes (through
+    the oracle's reader): sample order, the ECs that survive, CSC N, at three thresholds, on the small fixture and on the one with
+    hundreds of cells.  The one quirk the triples cannot express: within one file an EC's cells are ordered by first appearance, which
+    the stand-in ``first`` reproduces from the scan's dict order."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from ms_checker import reduce_triples
+    if case == "g4":
+        g = _load(golden_dir, "g4_multi.json")
+        refs, lens = [r[0] for r in g["references"]], [r[1] for r in g["references"]]
+        files = [[tuple(r) for r in g["files"][f]] for f in g["glob_order"]]
+        mcs, tag = (-1, 20, 60), "g4_multi_min%s.bin"
+    else:
+        g, refs, lens, files, mcs = _g4b(golden_dir)
+        tag = "g4b_multi_min%s.bin"
+    tr, keys, cells = _triples_from_scans(files)
+    maps = orc.header_maps(refs, lens, None)
+    for mc in mcs:
+        ref = orc.ecload_bytes(_bytes(golden_dir, tag % (mc if mc > 0 else "0")))
+        kept, ec_keep, (n_ptr, n_idx, n_dat) = reduce_triples(tr, len(keys), len(cells), mc)
+        assert [cells[c] for c in kept] == list(ref["sname"]), mc
+        assert int(ec_keep.sum()) == len(ref["indptrA"]) - 1
+        assert np.array_equal(n_ptr, ref["indptrN"]) and np.array_equal(n_idx, ref["indicesN"]) and np.array_equal(n_dat, ref["dataN"]), mc
+        a = orc.combined_csr(orc.build_incidence(maps, [k for k, keep in zip(keys, ec_keep) if keep]))   # rows of A of the ECs the checker keeps
+        assert np.array_equal(a.indptr, ref["indptrA"]) and np.array_equal(a.indices, ref["indicesA"]) and np.array_equal(a.data, ref["dataA"]), mc
+
+
 def test_g5_bin_walk(golden_dir):
     g = _load(golden_dir, "g5_binwalk.json")
     b = _bytes(golden_dir, "g5_binwalk.bin")

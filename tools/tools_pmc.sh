@@ -1,12 +1,12 @@
 #!/bin/bash
 # GPU box: PMC counters for k_stream (separate passes, no tracing domains besides kernel-trace).  usage: tools_pmc.sh <workload> <outdir>
 W=${1:-c2}; OUT=${2:-gpurun_out/pmc}
-R=$GRAFT_REPO_ROOT; mkdir -p $R/$OUT
+R=$GRAFT_REPO_ROOT; mkdir -p $R/$OUT; RAW=/tmp/pmc_raw_$$; mkdir -p $RAW   # (raw rocprofv3 output stays on the box: only summaries travel back)
 cd /tmp && export TMPDIR=/tmp ECB_NO_VERIFY=1
 run() { # name counters...
   name=$1; shift
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "k_stream<false, false>" --output-format csv -d $R/$OUT/$name -- python $R/bench.py --workload $W --steps 1 --warmup 0 --no-cpu-baseline > $R/$OUT/$name.log 2>&1
-  f=$(find $R/$OUT/$name -name "*counter_collection.csv" | head -1)
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "k_stream<false, false>" --output-format csv -d $RAW/$name -- python $R/bench.py --workload $W --steps 1 --warmup 0 --no-cpu-baseline > $R/$OUT/$name.log 2>&1
+  f=$(find $RAW/$name -name "*counter_collection.csv" | head -1)
   python - "$f" <<'PY'
 import csv, sys, collections
 d = collections.defaultdict(float); n = collections.defaultdict(int)

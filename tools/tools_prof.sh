@@ -1,11 +1,11 @@
 #!/bin/bash
 # GPU box: rocprofv3 kernel trace of one bench run; prints libecb's kernels only.  usage: tools_prof.sh <workload> <outdir>
 W=${1:-c2}; OUT=${2:-gpurun_out/prof}
-R=$GRAFT_REPO_ROOT; mkdir -p $R/$OUT
+R=$GRAFT_REPO_ROOT; mkdir -p $R/$OUT; RAW=/tmp/prof_raw_$$; mkdir -p $RAW
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT -- python $R/bench.py --workload $W --steps 5 --warmup 1 --no-cpu-baseline > $R/$OUT/run.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW -- python $R/bench.py --workload $W --steps 5 --warmup 1 --no-cpu-baseline > $R/$OUT/run.log 2>&1
 cd $R
-f=$(find $OUT -name "*kernel_stats.csv" | head -1)
+f=$(find $RAW -name "*kernel_stats.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'anonymous namespace)::k_' in r['Name'] or 'fillBuffer' in r['Name']]   # (+ the runtime's fill kernels: hipMemsetAsync in reset)
