@@ -30,6 +30,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -2163,6 +2164,97 @@ __global__ void k_cv_back_rowptr(const u64* keys, const u32* pos, u64 total, u32
     indptr[e] = at < total ? (int)pos[at] : (int)nnz;       // pos[] = index of the run that starts at or after `at`
 }
 
+// ---- CSR(bitmask) -> per-haplotype CSC as a transposition of the NON-ZEROS (bin_utils.py:979-995, Sparse3DMatrix.py:189-193) ----
+// The non-zeros (locus, EC, mask) are sorted by locus -- stable, so ECs stay ascending within a column -- which is the whole
+// transposition: 12 M elements and the digits of the locus alone (three 8-bit passes at 80 k loci), not the 79 M set bits and the
+// digits of (haplotype, locus).  A haplotype's row indices are then the ECs of the sorted non-zeros that carry its bit, in
+// that order: one counting pass per block of CVB non-zeros, one scan over (haplotype, block), one pass that writes.
+constexpr int CVB = 1024;
+__global__ __launch_bounds__(TPB) void k_cv_bits(const int* data, u64 nnz, u64* total) {
+    u64 v = 0;
+    for (u64 i = blockIdx.x * (u64)TPB + threadIdx.x; i < nnz; i += (u64)gridDim.x * TPB) v += __popc((u32)data[i]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    if ((threadIdx.x & 63u) == 0 && v) atomicAdd(total, v);
+}
+// one thread per row: key = locus << 32 | EC, value = mask; what a .bin of unknown origin may hold is checked here
+__global__ void k_cv_keys(const int* indptr, u32 n_ecs, const int* indices, const int* data, u64 nnz, u32 n_loci, u32 n_haps,
+                          u64* keys, u32* vals, u32* err) {
+    const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (e >= n_ecs) return;
+    const long long a = indptr[e], b = indptr[e + 1];
+    if (a < 0 || b < a || (u64)b > nnz || (e == 0 && a != 0)) { atomicOr(err, 1u); return; }
+    bool bad = false;
+    for (long long i = a; i < b; ++i) {
+        const u32 lc = (u32)indices[i], m = (u32)data[i];
+        bad |= lc >= n_loci || m == 0u || (m >> n_haps) != 0u;
+        keys[i] = ((u64)lc << 32) | (u32)e;
+        vals[i] = m;
+    }
+    if (bad) atomicOr(err, 2u);
+}
+__global__ __launch_bounds__(TPB) void k_cv_cnt(const u32* masks, u64 nnz, u32 n_haps, u32 nb, u32* blk) {
+    __shared__ u32 cnt[32];
+    if (threadIdx.x < 32) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const u64 i0 = (u64)blockIdx.x * CVB;
+#pragma unroll
+    for (int r = 0; r < CVB / TPB; ++r) {
+        const u64 i = i0 + (u64)r * TPB + threadIdx.x;
+        const u32 m = i < nnz ? masks[i] : 0u;
+        for (u32 h = 0; h < n_haps; ++h) {
+            const u64 bm = __ballot((m >> h) & 1u);
+            if ((threadIdx.x & 63u) == 0 && bm) atomicAdd(&cnt[h], (u32)__popcll(bm));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < n_haps) blk[(u64)threadIdx.x * nb + blockIdx.x] = cnt[threadIdx.x];
+}
+// scan[h * nb + b]: set bits of haplotype h before block b, counted on from the haplotypes before it -- the place of the block's
+// first such bit in the row-index array.  headval[h * n_loci + t]: where column t of haplotype h starts within h's own block.
+__global__ __launch_bounds__(TPB) void k_cv_emit(const u64* keys, const u32* masks, u64 nnz, u32 n_haps, u32 n_loci, u32 nb,
+                                                 const u32* scan, int* cscidx, u32* headval) {
+    __shared__ u32 run[32], wcnt[TPB / 64][32];
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    if (tid < 32) run[tid] = tid < n_haps ? scan[(u64)tid * nb + blockIdx.x] : 0u;
+    const u64 lt = (1ull << lane) - 1ull;
+    const u64 i0 = (u64)blockIdx.x * CVB;
+    for (int r = 0; r < CVB / TPB; ++r) {
+        const u64 i = i0 + (u64)r * TPB + tid;
+        const bool have = i < nnz;
+        const u64 key = have ? keys[i] : 0ull;
+        const u32 m = have ? masks[i] : 0u;
+        const u32 lc = (u32)(key >> 32);
+        const bool head = have && (i == 0 || (u32)(keys[i - 1] >> 32) != lc);
+        for (u32 h = 0; h < n_haps; ++h) {
+            const u64 bm = __ballot((m >> h) & 1u);
+            if (lane == 0) wcnt[w][h] = (u32)__popcll(bm);
+        }
+        __syncthreads();
+        for (u32 h = 0; h < n_haps; ++h) {
+            const u64 bm = __ballot((m >> h) & 1u);
+            u32 at = run[h] + (u32)__popcll(bm & lt);
+            for (u32 k = 0; k < w; ++k) at += wcnt[k][h];
+            if ((m >> h) & 1u) cscidx[at] = (int)(u32)key;
+            if (head) headval[(u64)h * n_loci + lc] = at - scan[(u64)h * nb];
+        }
+        __syncthreads();
+        if (tid < n_haps) { u32 c = 0; for (u32 k = 0; k < TPB / 64; ++k) c += wcnt[k][tid]; run[tid] += c; }
+        __syncthreads();
+    }
+}
+// column pointers: column t of haplotype h starts where the first non-empty column at or after t does
+__global__ void k_cv_ptr(const u64* keys, u64 nnz, u32 n_loci, u32 n_haps, u32 nb, const u32* scan, const u64* grand, const u32* headval, int* cscptr) {
+    const u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (t > n_loci) return;
+    const u64 at = lower_bound_u64(keys, nnz, t << 32);
+    const u32 t2 = at < nnz ? (u32)(keys[at] >> 32) : 0u;
+    for (u32 h = 0; h < n_haps; ++h) {
+        const u32 tot = (h + 1 < n_haps ? scan[(u64)(h + 1) * nb] : (u32)*grand) - scan[(u64)h * nb];
+        cscptr[(u64)h * (n_loci + 1) + t] = (int)(at < nnz ? headval[(u64)h * n_loci + t2] : tot);
+    }
+}
+
 __global__ void k_iota(int* out, u64 n) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i < n) out[i] = (int)i;
@@ -2876,13 +2968,14 @@ hipError_t radix_sort_pairs64(hipStream_t st, u64* k[2], u32* v[2], u64 n, const
     *where = 0;
     if (n < 2) return hipSuccess;
     if (n >= (1ull << 32)) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(sc.d_word, 0, 8, st);
-    if (e != hipSuccess) return e;
-    k_or_reduce<<<(unsigned)std::min<u64>(1024, (n + TPB - 1) / TPB), TPB, 0, st>>>(k[0], n, sc.d_word);
-    u64 ormask = 0;
-    if ((e = hipMemcpyAsync(&ormask, sc.d_word, 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
-    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
-    ormask &= bit_mask;
+    hipError_t e = hipSuccess;
+    u64 ormask = bit_mask;                          // (a caller that names the bits to sort on has no use for the reduction and its host wait)
+    if (bit_mask == ~0ull) {
+        if ((e = hipMemsetAsync(sc.d_word, 0, 8, st)) != hipSuccess) return e;
+        k_or_reduce<<<(unsigned)std::min<u64>(1024, (n + TPB - 1) / TPB), TPB, 0, st>>>(k[0], n, sc.d_word);
+        if ((e = hipMemcpyAsync(&ormask, sc.d_word, 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    }
     const u32 nb = (u32)rs_tiles(n);
     const u64 m = 256ull * nb, sb = rs_scan_blocks(n);
     int cur = 0;
@@ -4009,40 +4102,101 @@ int cv_scan(hipStream_t st, const u32* in, u64 n, u32* out, u64* total, Scratch&
 }
 }  // namespace
 
+// Scratch of the stateless conversions, kept per device between calls (grown on demand; ecb_release_scratch frees it): a
+// config-3-sized conversion needs ~0.4 GB in a dozen buffers, and a dozen hipMallocs cost more than its kernels do.
+namespace {
+struct CvScratch {
+    enum { KEYS0, KEYS1, VALS0, VALS1, HIST, OFFS, SUMS, SUMS2, BLK, SCAN, HEAD, WORDS, X0, X1, X2, X3, N };
+    void* p[N] = {}; u64 bytes[N] = {};
+    template <class T> T* get(int id, u64 count) {
+        const u64 need = std::max<u64>(count, 1) * sizeof(T);
+        if (bytes[id] < need) {
+            if (p[id]) hipFree(p[id]);
+            p[id] = nullptr; bytes[id] = 0;
+            if (hipMalloc(&p[id], need + need / 8) != hipSuccess) return nullptr;
+            bytes[id] = need + need / 8;
+        }
+        return reinterpret_cast<T*>(p[id]);
+    }
+    void release() { for (int i = 0; i < N; ++i) { if (p[i]) hipFree(p[i]); p[i] = nullptr; bytes[i] = 0; } }
+};
+constexpr int CV_MAX_DEV = 64;
+CvScratch g_cv[CV_MAX_DEV];
+std::mutex g_cv_lock;
+// exclusive scan on `st`, nothing waits: sums = n / SCAN_BLOCK + 1 words of scratch, the total (64 bits) lands in *d_grand
+void cv_scan_queue(hipStream_t st, const u32* in, u64 n, u32* out, u32* sums, u64* d_grand) {
+    const u64 nb = std::max<u64>(1, (n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    k_scan_sums<<<(unsigned)nb, TPB, 0, st>>>(in, n, sums);
+    k_scan_top<<<1, TPB, 0, st>>>(sums, nb, d_grand);
+    k_scan_apply<<<(unsigned)nb, TPB, 0, st>>>(in, n, sums, out);
+}
+}  // namespace
+
+extern "C" int ecb_release_scratch(int device) {
+    if (device < 0 || device >= CV_MAX_DEV) return ECB_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, ECB_ERR_NO_DEVICE, "no such device");
+    std::lock_guard<std::mutex> g(g_cv_lock);
+    g_cv[device].release();
+    return ECB_OK;
+}
+
 extern "C" int ecb_csr_to_hapcsc_device(int device, uint32_t n_ecs, uint32_t n_loci, uint32_t n_haps, const void* d_indptr,
                                         const void* d_indices, const void* d_data, void* d_cscptr, void* d_cscidx,
                                         uint64_t* total) {
     if (!d_indptr || !d_indices || !d_data || !total || !n_ecs || !n_loci || !n_haps || n_haps > 31) return fail(nullptr, ECB_ERR_ARG, "bad argument");
     if ((u64)n_haps * n_loci >= (1ull << 32)) return fail(nullptr, ECB_ERR_LIMIT, "haplotypes x loci does not fit 32 bits");
-    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, ECB_ERR_NO_DEVICE, "no such device");
+    if (device < 0 || device >= CV_MAX_DEV || hipSetDevice(device) != hipSuccess) return fail(nullptr, ECB_ERR_NO_DEVICE, "no such device");
     hipStream_t st = nullptr;
     int nnz_i = 0;
     if (hipMemcpy(&nnz_i, (const int*)d_indptr + n_ecs, 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "read nnz");
+    if (nnz_i < 0) return fail(nullptr, ECB_ERR_CONTRACT, "malformed CSR: negative row pointer");
     const u64 nnz = (u64)nnz_i;
-    Scratch sc;
-    u32 *cnt = sc.get<u32>(nnz), *pos = sc.get<u32>(nnz);
-    if (!cnt || !pos) return fail(nullptr, ECB_ERR_HIP, "out of device memory");
-    k_cv_popc<<<nblk(nnz, TPB), TPB, 0, st>>>((const int*)d_data, nnz, cnt);
-    u64 tot = 0;
-    if (cv_scan(st, cnt, nnz, pos, &tot, sc) != ECB_OK) return fail(nullptr, ECB_ERR_HIP, "scan");
-    if (tot >= (1ull << 32)) return fail(nullptr, ECB_ERR_LIMIT, "more than 2^32-1 set haplotype bits");
-    *total = tot;
-    if (!d_cscidx || !d_cscptr) return ECB_OK;
-    u64 *keys = sc.get<u64>(tot), *keys2 = sc.get<u64>(tot);
-    u32* vals = sc.get<u32>(tot);
-    SortScratch ss{sc.get<u32>(256 * rs_tiles(tot)), sc.get<u32>(256 * rs_tiles(tot)), sc.get<u32>(rs_scan_blocks(tot) + 8), sc.get<u64>(1)};
-    if (!keys || !vals || !keys2 || !ss.hist || !ss.offs || !ss.sums || !ss.d_word) return fail(nullptr, ECB_ERR_HIP, "out of device memory");
-    k_cv_expand<<<nblk(nnz, TPB), TPB, 0, st>>>((const int*)d_indptr, n_ecs, (const int*)d_indices, (const int*)d_data, nnz, pos,
-                                               n_loci, keys, vals);
-    {   // stable sort by (haplotype, locus): rows stay ascending within a column, as scipy's tocsc() leaves them
-        u64* kk[2] = {keys, keys2}; u32* vv[2] = {vals, (u32*)d_cscidx};
-        int where = 0;
-        if (radix_sort_pairs64(st, kk, vv, tot, ss, &where) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "sort");
-        if (where == 0 && hipMemcpyAsync(d_cscidx, vals, tot * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "copy");
-        keys2 = kk[where];
+    std::lock_guard<std::mutex> guard(g_cv_lock);
+    CvScratch& S = g_cv[device];
+    u64* words = S.get<u64>(CvScratch::WORDS, 4);                  // [0] set bits, [1] the scan's total, [2] error bits
+    if (!words) return fail(nullptr, ECB_ERR_HIP, "out of device memory");
+    if (!d_cscidx || !d_cscptr) {                                  // the first call: how many row indices there will be
+        u64 tot = 0;
+        if (hipMemsetAsync(words, 0, 8, st) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "memset");
+        if (nnz) k_cv_bits<<<(unsigned)std::min<u64>(2048, nblk(nnz, TPB)), TPB, 0, st>>>((const int*)d_data, nnz, words);
+        if (hipMemcpy(&tot, words, 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "count");
+        if (tot >= (1ull << 32)) return fail(nullptr, ECB_ERR_LIMIT, "more than 2^32-1 set haplotype bits");
+        *total = tot;
+        return ECB_OK;
     }
     const u64 nc = (u64)n_haps * (n_loci + 1);
-    k_cv_cscptr<<<nblk(nc, TPB), TPB, 0, st>>>(keys2, tot, n_loci, n_haps, (int*)d_cscptr);
+    if (!nnz) {
+        if (hipMemset(d_cscptr, 0, nc * 4) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "memset");
+        *total = 0;
+        return ECB_OK;
+    }
+    const u32 nb = (u32)nblk(nnz, CVB);
+    u64 *k0 = S.get<u64>(CvScratch::KEYS0, nnz), *k1 = S.get<u64>(CvScratch::KEYS1, nnz);
+    u32 *v0 = S.get<u32>(CvScratch::VALS0, nnz), *v1 = S.get<u32>(CvScratch::VALS1, nnz);
+    SortScratch ss{S.get<u32>(CvScratch::HIST, 256 * rs_tiles(nnz)), S.get<u32>(CvScratch::OFFS, 256 * rs_tiles(nnz)),
+                   S.get<u32>(CvScratch::SUMS, rs_scan_blocks(nnz) + 8), words + 3};
+    u32 *blk = S.get<u32>(CvScratch::BLK, (u64)n_haps * nb), *scan = S.get<u32>(CvScratch::SCAN, (u64)n_haps * nb);
+    u32 *sums2 = S.get<u32>(CvScratch::SUMS2, (u64)n_haps * nb / SCAN_BLOCK + 8), *headval = S.get<u32>(CvScratch::HEAD, (u64)n_haps * n_loci);
+    if (!k0 || !k1 || !v0 || !v1 || !ss.hist || !ss.offs || !ss.sums || !blk || !scan || !sums2 || !headval) return fail(nullptr, ECB_ERR_HIP, "out of device memory");
+    if (hipMemsetAsync(words, 0, 24, st) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "memset");
+    k_cv_keys<<<nblk(n_ecs, TPB), TPB, 0, st>>>((const int*)d_indptr, n_ecs, (const int*)d_indices, (const int*)d_data, nnz, n_loci, n_haps,
+                                               k0, v0, reinterpret_cast<u32*>(words + 2));
+    u32 lbits = 1;
+    while (lbits < 32 && ((u64)1 << lbits) < n_loci) ++lbits;
+    u64* kk[2] = {k0, k1}; u32* vv[2] = {v0, v1};
+    int where = 0;
+    // stable sort on the locus alone: ECs stay ascending within a column, as scipy's tocsc() leaves them
+    if (radix_sort_pairs64(st, kk, vv, nnz, ss, &where, ((1ull << lbits) - 1ull) << 32) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "sort");
+    const u64* keys = kk[where]; const u32* masks = vv[where];
+    k_cv_cnt<<<nb, TPB, 0, st>>>(masks, nnz, n_haps, nb, blk);
+    cv_scan_queue(st, blk, (u64)n_haps * nb, scan, sums2, words + 1);
+    u64 back[3] = {0, 0, 0};
+    if (hipMemcpy(back, words, 24, hipMemcpyDeviceToHost) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "csr -> csc (count)");
+    if (back[2]) return fail(nullptr, ECB_ERR_CONTRACT, "malformed CSR: row pointers out of order, a locus beyond n_loci, or a mask that is zero or beyond n_haplotypes");
+    if (back[1] >= (1ull << 32)) return fail(nullptr, ECB_ERR_LIMIT, "more than 2^32-1 set haplotype bits");
+    *total = back[1];
+    k_cv_emit<<<nb, TPB, 0, st>>>(keys, masks, nnz, n_haps, n_loci, nb, scan, (int*)d_cscidx, headval);
+    k_cv_ptr<<<nblk((u64)n_loci + 1, TPB), TPB, 0, st>>>(keys, nnz, n_loci, n_haps, nb, scan, words + 1, headval, (int*)d_cscptr);
     if (hipStreamSynchronize(st) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "csr -> csc");
     return ECB_OK;
 }

@@ -242,6 +242,8 @@ int ecb_add_counters(ecb_handle* h, uint64_t all_alignments, uint64_t valid_alig
 int ecb_csr_to_hapcsc_device(int device, uint32_t n_ecs, uint32_t n_loci, uint32_t n_haps, const void* d_indptr_a,
                              const void* d_indices_a, const void* d_data_a, void* d_csc_indptr, void* d_csc_indices,
                              uint64_t* total);
+/* The conversions keep their device scratch between calls (per device); this gives it back. */
+int ecb_release_scratch(int device);
 int ecb_hapcsc_to_csr_device(int device, uint32_t n_ecs, uint32_t n_loci, uint32_t n_haps, const void* d_csc_indptr,
                              const void* d_csc_indices, uint64_t total, void* d_indptr_a, void* d_indices_a,
                              void* d_data_a, uint64_t* nnz);
