@@ -2039,10 +2039,19 @@ __global__ __launch_bounds__(TPB) void k_emit_big(const Slot* table, const u32* 
 }
 __global__ void k_set_last(u32* dst, const u64* v) { *dst = (u32)*v; }
 
-// multisample: key = EC rank << 32 | meta (cell, file) of every read
+// multisample: sort key = EC rank << 32 | (cell, file) of every read, the cell ABOVE the file: the triples come out in the order
+// (EC, cell, file), in which the files of one (EC, cell) pair -- one entry of N -- follow each other
+constexpr u32 MS_FILE_BITS = 32 - ECB_CELL_BITS;
+__host__ __device__ __forceinline__ u32 ms_swz(u32 meta) { return ((meta & ((1u << ECB_CELL_BITS) - 1u)) << MS_FILE_BITS) | (meta >> ECB_CELL_BITS); }
+__host__ __device__ __forceinline__ u32 ms_unswz(u32 s) { return (s >> MS_FILE_BITS) | (s << ECB_CELL_BITS); }
+__host__ __device__ __forceinline__ u64 ms_swz_key(u64 key) { return (key & 0xFFFFFFFF00000000ull) | ms_swz((u32)key); }
 __global__ void k_ms_keys(const u32* read_slot, const u32* rank_of_slot, const u32* meta, u64 n, u64* keys, u32* vals) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (i < n) { keys[i] = ((u64)rank_of_slot[read_slot[i]] << 32) | meta[i]; vals[i] = (u32)i; }
+    if (i < n) { keys[i] = ((u64)rank_of_slot[read_slot[i]] << 32) | ms_swz(meta[i]); vals[i] = (u32)i; }
+}
+__global__ void k_ms_swz_keys(u64* keys, u64 n) {           // EC << 32 | meta  ->  the sort key above, in place
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = ms_swz_key(keys[i]);
 }
 __global__ void k_ms_heads(const u64* keys, u64 n, u32* flag) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
@@ -2051,7 +2060,7 @@ __global__ void k_ms_heads(const u64* keys, u64 n, u32* flag) {
 __global__ void k_ms_emit(const u64* keys, const u32* vals, const u32* flag, const u32* pos, u64 n, u32 n_out,
                           u64* okey, u32* ofirst, u32* ostart) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (i < n && flag[i]) { okey[pos[i]] = keys[i]; ofirst[pos[i]] = vals[i]; ostart[pos[i]] = (u32)i; }
+    if (i < n && flag[i]) { okey[pos[i]] = (keys[i] & 0xFFFFFFFF00000000ull) | ms_unswz((u32)keys[i]); ofirst[pos[i]] = vals[i]; ostart[pos[i]] = (u32)i; }
     if (i == 0) ostart[n_out] = (u32)n;
 }
 __global__ void k_ms_split(const u64* okey, const u32* ostart, const u32* ocount, u64 n, u32* ec, u32* meta, u32* count) {
@@ -2096,7 +2105,7 @@ __global__ void k_ms_combine(const u64* keys, const u32* idx, const u32* flag, c
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const u32 o = pos[i] - (flag[i] ? 0u : 1u);                  // pos = exclusive scan of the head flags
-    if (flag[i]) okey[o] = keys[i];
+    if (flag[i]) okey[o] = (keys[i] & 0xFFFFFFFF00000000ull) | ms_unswz((u32)keys[i]);
     atomicAdd(&ocount[o], cnt_in[idx[i]]);
     atomicMin(&ofirst[o], first_in[idx[i]]);
 }
@@ -2392,58 +2401,113 @@ __global__ __launch_bounds__(TPB) void k_or_reduce(const u64* keys, u64 n, u64* 
 // order of the reference's cr_totals (files in order; within a file ECs by first appearance there; within an EC cells by
 // first appearance), per-cell totals, minimum-count filter, EC re-rank, CSC N, rows of A that survive.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_msf_keys_fe(const u32* ec, const u32* meta, u64 n, u64* key, u32* val) {          // (file, EC) of every triple
-    const u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (t < n) { key[t] = ((u64)(meta[t] >> ECB_CELL_BITS) << 32) | ec[t]; val[t] = (u32)t; }
-}
-__global__ void k_msf_runfix(const u32* flag, u32* runid, u64 n) {       // exclusive scan of head flags -> index of the run an element is in
-    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (i < n && !flag[i]) runid[i] -= 1u;
-}
-__global__ void k_msf_runmin(const u32* val, const u32* runid, const u32* first, u64 n, u32* runmin) {
-    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (i < n) atomicMin(&runmin[runid[i]], first[val[i]]);
-}
-__global__ void k_msf_spread(const u32* val, const u32* runid, const u32* runmin, u64 n, u32* fec) {
-    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (i < n) fec[val[i]] = runmin[runid[i]];
-}
-__global__ void k_msf_keys_cell(const u32* meta, u64 n, u64* key, u32* val) {
-    const u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (t < n) { key[t] = meta[t] & ((1u << ECB_CELL_BITS) - 1u); val[t] = (u32)t; }
-}
-__global__ void k_msf_runstart(const u32* flag, const u32* runid, u64 n, u32* start, u32 n_runs) {
-    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (i < n && flag[i]) start[runid[i]] = (u32)i;
-    if (i == 0) start[n_runs] = (u32)n;
-}
-// one workgroup per cell: reads in it, and the earliest (file, first appearance of the EC in that file, first read) among its triples
-__global__ __launch_bounds__(TPB) void k_msf_cell(const u64* skey, const u32* sval, const u32* start, const u32* meta, const u32* cnt,
-                                                  const u32* fec, const u32* first, u32* cell_id, u64* total, u64* best_hi, u64* best_lo) {
-    const u32 c = blockIdx.x, a = start[c], b = start[c + 1];
-    u64 sum = 0, bh = ~0ull, bl = ~0ull;
-    for (u32 i = a + threadIdx.x; i < b; i += TPB) {
-        const u32 t = sval[i];
-        sum += cnt[t];
-        const u64 hi = meta[t] >> ECB_CELL_BITS, lo = ((u64)fec[t] << 32) | first[t];
-        if (hi < bh || (hi == bh && lo < bl)) { bh = hi; bl = lo; }
+// Per cell: its reads, and the first file it has reads in (the reference walks the files in order: that file decides where the
+// cell enters cr_totals).  Counters and minima are kept in LDS per workgroup and flushed once (n_cells <= MSF_LDS_CELLS); more
+// cells than that go to memory directly.
+constexpr u32 MSF_LDS_CELLS = 8192;
+constexpr int TPB_MSF = 1024;
+__global__ __launch_bounds__(TPB_MSF) void k_msf2_cells(const u32* meta, const u32* cnt, u64 n, u32 n_cells, u64* total, u32* firstfile, u32* err) {
+    extern __shared__ u32 sh32[];                            // lfile[n_cells] | lcnt[n_cells]
+    const bool lds = n_cells <= MSF_LDS_CELLS;
+    u32 *lfile = sh32, *lcnt = sh32 + (lds ? n_cells : 0);
+    if (lds) {
+        for (u32 c = threadIdx.x; c < n_cells; c += TPB_MSF) { lfile[c] = 0xFFFFFFFFu; lcnt[c] = 0; }
+        __syncthreads();
     }
-    __shared__ u64 s_sum[TPB / 64], s_h[TPB / 64], s_l[TPB / 64];
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        sum += __shfl_xor(sum, d);
-        const u64 oh = __shfl_xor(bh, d), ol = __shfl_xor(bl, d);
-        if (oh < bh || (oh == bh && ol < bl)) { bh = oh; bl = ol; }
+    const u64 per = (n + gridDim.x - 1) / gridDim.x, t0 = blockIdx.x * per, t1 = min(t0 + per, n);
+    for (u64 t = t0 + threadIdx.x; t < t1; t += TPB_MSF) {
+        const u32 m = meta[t], c = m & ((1u << ECB_CELL_BITS) - 1u), f = m >> ECB_CELL_BITS;
+        if (c >= n_cells) { atomicOr(err, 2u); continue; }   // (cells are the ids the host handed out, 0 .. n_cells - 1)
+        if (lds) { atomicAdd(&lcnt[c], cnt[t]); atomicMin(&lfile[c], f); }
+        else { atomicAdd(&total[c], (u64)cnt[t]); atomicMin(&firstfile[c], f); }
     }
-    if ((threadIdx.x & 63u) == 0) { s_sum[threadIdx.x >> 6] = sum; s_h[threadIdx.x >> 6] = bh; s_l[threadIdx.x >> 6] = bl; }
+    if (!lds) return;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < TPB / 64; ++w) {
-            sum += s_sum[w];
-            if (s_h[w] < bh || (s_h[w] == bh && s_l[w] < bl)) { bh = s_h[w]; bl = s_l[w]; }
+    for (u32 c = threadIdx.x; c < n_cells; c += TPB_MSF)
+        if (lfile[c] != 0xFFFFFFFFu) { atomicAdd(&total[c], (u64)lcnt[c]); atomicMin(&firstfile[c], lfile[c]); }
+}
+// seg[e] = first triple of EC e (the triples are sorted by EC; an EC without triples gets an empty stretch), seg[n_ecs] = n
+__global__ void k_msf2_seg(const u32* ec, u64 n, u32 n_ecs, u32* seg, u32* err) {
+    const u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u32 e = ec[t];
+    if (e >= n_ecs) { atomicOr(err, 1u); return; }
+    const long long ep = t ? (long long)ec[t - 1] : -1ll;
+    for (long long x = ep + 1; x <= (long long)e; ++x) seg[x] = (u32)t;
+    if (t == n - 1) for (u64 x = (u64)e + 1; x <= n_ecs; ++x) seg[x] = (u32)n;
+}
+// One wave per EC: (i) the EC's first appearance in every file it has reads in -- the smallest first read among its triples of
+// that file (a table of one word per file in LDS); (ii) every triple whose file is its cell's first file offers the cell
+// (first appearance of the EC in that file, first read of the triple) -- the smallest offer is where the cell enters the
+// reference's cr_totals (bam_utils_multisample.py:513-546); (iii) whether any of the EC's cells survives the minimum count.
+constexpr u32 MSF_FILES = 1u << MS_FILE_BITS;
+__global__ __launch_bounds__(TPB) void k_msf2_ecs(const u32* meta, const u32* first, const u32* seg, u32 n_ecs, const u64* total,
+                                                  const u32* firstfile, u64 min_count, u64* cellkey, u32* keep_ec) {
+    __shared__ u32 fecw[TPB / 64][MSF_FILES];
+    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    u32* fec = fecw[w];
+    for (u32 f = lane; f < MSF_FILES; f += 64) fec[f] = 0xFFFFFFFFu;
+    wave_sync();
+    const u64 nw = (u64)gridDim.x * (TPB / 64);
+    for (u64 e = (u64)blockIdx.x * (TPB / 64) + w; e < n_ecs; e += nw) {
+        const u32 a = seg[e], b = seg[e + 1];
+        bool keep = false;
+        for (u32 t = a + lane; t < b; t += 64) {
+            const u32 m = meta[t];
+            atomicMin(&fec[m >> ECB_CELL_BITS], first[t]);
+            keep |= total[m & ((1u << ECB_CELL_BITS) - 1u)] >= min_count;
         }
-        cell_id[c] = (u32)skey[a]; total[c] = sum; best_hi[c] = bh; best_lo[c] = bl;
+        wave_sync();
+        for (u32 t = a + lane; t < b; t += 64) {
+            const u32 m = meta[t], c = m & ((1u << ECB_CELL_BITS) - 1u), f = m >> ECB_CELL_BITS;
+            if (firstfile[c] == f) {
+                const u64 offer = ((u64)fec[f] << 32) | first[t];
+                if (offer < cellkey[c]) atomicMin(&cellkey[c], offer);       // (the plain read may be stale: then one atomic too many)
+            }
+        }
+        wave_sync();
+        for (u32 t = a + lane; t < b; t += 64) fec[meta[t] >> ECB_CELL_BITS] = 0xFFFFFFFFu;
+        wave_sync();
+        if (__ballot(keep) && lane == 0) keep_ec[e] = 1u;
     }
+}
+// cells that have reads, as the lists the ordering below works on
+__global__ void k_msf2_cellflag(const u64* total, u32 n_cells, u32* flag) {
+    const u64 c = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (c < n_cells) flag[c] = total[c] ? 1u : 0u;
+}
+__global__ void k_msf2_celllist(const u64* total, const u32* firstfile, const u64* cellkey, const u32* flag, const u32* pos, u32 n_cells,
+                                u32* cell_id, u64* ctotal, u64* bhi, u64* blo) {
+    const u64 c = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (c >= n_cells || !flag[c]) return;
+    const u32 o = pos[c];
+    cell_id[o] = (u32)c; ctotal[o] = total[c]; bhi[o] = firstfile[c]; blo[o] = cellkey[c];
+}
+// (EC, cell) pairs that survive: a pair = the triples of one EC and one cell, which follow each other (one per file)
+__global__ void k_msf2_pairflag(const u32* ec, const u32* meta, u64 n, const u32* new_cell, u32* flag) {
+    const u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u32 c = meta[t] & ((1u << ECB_CELL_BITS) - 1u);
+    const bool head = t == 0 || ec[t - 1] != ec[t] || (meta[t - 1] & ((1u << ECB_CELL_BITS) - 1u)) != c;
+    flag[t] = (head && new_cell[c] != 0xFFFFFFFFu) ? 1u : 0u;
+}
+__global__ void k_msf2_pairs(const u32* ec, const u32* meta, const u32* cnt, const u32* flag, const u32* pos, u64 n, const u32* new_cell,
+                             const u32* new_rank, u64* key, u32* val) {
+    const u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (t >= n || !flag[t]) return;
+    const u32 e = ec[t], c = meta[t] & ((1u << ECB_CELL_BITS) - 1u);
+    u32 sum = 0;
+    for (u64 x = t; x < n && ec[x] == e && (meta[x] & ((1u << ECB_CELL_BITS) - 1u)) == c; ++x) sum += cnt[x];   // (the same cell's reads of one EC in several files add up, :737-791)
+    key[pos[t]] = ((u64)new_cell[c] << 32) | new_rank[e];
+    val[pos[t]] = sum;
+}
+__global__ void k_msf2_nout(const u64* key, const u32* val, u64 n, int* indices, int* data) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n) { indices[i] = (int)(u32)key[i]; data[i] = (int)val[i]; }
+}
+__global__ void k_msf2_nptr(const u64* key, u64 n, u32 n_cells, int* indptr) {
+    const u64 c = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (c <= n_cells) indptr[c] = (int)lower_bound_u64(key, n, c << 32);
 }
 __global__ void k_msf_iota(u32* v, u64 n) { const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; if (i < n) v[i] = (u32)i; }
 __global__ void k_msf_gather64(const u64* src, const u32* idx, u64 n, u64* dst) { const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; if (i < n) dst[i] = src[idx[i]]; }
@@ -2454,34 +2518,6 @@ __global__ void k_msf_keepflag(const u32* order, const u64* total, u64 n, u64 mi
 __global__ void k_msf_newcell(const u32* order, const u32* flag, const u32* pos, const u32* cell_id, u64 n, u32* new_cell, u32* kept_cells) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i < n && flag[i]) { const u32 c = cell_id[order[i]]; new_cell[c] = pos[i]; kept_cells[pos[i]] = c; }
-}
-__global__ void k_msf_mark(const u32* ec, const u32* meta, const u32* new_cell, u64 n, u32* keep_ec, u32* kt) {
-    const u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const bool k = new_cell[meta[t] & ((1u << ECB_CELL_BITS) - 1u)] != 0xFFFFFFFFu;
-    kt[t] = k ? 1u : 0u;
-    if (k) keep_ec[ec[t]] = 1u;
-}
-__global__ void k_msf_nkeys(const u32* ec, const u32* meta, const u32* cnt, const u32* kt, const u32* kpos, const u32* new_cell,
-                            const u32* new_rank, u64 n, u64* key, u32* val) {
-    const u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (t < n && kt[t]) {
-        key[kpos[t]] = ((u64)new_cell[meta[t] & ((1u << ECB_CELL_BITS) - 1u)] << 32) | new_rank[ec[t]];
-        val[kpos[t]] = cnt[t];
-    }
-}
-__global__ void k_msf_nemit(const u64* key, const u32* val, const u32* flag, const u32* pos, u64 n, int* indices, int* data) {
-    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const u32 o = pos[i] - (flag[i] ? 0u : 1u);                      // pos = exclusive scan of the head flags
-    if (flag[i]) indices[o] = (int)(u32)key[i];
-    atomicAdd(&data[o], (int)val[i]);
-}
-__global__ void k_msf_nptr(const u64* key, const u32* pos, u64 n, u32 nnz, u32 n_cells, int* indptr) {
-    const u64 c = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (c > n_cells) return;
-    const u64 at = lower_bound_u64(key, n, (u64)c << 32);
-    indptr[c] = at < n ? (int)pos[at] : (int)nnz;                    // pos[] = index of the run that starts at or after `at`
 }
 __global__ void k_msf_rowlen(const u32* indptr, const u32* keep_ec, const u32* new_rank, u64 n_ecs, u32* rowlen2) {
     const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
@@ -3909,6 +3945,7 @@ int ecb_ms_adopt_triples_device(ecb_handle* h, uint32_t n_tables, const void* co
     }
     u64 nt = 0;
     if (tot) {
+        k_ms_swz_keys<<<nblk(tot, TPB), TPB, 0, h->stream>>>(keys, tot);      // (sorted as (EC, cell, file), like a handle's own triples)
         k_iota<<<nblk(tot, TPB), TPB, 0, h->stream>>>((int*)vals, tot);
         {
             u64* kk[2] = {keys, keys2}; u32* vv[2] = {vals, vals2};
@@ -3945,42 +3982,53 @@ int ecb_ms_filter(ecb_handle* h, uint32_t n_cells, int64_t minimum_count, ecb_ms
     const u64 T = h->n_triples, E = h->sizes.n_ecs;
     const u64 min_count = minimum_count <= 0 ? 1ull : (u64)minimum_count;          // bam_utils_multisample.py:596-597
     if (!T) return fail(h, ECB_ERR_EMPTY, "no (EC, cell) counts: nothing to filter");
-    Scratch sc;
-    u32 *ec = sc.get<u32>(T), *meta = sc.get<u32>(T), *cnt = sc.get<u32>(T), *fec = sc.get<u32>(T);
-    u64 *k0 = sc.get<u64>(T), *k1 = sc.get<u64>(T);
-    u32 *v0 = sc.get<u32>(T), *v1 = sc.get<u32>(T), *flag = sc.get<u32>(T), *runid = sc.get<u32>(T), *runmin = sc.get<u32>(T + 1);
-    if (!ec || !meta || !cnt || !fec || !k0 || !k1 || !v0 || !v1 || !flag || !runid || !runmin) return fail(h, ECB_ERR_HIP, "out of device memory");
+    // The triples are sorted by (EC, cell, file) (ms_reduce / ecb_ms_adopt_triples_device).  Everything read-sized below is a
+    // linear pass over them; the only sort left is the one that turns the surviving (EC, cell) pairs -- in EC order -- into
+    // the columns of N, on the digits of the cell alone.  The triple-sized buffers are the ones ms_reduce sorted in (its pool).
+    u32 *x = nullptr, *flag = nullptr, *pos = nullptr, *v0 = nullptr, *v1 = nullptr;
+    u64 *k0 = nullptr, *k1 = nullptr;
+    POOL(h, P_MS_TMP, x, 3 * T);
+    POOL(h, P_MS_FLAG, flag, std::max<u64>(T, n_cells)); POOL(h, P_MS_POS, pos, std::max<u64>(T, n_cells));
+    POOL(h, P_MS_KEYS, k0, T); POOL(h, P_MS_KEYS2, k1, T); POOL(h, P_MS_VALS, v0, T); POOL(h, P_MS_VALS2, v1, T);
+    u32 *ec = x, *meta = x + T, *cnt = x + 2 * T;
     k_ms_split<<<nblk(T, TPB), TPB, 0, st>>>(h->ms_okey, h->ms_ostart, h->ms_ocount, T, ec, meta, cnt);
     const u32* first = h->ms_ofirst;
+    Scratch sc;                                              // (cell- and EC-sized scratch: small)
+    u64 *total = sc.get<u64>(n_cells), *cellkey = sc.get<u64>(n_cells);
+    u32 *firstfile = sc.get<u32>(n_cells), *seg = sc.get<u32>(E + 1), *keep_ec = sc.get<u32>(E), *new_rank = sc.get<u32>(E), *new_cell = sc.get<u32>(n_cells);
+    u32* d_err = sc.get<u32>(1);
+    if (!total || !cellkey || !firstfile || !seg || !keep_ec || !new_rank || !new_cell || !d_err) return fail(h, ECB_ERR_HIP, "out of device memory");
+    HIPCHK(h, hipMemsetAsync(total, 0, (u64)n_cells * 8, st));
+    HIPCHK(h, hipMemsetAsync(cellkey, 0xFF, (u64)n_cells * 8, st));
+    HIPCHK(h, hipMemsetAsync(firstfile, 0xFF, (u64)n_cells * 4, st));
+    HIPCHK(h, hipMemsetAsync(keep_ec, 0, E * 4, st));
+    HIPCHK(h, hipMemsetAsync(d_err, 0, 4, st));
+    // 1. per cell: reads and first file
+    {
+        const bool lds = n_cells <= MSF_LDS_CELLS;
+        const unsigned grid = (unsigned)std::min<u64>(lds ? 512 : 2048, nblk(T, TPB_MSF));
+        k_msf2_cells<<<grid, TPB_MSF, lds ? (size_t)n_cells * 8 : 0, st>>>(meta, cnt, T, n_cells, total, firstfile, d_err);
+    }
+    // 2. per EC: its first appearance in every file; where every cell enters the cell order; whether the EC keeps a cell
+    k_msf2_seg<<<nblk(T, TPB), TPB, 0, st>>>(ec, T, (u32)E, seg, d_err);
+    k_msf2_ecs<<<(unsigned)std::min<u64>(nblk(E * 64, TPB), 256 * 8), TPB, 0, st>>>(meta, first, seg, (u32)E, total, firstfile, min_count, cellkey, keep_ec);
+    // 3. cell order: by (first appearance of the EC in the cell's first file, first read), then -- stable -- by that file
     int rc, where = 0;
-    u64 tot = 0;
-    // 1. first appearance of every EC in every file: group the triples by (file, EC), minimum of their first reads
-    k_msf_keys_fe<<<nblk(T, TPB), TPB, 0, st>>>(ec, meta, T, k0, v0);
-    { u64* kk[2] = {k0, k1}; u32* vv[2] = {v0, v1}; rc = handle_sort(h, kk, vv, T, &where); if (rc != ECB_OK) return rc;
-      k_ms_heads<<<nblk(T, TPB), TPB, 0, st>>>(kk[where], T, flag);
-      rc = excl_scan(h, flag, T, runid, &tot); if (rc != ECB_OK) return rc;
-      // runid[i] = heads before i; the run of i is that, minus one unless i is a head itself -- fold it in place
-      k_msf_runfix<<<nblk(T, TPB), TPB, 0, st>>>(flag, runid, T);
-      HIPCHK(h, hipMemsetAsync(runmin, 0xFF, (tot + 1) * 4, st));
-      k_msf_runmin<<<nblk(T, TPB), TPB, 0, st>>>(vv[where], runid, first, T, runmin);
-      k_msf_spread<<<nblk(T, TPB), TPB, 0, st>>>(vv[where], runid, runmin, T, fec); }
-    // 2. per cell: reads, and the earliest (file, EC's first appearance in the file, first read) -- its place in the cell order
-    k_msf_keys_cell<<<nblk(T, TPB), TPB, 0, st>>>(meta, T, k0, v0);
-    u64 n_runs = 0;
-    u64* skey = nullptr; u32* sval = nullptr;
-    { u64* kk[2] = {k0, k1}; u32* vv[2] = {v0, v1}; rc = handle_sort(h, kk, vv, T, &where); if (rc != ECB_OK) return rc;
-      skey = kk[where]; sval = vv[where];
-      k_ms_heads<<<nblk(T, TPB), TPB, 0, st>>>(skey, T, flag);
-      rc = excl_scan(h, flag, T, runid, &n_runs); if (rc != ECB_OK) return rc;
-      k_msf_runfix<<<nblk(T, TPB), TPB, 0, st>>>(flag, runid, T); }
-    const u64 C = n_runs;                                    // cells that have reads
-    u32 *cstart = sc.get<u32>(C + 1), *cell_id = sc.get<u32>(C), *corder = sc.get<u32>(C), *corder2 = sc.get<u32>(C), *cflag = sc.get<u32>(C), *cpos = sc.get<u32>(C);
+    k_msf2_cellflag<<<nblk(n_cells, TPB), TPB, 0, st>>>(total, n_cells, flag);
+    u64 C = 0;
+    rc = excl_scan(h, flag, n_cells, pos, &C); if (rc != ECB_OK) return rc;
+    {
+        u32 err = 0;
+        HIPCHK(h, hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        if (err & 1u) return fail(h, ECB_ERR_CONTRACT, "triple with an EC id beyond the finalized ECs");
+        if (err & 2u) return fail(h, ECB_ERR_CONTRACT, "a read's cell id is not below n_cells");
+    }
+    if (!C) return fail(h, ECB_ERR_EMPTY, "no (EC, cell) counts: nothing to filter");
+    u32 *cell_id = sc.get<u32>(C), *corder = sc.get<u32>(C), *corder2 = sc.get<u32>(C), *cflag = sc.get<u32>(C), *cpos = sc.get<u32>(C);
     u64 *ctotal = sc.get<u64>(C), *bhi = sc.get<u64>(C), *blo = sc.get<u64>(C), *ck0 = sc.get<u64>(C), *ck1 = sc.get<u64>(C);
-    u32* new_cell = sc.get<u32>(n_cells);
-    if (!cstart || !cell_id || !corder || !corder2 || !cflag || !cpos || !ctotal || !bhi || !blo || !ck0 || !ck1 || !new_cell) return fail(h, ECB_ERR_HIP, "out of device memory");
-    k_msf_runstart<<<nblk(T, TPB), TPB, 0, st>>>(flag, runid, T, cstart, (u32)C);
-    k_msf_cell<<<(unsigned)C, TPB, 0, st>>>(skey, sval, cstart, meta, cnt, fec, first, cell_id, ctotal, bhi, blo);
-    // 3. cell order: by (first appearance of the EC in the file, first read), then -- stable -- by file
+    if (!cell_id || !corder || !corder2 || !cflag || !cpos || !ctotal || !bhi || !blo || !ck0 || !ck1) return fail(h, ECB_ERR_HIP, "out of device memory");
+    k_msf2_celllist<<<nblk(n_cells, TPB), TPB, 0, st>>>(total, firstfile, cellkey, flag, pos, n_cells, cell_id, ctotal, bhi, blo);
     k_msf_iota<<<nblk(C, TPB), TPB, 0, st>>>(corder, C);
     HIPCHK(h, hipMemcpyAsync(ck0, blo, C * 8, hipMemcpyDeviceToDevice, st));
     u32* ord = nullptr;
@@ -3997,26 +4045,30 @@ int ecb_ms_filter(ecb_handle* h, uint32_t n_cells, int64_t minimum_count, ecb_ms
     HIPCHK(h, hipMemsetAsync(new_cell, 0xFF, (u64)n_cells * 4, st));
     k_msf_newcell<<<nblk(C, TPB), TPB, 0, st>>>(ord, cflag, cpos, cell_id, C, new_cell, h->f_cells);
     // 4. ECs that keep a cell, re-ranked (bam_utils_multisample.py:611-636)
-    u32 *keep_ec = sc.get<u32>(E), *new_rank = sc.get<u32>(E), *kt = flag, *kpos = runid;
-    if (!keep_ec || !new_rank) return fail(h, ECB_ERR_HIP, "out of device memory");
-    HIPCHK(h, hipMemsetAsync(keep_ec, 0, E * 4, st));
-    k_msf_mark<<<nblk(T, TPB), TPB, 0, st>>>(ec, meta, new_cell, T, keep_ec, kt);
     u64 E2 = 0, K = 0;
     rc = excl_scan(h, keep_ec, E, new_rank, &E2); if (rc != ECB_OK) return rc;
-    rc = excl_scan(h, kt, T, kpos, &K); if (rc != ECB_OK) return rc;
-    // 5. N as CSC over (kept EC, kept cell): the same cell's reads of one EC in several files add up (:737-791)
-    k_msf_nkeys<<<nblk(T, TPB), TPB, 0, st>>>(ec, meta, cnt, kt, kpos, new_cell, new_rank, T, k0, v0);
-    u64 nnz_n = 0;
-    { u64* kk[2] = {k0, k1}; u32* vv[2] = {v0, v1}; rc = handle_sort(h, kk, vv, K, &where); if (rc != ECB_OK) return rc;
-      u32* hflag = sc.get<u32>(K), *hpos = sc.get<u32>(K);
-      if (!hflag || !hpos) return fail(h, ECB_ERR_HIP, "out of device memory");
-      k_ms_heads<<<nblk(K, TPB), TPB, 0, st>>>(kk[where], K, hflag);
-      rc = excl_scan(h, hflag, K, hpos, &nnz_n); if (rc != ECB_OK) return rc;
-      if (nnz_n >= (1ull << 31)) return fail(h, ECB_ERR_LIMIT, "N has more than 2^31-1 non-zeros");
-      POOL(h, P_F_IPN, h->f_ipn, S + 1); POOL(h, P_F_IXN, h->f_ixn, nnz_n); POOL(h, P_F_DAN, h->f_dan, nnz_n);
-      HIPCHK(h, hipMemsetAsync(h->f_dan, 0, nnz_n * 4, st));
-      k_msf_nemit<<<nblk(K, TPB), TPB, 0, st>>>(kk[where], vv[where], hflag, hpos, K, h->f_ixn, h->f_dan);
-      k_msf_nptr<<<nblk(S + 1, TPB), TPB, 0, st>>>(kk[where], hpos, K, (u32)nnz_n, (u32)S, h->f_ipn); }
+    // 5. N as CSC over (kept EC, kept cell): the surviving (EC, cell) pairs, the reads of their files added up (:737-791), come
+    //    in EC order; a stable sort on the cell's digits makes them the columns
+    k_msf2_pairflag<<<nblk(T, TPB), TPB, 0, st>>>(ec, meta, T, new_cell, flag);
+    rc = excl_scan(h, flag, T, pos, &K); if (rc != ECB_OK) return rc;
+    if (K >= (1ull << 31)) return fail(h, ECB_ERR_LIMIT, "N has more than 2^31-1 non-zeros");
+    k_msf2_pairs<<<nblk(T, TPB), TPB, 0, st>>>(ec, meta, cnt, flag, pos, T, new_cell, new_rank, k0, v0);
+    const u64 nnz_n = K;
+    {
+        u32 sbits = 1;
+        while (sbits < 32 && (1ull << sbits) < S) ++sbits;
+        SortScratch ss{};
+        u64* tot = nullptr;
+        POOL(h, P_RS_HIST, ss.hist, 256 * rs_tiles(K)); POOL(h, P_RS_OFFS, ss.offs, 256 * rs_tiles(K));
+        POOL(h, P_RS_SUMS, ss.sums, rs_scan_blocks(K) + 8); POOL(h, P_TOTALS, tot, 8);
+        ss.d_word = tot + 6;
+        u64* kk[2] = {k0, k1}; u32* vv[2] = {v0, v1};
+        const hipError_t e = radix_sort_pairs64(st, kk, vv, K, ss, &where, ((1ull << sbits) - 1ull) << 32);
+        if (e != hipSuccess) return fail(h, ECB_ERR_HIP, "radix sort: %s", hipGetErrorString(e));
+        POOL(h, P_F_IPN, h->f_ipn, S + 1); POOL(h, P_F_IXN, h->f_ixn, nnz_n); POOL(h, P_F_DAN, h->f_dan, nnz_n);
+        k_msf2_nout<<<nblk(K, TPB), TPB, 0, st>>>(kk[where], vv[where], K, h->f_ixn, h->f_dan);
+        k_msf2_nptr<<<nblk(S + 1, TPB), TPB, 0, st>>>(kk[where], K, (u32)S, h->f_ipn);
+    }
     // 6. the rows of A of the ECs that are left
     u32* rowlen2 = sc.get<u32>(E2 + 1);
     if (!rowlen2) return fail(h, ECB_ERR_HIP, "out of device memory");

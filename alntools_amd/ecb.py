@@ -266,7 +266,7 @@ class EcBuilder(object):
         return out
 
     def export_pairs(self):
-        """Multisample: distinct (EC, cell, file) triples -> dict(ec, cell, file, count, first), sorted by (ec, meta)."""
+        """Multisample: distinct (EC, cell, file) triples -> dict(ec, cell, file, count, first), sorted by (ec, cell, file)."""
         s = self.sizes or self.finalize()
         n = s["nnz_n"]
         ec, meta, cnt, first = (np.empty(n, np.uint32) for _ in range(4))

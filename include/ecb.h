@@ -132,7 +132,7 @@ int ecb_export_ranges(ecb_handle* h, int64_t* range_len);
 /* The raw extremes behind ecb_export_ranges (min = INT32_MAX and max = INT32_MIN where nothing aligned). */
 int ecb_export_range_minmax(ecb_handle* h, int32_t* range_min, int32_t* range_max);
 /* Multisample, after ecb_finalize: the distinct (EC, cell, file) triples -- sizes.nnz_n of them, sorted by
- * (EC, meta) -- with the number of reads and the first read index of each: what the reference keeps as
+ * (EC, cell, file) -- with the number of reads and the first read index of each: what the reference keeps as
  * ec[key][cell] per worker (bam_utils_multisample.py:288-290, 503-576).  Cell order, the minimum-count filter
  * and the CSC N matrix (:596-636, 737-791) are metadata-sized work done by the host from these. */
 int ecb_export_pairs(ecb_handle* h, uint32_t* ec, uint32_t* meta, uint32_t* count, uint32_t* first_read);
@@ -218,7 +218,7 @@ int ecb_assemble_ranges_device(ecb_handle* h, uint32_t n_pieces, const void* con
  * were merged and the root finalized: ecb_export_ec_keys_device writes the 8-byte set hash of every EC in rank order
  * (n_ecs * 8 bytes; broadcast it together with the root's CSR A from ecb_export_device).  A shard finds its own ECs in
  * that list -- by hash, then by comparing its stored key with the CSR row -- and reduces its reads to distinct
- * (EC, cell, file) triples with GLOBAL EC ids -- ecb_ms_local_triples_device: key = EC << 32 | meta (sorted), count,
+ * (EC, cell, file) triples with GLOBAL EC ids -- ecb_ms_local_triples_device: key = EC << 32 | meta (in the order (EC, cell, file)), count,
  * first read (read_base added); buffers of n_reads elements, *n_triples written.  The root combines the shards' triples
  * (a cell whose reads straddle two shards: counts added, first = min) with ecb_ms_adopt_triples_device, after which
  * ecb_export_pairs works as on one GPU.  (bam_utils_multisample.py:503-576: the merge of the workers' ec[key][cell].) */

@@ -526,14 +526,15 @@ def test_full_size_config4_multisample_triples():
     for k, exp in (("indptrA", a_ptr), ("indicesA", a_idx), ("dataA", a_dat), ("indptrN", n_ptr), ("indicesN", n_idx), ("dataN", n_dat)):
         assert np.array_equal(f[k], exp), k
     del a, f, kept, ec_keep, n_ptr, n_idx, n_dat, a_ptr, a_idx, a_dat
-    key = (rec.to(torch.int64) << 32) | (meta.to(torch.int64) & 0xFFFFFFFF)
+    m64 = meta.to(torch.int64) & 0xFFFFFFFF
+    key = (rec.to(torch.int64) << 32) | ((m64 & 0x3FFFFF) << 10) | (m64 >> 22)    # the triples come sorted by (EC, cell, file)
     order = torch.argsort(key, stable=True)
     ks = key[order]
     heads = torch.nonzero(torch.cat([torch.ones(1, dtype=torch.bool, device=dev), ks[1:] != ks[:-1]])).flatten()
     exp_key = ks[heads].cpu().numpy()
     exp_cnt = torch.diff(torch.cat([heads, torch.tensor([len(ks)], device=dev)])).cpu().numpy()
     exp_first = order[heads].cpu().numpy()                                        # stable sort: a run starts with its smallest read
-    got_key = (pr["ec"] << 32) | (pr["cell"] | (pr["file"] << 22))
+    got_key = (pr["ec"] << 32) | (pr["cell"] << 10) | pr["file"]
     assert len(got_key) == len(exp_key) == s["nnz_n"]
     assert np.array_equal(got_key, exp_key) and np.array_equal(pr["count"], exp_cnt) and np.array_equal(pr["first"], exp_first)
 
@@ -704,13 +705,14 @@ def test_multisample_triples_at_scale():
     assert s["n_reads"] == n_reads and len(rec) == n_reads
     assert rec.min() == 0 and rec.max() == s["n_ecs"] - 1
     assert int(pr["count"].sum()) == n_reads
-    key = (rec.astype(np.int64) << 32) | meta.astype(np.int64)
+    m64 = meta.astype(np.int64)
+    key = (rec.astype(np.int64) << 32) | ((m64 & 0x3FFFFF) << 10) | (m64 >> 22)   # the triples come sorted by (EC, cell, file)
     order = np.argsort(key, kind="stable")
     ks = key[order]
     heads = np.flatnonzero(np.concatenate(([True], ks[1:] != ks[:-1])))
     exp_key, exp_cnt = ks[heads], np.diff(np.concatenate((heads, [len(ks)])))
     exp_first = order[heads]                                # stable sort: the first of a run is its smallest read index
-    got_key = (pr["ec"] << 32) | (pr["cell"] | (pr["file"] << 22))
+    got_key = (pr["ec"] << 32) | (pr["cell"] << 10) | pr["file"]
     assert len(got_key) == len(exp_key) == s["nnz_n"]
     assert np.array_equal(got_key, exp_key)
     assert np.array_equal(pr["count"], exp_cnt)
@@ -816,7 +818,8 @@ def test_multisample_over_shards_equals_one_handle():
     tables = []
     for eng, b0 in shards:
         key, cnt, first, n = eng.ms_local_triples(keys, s["n_ecs"], nnz, b0)
-        assert n > 0 and bool((key[1:n] > key[:n - 1]).all())
+        sk = (key[:n] & ~0xFFFFFFFF) | ((key[:n] & 0x3FFFFF) << 10) | ((key[:n] >> 22) & 0x3FF)    # sorted by (EC, cell, file)
+        assert n > 0 and bool((sk[1:] > sk[:-1]).all())
         tables.append((key, cnt, first, n))
     nt = root.ms_adopt_triples(tables)
     assert nt == s1["nnz_n"] and nt < sum(t[3] for t in tables)          # cells straddle the shards: triples were combined
