@@ -146,12 +146,47 @@ def _log_summary(maps, sizes):
     LOG.info("# Unique Reads: {:,}".format(sizes["n_reads"]))
 
 
+def _deal_out(reader, enc, world, builder, track, group_send):
+    """Rank 0 of a multi-GPU run: decode the file ONCE and deal its records out in contiguous read ranges -- the reference plans its
+    chunks once and gives every process its own (``bam_utils.py:1174-1304, 646-680``).  The owner of the records being decoded
+    moves on from rank r to r + 1 when the decoder is (r + 1) / world of the way through the file, at the next read boundary;
+    rank 0 pushes its own share as it goes.  ``group_send(dst, arrays or None)`` ships one batch (``None``: nothing more)."""
+    owner, base = 0, 0                                # the rank being fed, and the run counter of its first read
+    prog = getattr(reader, "progress", None)
+    for t in iter_tuple_batches(reader, enc):
+        rid = t["read_id"]
+        cols = [rid, t["locus"], t["hapflag"]] + ([t["pos"]] if track else [])
+        lo = 0
+        while True:
+            target = min(world - 1, int(world * prog())) if prog else 0
+            cut = len(rid)
+            if target > owner:                       # hand over at the first read that starts in what is left of this batch
+                first = int(rid[lo]) if rid[lo] != 0xFFFFFFFF else -1
+                heads = np.flatnonzero(rid[lo:].astype(np.int64) > first) if first >= 0 else np.flatnonzero(rid[lo:] != 0xFFFFFFFF)
+                cut = lo + int(heads[0]) if len(heads) else len(rid)
+            if cut > lo:
+                part = [c[lo:cut] for c in cols]
+                local = np.where(part[0] == 0xFFFFFFFF, np.uint32(0xFFFFFFFF), part[0] - np.uint32(base)).astype(np.uint32)
+                if owner == 0:
+                    builder.push(local, part[1], part[2], part[3] if track else None)
+                else:
+                    group_send(owner, [local] + part[1:])
+            if cut == len(rid):
+                break
+            owner += 1                               # (the read at `cut` is the new owner's read 0)
+            base = int(rid[cut])
+            lo = cut
+    for r in range(1, world):
+        group_send(r, None)
+
+
 def _rank_convert(rank, world, port, backend, devices, bam_filename, ec_filename, emase_filename, range_filename, sample,
                   target_filename, result_path):
-    """One process per GPU (the reference: one process per contiguous chunk range, ``bam_utils.py:646-680``): every rank
-    decodes the BAM, takes the contiguous read range ``[rank R / world, (rank + 1) R / world)``, builds its EC table on its
-    GPU; the tables are merged by key range over RCCL (``dist.exchange_and_merge``: the ordered merge of ``:680-724``), every
-    rank finalizes its range, rank 0 puts the ranges together and writes.  The decode is not shared: every rank reads the file (twice: reads are counted first)."""
+    """One process per GPU (the reference: one process per contiguous chunk range, ``bam_utils.py:646-680``).  Rank 0 decodes the
+    BAM once and deals the records out in contiguous read ranges (:func:`_deal_out`; the tuples travel over the process group --
+    xGMI under RCCL); every rank builds the EC table of its range on its GPU; the tables are merged by key range
+    (``dist.exchange_and_merge``: the ordered merge of ``:680-724``), every rank finalizes its range, rank 0 puts the ranges
+    together and writes."""
     import json
     import torch
     import torch.distributed as tdist
@@ -166,30 +201,37 @@ def _rank_convert(rank, world, port, backend, devices, bam_filename, ec_filename
         tdist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     else:
         tdist.init_process_group(backend, rank=rank, world_size=world)
+    wire = device if backend == "nccl" else torch.device("cpu")        # where a message lives while it travels
     targets = list(utils.parse_targets(target_filename).keys()) if target_filename else None
-    # pass 1: how many reads there are (name runs among valid records: only the host can tell)
+    track = range_filename is not None
+    n_cols = 4 if track else 3
+    # every rank reads the header (the maps); only rank 0 reads on
     reader = open_bam(bam_filename, names=False)
     maps = HeaderMaps(reader.references, reader.lengths, targets)
-    enc = TupleEncoder(maps)
-    for _ in iter_tuple_batches(reader, enc):
-        pass
-    reader.close()
-    R = 0 if enc.cur == 0xFFFFFFFF else enc.cur + 1
-    r0, r1 = rank * R // world, (rank + 1) * R // world
-    wrap = lambda e: e if backend == "nccl" else ecdist.HostStagedEngine(e)
-    track = range_filename is not None
     b = EcBuilder(maps.n_loci, maps.n_haplotypes, device=dev_index, track_ranges=track)
-    # pass 2: my reads.  A record belongs to the read whose id it carries (records before the first read: to rank 0).
-    reader = open_bam(bam_filename, names=False)
-    enc = TupleEncoder(maps)
-    for t in iter_tuple_batches(reader, enc):
-        rid = t["read_id"].astype(np.int64)
-        rid[rid == 0xFFFFFFFF] = -1
-        mine = (rid >= r0) & (rid < r1) if rank else (rid < r1)
-        if mine.any():
-            local = np.where(rid[mine] < 0, 0xFFFFFFFF, rid[mine] - r0).astype(np.uint32)
-            b.push(local, t["locus"][mine], t["hapflag"][mine], t["pos"][mine] if track else None)
-    reader.close()
+    if rank == 0:
+        def send(dst, arrays):
+            n = 0 if arrays is None else len(arrays[0])
+            tdist.send(torch.tensor([n, 0 if arrays is None else 1], dtype=torch.int64, device=wire), dst)
+            if n:
+                msg = torch.from_numpy(np.concatenate([np.ascontiguousarray(a).view(np.int32) for a in arrays])).to(wire)
+                tdist.send(msg, dst)
+        _deal_out(reader, TupleEncoder(maps), world, b, track, send)
+        reader.close()
+    else:
+        reader.close()
+        while True:
+            head = torch.empty(2, dtype=torch.int64, device=wire)
+            tdist.recv(head, 0)
+            n, more = (int(x) for x in head.cpu().tolist())
+            if not more:
+                break
+            msg = torch.empty(n * n_cols, dtype=torch.int32, device=wire)
+            tdist.recv(msg, 0)
+            a = msg.cpu().numpy()
+            cols = [a[i * n:(i + 1) * n] for i in range(n_cols)]
+            b.push(cols[0].view(np.uint32), cols[1].view(np.uint32), cols[2].view(np.uint32), cols[3] if track else None)
+    wrap = lambda e: e if backend == "nccl" else ecdist.HostStagedEngine(e)
     eng = wrap(ecdist.GpuEngine(b, device))
     fresh = lambda: wrap(ecdist.GpuEngine(EcBuilder(maps.n_loci, maps.n_haplotypes, device=dev_index, track_ranges=False), device))
     merged = ecdist.exchange_and_merge(eng, fresh, fresh, root=0, finalize_ranges=True)     # (every rank ranks and emits its own key range)

@@ -19,8 +19,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbamdec.so")
 SRC = os.path.join(_HERE, "csrc", "bamdec.c")
 SYMBOLS = ("bd_abi_version", "bd_open", "bd_close", "bd_last_error", "bd_n_references", "bd_reference_name",
-           "bd_reference_length", "bd_header_text", "bd_references", "bd_read", "bd_read_tuples", "bd_read_ms", "bd_ms_cells")
-ABI_VERSION = 2            # include/bamdec.h: bd_abi_version()
+           "bd_reference_length", "bd_header_text", "bd_references", "bd_read", "bd_read_tuples", "bd_read_ms", "bd_ms_cells", "bd_progress")
+ABI_VERSION = 3            # include/bamdec.h: bd_abi_version()
 _lib = None
 
 
@@ -64,6 +64,7 @@ def lib():
             [C.c_void_p] * 4 + [C.POINTER(C.c_size_t)] * 2
         l.bd_read_ms.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 7 + [C.POINTER(C.c_size_t)]
         l.bd_ms_cells.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_size_t)]
+        l.bd_progress.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         _lib = l
     return _lib
 
@@ -161,6 +162,13 @@ class NativeBamReader(object):
             cells = [raw[off[i]:off[i + 1]].decode("utf-8") for i in range(nc.value)]
         return dict(flag=self._flag[:k], tid=self._i32[0][:k], pos=self._i32[1][:k], next_tid=self._i32[2][:k],
                     next_pos=self._i32[3][:k], valid=self._u8[0][:k], newrun=self._u8[1][:k]), cells
+
+    def progress(self):
+        """Fraction of the file taken in so far (compressed bytes, read-ahead included): monotone, 1.0 at the end."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        if self._l.bd_progress(self._h, C.byref(a), C.byref(b)) != 0 or not b.value:
+            return 0.0
+        return min(1.0, a.value / float(b.value))
 
     def close(self):
         if self._h:

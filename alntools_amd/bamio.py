@@ -14,6 +14,7 @@ both literally, ``bam_utils.py:29-30,134-154``).
 """
 from __future__ import annotations
 
+import os
 import struct
 import zlib
 
@@ -167,6 +168,7 @@ class BamReader(object):
     def __init__(self, path):
         self.path = path
         self._fh = open(path, "rb")
+        self._size = os.path.getsize(path)
         self._blocks = iter_bgzf_blocks(self._fh)
         self._buf = b""
         self._pos = 0
@@ -221,6 +223,10 @@ class BamReader(object):
         qname = self._buf[p + 36:p + 36 + l_name - 1].decode("utf-8")
         self._pos = p + 4 + bs
         return qname, flag, ref_id, pos, nref, npos
+
+    def progress(self):
+        """Fraction of the file's (compressed) bytes taken in so far."""
+        return min(1.0, self._fh.tell() / float(self._size)) if self._size else 0.0
 
     def read_batch(self, max_records):
         """Up to ``max_records`` records as column arrays

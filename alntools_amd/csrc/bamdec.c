@@ -31,7 +31,7 @@ typedef struct {
 } bd_block;
 
 typedef struct bd_handle {
-    FILE* f;
+    FILE* f; uint64_t file_size;
     uint8_t* raw; size_t raw_cap;               /* compressed bytes of the blocks being inflated */
     uint8_t* buf; size_t cap, len, pos;         /* inflated stream: [pos, len) is unread */
     bd_block blocks[BLOCKS_PER_FILL];
@@ -159,7 +159,16 @@ static int need(bd_handle* h, size_t n) {
 static inline int32_t rd_i32(const uint8_t* p) { int32_t v; memcpy(&v, p, 4); return v; }   /* (little-endian hosts only, like the rest of the repo) */
 
 /* ---- API ------------------------------------------------------------------------------------------------------- */
-int bd_abi_version(void) { return 2; }
+int bd_abi_version(void) { return 3; }
+
+/* how far the file has been read (compressed bytes, read-ahead included) and how long it is: a monotone measure of progress */
+int bd_progress(bd_handle* h, uint64_t* consumed, uint64_t* total) {
+    if (!h || !h->f || !consumed || !total) return BD_ERR_ARG;
+    const long at = ftell(h->f);
+    if (at < 0) return fail(h, BD_ERR_IO, "ftell");
+    *consumed = (uint64_t)at; *total = h->file_size;
+    return BD_OK;
+}
 
 void bd_close(bd_handle* h) {
     if (!h) return;
@@ -181,6 +190,8 @@ int bd_open(const char* path, int n_threads, bd_handle** out) {
     h->f = fopen(path, "rb");
     if (!h->f) { free(h); return BD_ERR_IO; }
     setvbuf(h->f, NULL, _IOFBF, 1 << 22);
+    if (fseek(h->f, 0, SEEK_END) == 0) { const long sz = ftell(h->f); h->file_size = sz > 0 ? (uint64_t)sz : 0; }
+    if (fseek(h->f, 0, SEEK_SET) != 0) { fclose(h->f); free(h); return BD_ERR_IO; }
     int rc = need(h, 12);
     if (rc != 0 || memcmp(h->buf + h->pos, "BAM\1", 4) != 0) { bd_close(h); return BD_ERR_FORMAT; }
     h->l_text = rd_i32(h->buf + h->pos + 4);

@@ -131,20 +131,26 @@ def _dev_ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def csr_to_hapcsc(indptr, indices, data, n_loci, n_haps):
+def csr_to_hapcsc(indptr, indices, data, n_loci, n_haps, nnz=None):
     """f-2 on device tensors (int32, CUDA): CSR(bitmask) -> (csc_indptr [H, T+1], csc_indices [total], nnz per haplotype).
-    Haplotype h's row indices are ``csc_indices[starts[h]:starts[h+1]]`` (``bin_utils.ec2emase``'s per-haplotype CSC)."""
+    Haplotype h's row indices are ``csc_indices[starts[h]:starts[h+1]]`` (``bin_utils.ec2emase``'s per-haplotype CSC).
+    One call: the row-index buffer is sized for every non-zero carrying every haplotype (``nnz`` x H, when that is below 2^30
+    elements) instead of asking the library for the count of set bits first."""
     import torch
     lib = load()
     dev = indptr.device
     E = indptr.numel() - 1
     tot = C.c_uint64()
-    rc = lib.ecb_csr_to_hapcsc_device(dev.index or 0, E, n_loci, n_haps, _dev_ptr(indptr), _dev_ptr(indices), _dev_ptr(data),
-                                      None, None, C.byref(tot))
-    if rc != 0:
-        raise EcbError(rc, (lib.ecb_last_error(None) or b"").decode())
+    nnz = indices.numel() if nnz is None else int(nnz)
+    cap = nnz * n_haps
+    if cap >= (1 << 30):                             # (a count first: the exact size)
+        rc = lib.ecb_csr_to_hapcsc_device(dev.index or 0, E, n_loci, n_haps, _dev_ptr(indptr), _dev_ptr(indices), _dev_ptr(data),
+                                          None, None, C.byref(tot))
+        if rc != 0:
+            raise EcbError(rc, (lib.ecb_last_error(None) or b"").decode())
+        cap = tot.value
     cptr = torch.empty((n_haps, n_loci + 1), dtype=torch.int32, device=dev)
-    cidx = torch.empty(max(tot.value, 1), dtype=torch.int32, device=dev)
+    cidx = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
     rc = lib.ecb_csr_to_hapcsc_device(dev.index or 0, E, n_loci, n_haps, _dev_ptr(indptr), _dev_ptr(indices), _dev_ptr(data),
                                       _dev_ptr(cptr), _dev_ptr(cidx), C.byref(tot))
     if rc != 0:

@@ -107,6 +107,37 @@ def test_convert_over_several_ranks_writes_the_reference_bytes(tmp_path, monkeyp
         assert sizes["n_ecs"] > 0
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_multisample_convert_over_several_ranks_writes_the_reference_bytes(tmp_path, monkeypatch, world):
+    """``ALNTOOLS_GPUS=N`` for a directory of BAM files (``bam_utils_multisample.convert``): the files are dealt out to N processes
+    (the reference: one worker per file, ``bam_utils_multisample.py:473-480``; here all on the one GPU of the box, over gloo), cell
+    ids agreed on, EC tables merged by key range and adopted by rank 0, every rank's reads reduced to (EC, cell, file) triples
+    against the merged ECs, rank 0 filters and writes: the reference's ``.bin`` bytes at its three thresholds, its range file,
+    its counters -- three files on two ranks (uneven) and on three."""
+    import json
+    from alntools_amd import bam_utils_multisample as ms, bamio
+    golden = os.path.join(os.path.dirname(__file__), "golden")
+    monkeypatch.setenv("ALNTOOLS_GPUS", str(world))
+    monkeypatch.setenv("ALNTOOLS_DIST_BACKEND", "gloo")
+    monkeypatch.setenv("ALNTOOLS_GPU_LIST", ",".join(["0"] * world))
+    g = json.load(open(os.path.join(golden, "g4_multi.json")))
+    refs = [tuple(r) for r in g["references"]]
+    paths = []
+    for fname in g["glob_order"]:                      # the order the reference's glob returned when the golden was made
+        p = str(tmp_path / fname)
+        bamio.write_bam(p, refs, [tuple(r) for r in g["files"][fname]])
+        paths.append(p)
+    for mc, tag in ((-1, "0"), (20, "20"), (60, "60")):
+        out, rng = str(tmp_path / ("m%s.bin" % tag)), str(tmp_path / ("m%s.range" % tag))
+        r = ms.convert_files(paths, out, None, minimum_count=mc, range_filename=rng)
+        assert open(out, "rb").read() == open(os.path.join(golden, "g4_multi_min%s.bin" % tag), "rb").read(), mc
+        c = g["counters"][str(mc)]
+        assert r["valid_alignments"] == c["Number of alignments"]
+        assert r["n_ecs"] == c["Number of ECs after filtering"] and r["n_cells"] == c["Number of cells after filtering"]
+        assert r["n_ecs_before"] == c["Number of ECs"] and r["n_cells_before"] == c["Number of cells"]
+        assert open(rng).read() == open(os.path.join(golden, "g4_multi.range.txt")).read()
+
+
 def _pieces_of(spec, world, dev):
     """The multi-rank protocol by hand in one process: ``world`` shard handles, cut into ``world`` key ranges, range q merged
     on its own handle and finalized there -> ([(packed, n_ecs, nnz)], totals)."""

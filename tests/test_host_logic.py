@@ -109,7 +109,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     assert declared == set(bamdec.SYMBOLS), declared ^ set(bamdec.SYMBOLS)
     for s in declared:
         assert hasattr(bamdec.lib(), s), s
-    assert bamdec.lib().bd_abi_version() == 2
+    assert bamdec.lib().bd_abi_version() == bamdec.ABI_VERSION == 3
 
 
 def test_plain_c_program_links_against_the_abi(tmp_path):
