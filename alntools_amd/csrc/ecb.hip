@@ -2436,39 +2436,60 @@ __global__ void k_msf2_seg(const u32* ec, u64 n, u32 n_ecs, u32* seg, u32* err) 
     for (long long x = ep + 1; x <= (long long)e; ++x) seg[x] = (u32)t;
     if (t == n - 1) for (u64 x = (u64)e + 1; x <= n_ecs; ++x) seg[x] = (u32)n;
 }
-// One wave per EC: (i) the EC's first appearance in every file it has reads in -- the smallest first read among its triples of
-// that file (a table of one word per file in LDS); (ii) every triple whose file is its cell's first file offers the cell
-// (first appearance of the EC in that file, first read of the triple) -- the smallest offer is where the cell enters the
-// reference's cr_totals (bam_utils_multisample.py:513-546); (iii) whether any of the EC's cells survives the minimum count.
+// Per EC: (i) the EC's first appearance in every file it has reads in -- the smallest first read among its triples of that
+// file; (ii) every triple whose file is its cell's first file offers the cell (first appearance of the EC in that file, first
+// read of the triple) -- the smallest offer is where the cell enters the reference's cr_totals (bam_utils_multisample.py:
+// 513-546); (iii) whether any of the EC's cells survives the minimum count.
+// One THREAD per EC of up to MSF_SMALL triples (the run of the mill: two dozen triples; the few triples that make an offer look
+// their file's first appearance up by walking the EC's stretch again -- neighbours' stretches follow each other in memory), one
+// WORKGROUP per larger EC, queued by the first kernel, with the per-file table in LDS.  (One wave per EC with three dependent
+// sweeps was latency: 14 us per EC.)
+constexpr u32 MSF_SMALL = 256;
 constexpr u32 MSF_FILES = 1u << MS_FILE_BITS;
-__global__ __launch_bounds__(TPB) void k_msf2_ecs(const u32* meta, const u32* first, const u32* seg, u32 n_ecs, const u64* total,
-                                                  const u32* firstfile, u64 min_count, u64* cellkey, u32* keep_ec) {
-    __shared__ u32 fecw[TPB / 64][MSF_FILES];
-    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    u32* fec = fecw[w];
-    for (u32 f = lane; f < MSF_FILES; f += 64) fec[f] = 0xFFFFFFFFu;
-    wave_sync();
-    const u64 nw = (u64)gridDim.x * (TPB / 64);
-    for (u64 e = (u64)blockIdx.x * (TPB / 64) + w; e < n_ecs; e += nw) {
-        const u32 a = seg[e], b = seg[e + 1];
+__global__ void k_msf2_ecs_small(const u32* meta, const u32* first, const u32* seg, u32 n_ecs, const u64* total, const u32* firstfile,
+                                 u64 min_count, u64* cellkey, u32* keep_ec, u32* big, u32* n_big) {
+    const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (e >= n_ecs) return;
+    const u32 a = seg[e], b = seg[e + 1];
+    if (b - a > MSF_SMALL) { big[atomicAdd(n_big, 1u)] = (u32)e; return; }
+    bool keep = false;
+    for (u32 t = a; t < b; ++t) {
+        const u32 m = meta[t], c = m & ((1u << ECB_CELL_BITS) - 1u), f = m >> ECB_CELL_BITS;
+        keep |= total[c] >= min_count;
+        if (firstfile[c] != f) continue;
+        u32 fec = first[t];
+        for (u32 x = a; x < b; ++x) if ((meta[x] >> ECB_CELL_BITS) == f) fec = min(fec, first[x]);
+        const u64 offer = ((u64)fec << 32) | first[t];
+        if (offer < cellkey[c]) atomicMin(&cellkey[c], offer);               // (the plain read may be stale: then one atomic too many)
+    }
+    if (keep) keep_ec[e] = 1u;
+}
+__global__ __launch_bounds__(TPB) void k_msf2_ecs_big(const u32* meta, const u32* first, const u32* seg, const u32* big, const u32* n_big,
+                                                      const u64* total, const u32* firstfile, u64 min_count, u64* cellkey, u32* keep_ec) {
+    __shared__ u32 fec[MSF_FILES];
+    __shared__ u32 s_keep;
+    for (u32 q = blockIdx.x; q < *n_big; q += gridDim.x) {
+        const u32 e = big[q], a = seg[e], b = seg[e + 1];
+        for (u32 f = threadIdx.x; f < MSF_FILES; f += TPB) fec[f] = 0xFFFFFFFFu;
+        if (threadIdx.x == 0) s_keep = 0;
+        __syncthreads();
         bool keep = false;
-        for (u32 t = a + lane; t < b; t += 64) {
+        for (u32 t = a + threadIdx.x; t < b; t += TPB) {
             const u32 m = meta[t];
             atomicMin(&fec[m >> ECB_CELL_BITS], first[t]);
             keep |= total[m & ((1u << ECB_CELL_BITS) - 1u)] >= min_count;
         }
-        wave_sync();
-        for (u32 t = a + lane; t < b; t += 64) {
+        if (keep) s_keep = 1u;
+        __syncthreads();
+        for (u32 t = a + threadIdx.x; t < b; t += TPB) {
             const u32 m = meta[t], c = m & ((1u << ECB_CELL_BITS) - 1u), f = m >> ECB_CELL_BITS;
             if (firstfile[c] == f) {
                 const u64 offer = ((u64)fec[f] << 32) | first[t];
-                if (offer < cellkey[c]) atomicMin(&cellkey[c], offer);       // (the plain read may be stale: then one atomic too many)
+                if (offer < cellkey[c]) atomicMin(&cellkey[c], offer);
             }
         }
-        wave_sync();
-        for (u32 t = a + lane; t < b; t += 64) fec[meta[t] >> ECB_CELL_BITS] = 0xFFFFFFFFu;
-        wave_sync();
-        if (__ballot(keep) && lane == 0) keep_ec[e] = 1u;
+        if (threadIdx.x == 0 && s_keep) keep_ec[e] = 1u;
+        __syncthreads();
     }
 }
 // cells that have reads, as the lists the ordering below works on
@@ -3426,6 +3447,30 @@ int ecb_push_cells(ecb_handle* h, const uint32_t* meta, uint64_t first_read, siz
     return ECB_OK;
 }
 
+int ecb_push_cells_device(ecb_handle* h, const void* d_meta, uint64_t first_read, size_t n) {
+    if (!h) return ECB_ERR_ARG;
+    if (!(h->cfg.flags & ECB_F_MULTISAMPLE)) return fail(h, ECB_ERR_STATE, "handle was created without ECB_F_MULTISAMPLE");
+    if (h->finalized) return fail(h, ECB_ERR_STATE, "push after finalize");
+    if (!n) return ECB_OK;
+    if (!d_meta) return fail(h, ECB_ERR_ARG, "null meta");
+    HIPCHK(h, hipSetDevice(h->device));
+    const u64 need = first_read + n;
+    if (need > h->meta_cap) {
+        const u64 nc = std::max<u64>(need, h->meta_cap * 2);
+        u32* p = nullptr;
+        HIPCHK(h, hipMalloc(&p, nc * sizeof(u32)));
+        if (h->meta) {
+            HIPCHK(h, hipMemcpyAsync(p, h->meta, h->meta_hi * sizeof(u32), hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            HIPCHK(h, hipFree(h->meta));
+        }
+        h->meta = p; h->meta_cap = nc;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->meta + first_read, d_meta, n * sizeof(u32), hipMemcpyDeviceToDevice, h->stream));   // (ordered on the handle's stream: no wait)
+    h->meta_hi = std::max<u64>(h->meta_hi, need);
+    return ECB_OK;
+}
+
 int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
     if (!h || !out) return ECB_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
@@ -4011,7 +4056,13 @@ int ecb_ms_filter(ecb_handle* h, uint32_t n_cells, int64_t minimum_count, ecb_ms
     }
     // 2. per EC: its first appearance in every file; where every cell enters the cell order; whether the EC keeps a cell
     k_msf2_seg<<<nblk(T, TPB), TPB, 0, st>>>(ec, T, (u32)E, seg, d_err);
-    k_msf2_ecs<<<(unsigned)std::min<u64>(nblk(E * 64, TPB), 256 * 8), TPB, 0, st>>>(meta, first, seg, (u32)E, total, firstfile, min_count, cellkey, keep_ec);
+    {
+        u32* big = sc.get<u32>(E + 1);                       // ECs of more than MSF_SMALL triples, their number behind the list
+        if (!big) return fail(h, ECB_ERR_HIP, "out of device memory");
+        HIPCHK(h, hipMemsetAsync(big + E, 0, 4, st));
+        k_msf2_ecs_small<<<nblk(E, TPB), TPB, 0, st>>>(meta, first, seg, (u32)E, total, firstfile, min_count, cellkey, keep_ec, big, big + E);
+        k_msf2_ecs_big<<<(unsigned)std::min<u64>(std::max<u64>(E / MSF_SMALL, 1), 4096), TPB, 0, st>>>(meta, first, seg, big, big + E, total, firstfile, min_count, cellkey, keep_ec);
+    }
     // 3. cell order: by (first appearance of the EC in the cell's first file, first read), then -- stable -- by that file
     int rc, where = 0;
     k_msf2_cellflag<<<nblk(n_cells, TPB), TPB, 0, st>>>(total, n_cells, flag);

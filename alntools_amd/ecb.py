@@ -25,7 +25,7 @@ FLAG_NEXT_POS_NEG = 0x2000
 
 #: every symbol include/ecb.h declares
 SYMBOLS = ("ecb_abi_version", "ecb_device_count", "ecb_create", "ecb_destroy", "ecb_reset", "ecb_last_error",
-           "ecb_push", "ecb_push_device", "ecb_push_cells", "ecb_verify_device", "ecb_finalize", "ecb_export",
+           "ecb_push", "ecb_push_device", "ecb_push_cells", "ecb_push_cells_device", "ecb_verify_device", "ecb_finalize", "ecb_export",
            "ecb_export_device", "ecb_export_ranges", "ecb_export_range_minmax", "ecb_export_pairs", "ecb_ms_filter", "ecb_ms_export",
            "ecb_export_read_ec", "ecb_table_sizes",
            "ecb_table_export_device", "ecb_table_merge_device", "ecb_table_export_parts_device",
@@ -90,6 +90,7 @@ def load():
     lib.ecb_push.argtypes = [vp, vp, vp, vp, vp, sz]
     lib.ecb_push_device.argtypes = [vp, vp, vp, vp, vp, sz]
     lib.ecb_push_cells.argtypes = [vp, vp, u64, sz]
+    lib.ecb_push_cells_device.argtypes = [vp, vp, u64, sz]
     lib.ecb_verify_device.argtypes = [vp, vp, vp, vp, sz, C.POINTER(u64), C.POINTER(u64)]
     lib.ecb_finalize.argtypes = [vp, C.POINTER(Sizes)]
     lib.ecb_export.argtypes = [vp] + [vp] * 6
@@ -248,6 +249,16 @@ class EcBuilder(object):
         """Multisample: ``cell | file << 22`` of reads ``[first_read, first_read + len(meta))``."""
         m = np.ascontiguousarray(meta, dtype=np.uint32)
         self._chk(self._lib.ecb_push_cells(self._h, _ptr(m), first_read, len(m)))
+
+    def push_cells_device(self, meta, first_read):
+        """The same from an int32 CUDA tensor (kept alive by the caller until ``finalize``)."""
+        self._chk(self._lib.ecb_push_cells_device(self._h, _dev_ptr(meta), first_read, meta.numel()))
+
+    def ms_filter_sizes(self, n_cells, minimum_count):
+        """``ecb_ms_filter`` alone: the result stays on the device (``ms_filter`` also copies it to the host) -> its sizes."""
+        m = MsSizes()
+        self._chk(self._lib.ecb_ms_filter(self._h, n_cells, minimum_count, C.byref(m)))
+        return {k: int(getattr(m, k)) for k, _ in MsSizes._fields_}
 
     # -- results -------------------------------------------------------------
     def finalize(self):

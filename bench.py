@@ -35,6 +35,8 @@ WORKLOADS = {
     "tiny": (400_000, 4_000, 8, True, "smoke-sized paired-end workload"),
     "c3h": (50_000_000, 80_000, 8, True, "half of config 3 (debug)"),
     "c2x": (150_000_000, 40_000, 8, False, "3x config 2 (debug: > 2^31 records)"),
+    "c4": (200_000_000, 80_000, 8, True, "BASELINE config 4: multisample, 200M paired-end reads, 5k cell barcodes (log-normal sizes) over 64 files, minimum count 1000"),
+    "c4h": (100_000_000, 80_000, 8, True, "half of config 4 (debug)"),
     "dip": (200_000_000, 40_000, 2, False, "diploid single-end reads: 2 hap x 40k transcripts, ~4 records per read (short reads: several passes per tile)"),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
@@ -261,7 +263,7 @@ def main():
 
     # EC-table slots: sized for the workload's EC count (c3: 3.7 M ECs) so that the timed steps do not grow it
     # (a shard of 1/4 or 1/8 of config 3 still founds 2.3 - 3 M of its 3.7 M ECs: 2^23 slots keep it under half full)
-    ec_cap = 1 << int(os.environ.get("ECB_EC_CAP_LOG2", ("23" if world >= 4 else "24") if args.workload in ("c3", "c3h") else "22"))
+    ec_cap = 1 << int(os.environ.get("ECB_EC_CAP_LOG2", ("23" if world >= 4 else "24") if args.workload in ("c3", "c3h", "c4", "c4h") else "22"))
     b = ecb.EcBuilder(T, H, device=local, ec_capacity=ec_cap, arena_capacity=1 << 26)
     eng = ecdist.GpuEngine(b, device)
     if rehearsal:
@@ -289,13 +291,35 @@ def main():
         return part_eng
 
     sizes = {}
+    ms_sizes = {}
     parity_failed = False
+    multisample = args.workload in ("c4", "c4h")
+    n_cells, min_count, meta = 5000, 1000, None
+    if multisample:
+        if use_dist:
+            raise SystemExit("bench.py --workload c4 measures one GPU (the multi-GPU multisample path is behind bam_utils_multisample.convert)")
+        # cell of every read: 5 000 barcodes with log-normal sizes (sigma = 1), drawn by a hash of the read index; file = the read's
+        # 64th of the run (a directory of 64 BAM files read in order); ids in order of first appearance, as the host hands them out
+        g = torch.arange(st["reads"], dtype=torch.int64, device=device)
+        u = (((g * 0x9E3779B97F4A7C15) >> 11) & ((1 << 40) - 1)).to(torch.float64) / float(1 << 40)
+        w = torch.exp(torch.randn(n_cells, generator=torch.Generator().manual_seed(20260101), dtype=torch.float64)).to(device)
+        cdf = torch.cumsum(w / w.sum(), 0)
+        cell = torch.searchsorted(cdf, u).clamp_(max=n_cells - 1)
+        _, inv = torch.unique(cell, return_inverse=True)
+        meta = (inv | (((g * 64) // st["reads"]) << 22)).to(torch.int32)
+        del g, u, cell, inv
+        b.close()
+        b = ecb.EcBuilder(T, H, device=local, ec_capacity=ec_cap, arena_capacity=1 << 26, multisample=True)
     per_range = os.environ.get("ECB_DIST_FINALIZE", "ranges") != "root"      # ("root": the merged tables go to rank 0, which finalizes alone)
 
     def step():
         b.reset()
         b.push_device(rid, loc, hf)
-        if use_dist:
+        if multisample:      # + the cell of every read (4 B per read), the (EC, cell, file) triples, cell order / filter / N on the device
+            b.push_cells_device(meta, 0)
+            sizes.update(b.finalize())
+            ms_sizes.update(b.ms_filter_sizes(n_cells, min_count))
+        elif use_dist:
             m = ecdist.exchange_and_merge(eng, make_part, make_root, root=0, finalize_ranges=per_range)
             if m is not None:
                 sizes.update(m.b.finalize())
@@ -340,7 +364,7 @@ def main():
     # config 3 names bam2emase: the .h5 holds one CSC matrix per haplotype, so its device work is the step plus the transposition
     # of the finished CSR (ecb_csr_to_hapcsc_device).  Timed on its own, outside the K steps the headline is measured on.
     emase_ms = None
-    if not use_dist and not os.environ.get("ECB_ABLATE") and sizes.get("n_ecs"):
+    if not use_dist and not multisample and not os.environ.get("ECB_ABLATE") and sizes.get("n_ecs"):
         ipt = torch.empty(sizes["n_ecs"] + 1, dtype=torch.int32, device=device)
         ixt = torch.empty(sizes["nnz_a"], dtype=torch.int32, device=device)
         dat = torch.empty(sizes["nnz_a"], dtype=torch.int32, device=device)
@@ -360,7 +384,7 @@ def main():
         emase_bits = int(cidx.numel())
         del ipt, ixt, dat, cptr, cidx
     exact = None
-    if not use_dist and not os.environ.get("ECB_ABLATE") and not os.environ.get("ECB_NO_VERIFY"):
+    if not use_dist and not multisample and not os.environ.get("ECB_ABLATE") and not os.environ.get("ECB_NO_VERIFY"):
         # outside the timed region: re-derive every read's target set and compare it with its EC's stored key
         b.reset()
         b.push_device(rid, loc, hf)
@@ -387,6 +411,8 @@ def main():
         # the whole step against SURVEY 8d's B_alg = 12 A + 4 R + 4 (E + 1) + 8 nnz(A): tuples -> CSR, everything in between
         E, nnz = sizes.get("n_ecs") or 0, sizes.get("nnz_a") or 0
         step_bytes = 12.0 * total_records + 4.0 * total_reads + 4.0 * (E + 1) + 8.0 * nnz
+        if multisample:      # + the cell stream and N
+            step_bytes += 4.0 * total_reads + 8.0 * ms_sizes.get("nnz_n", 0)
         step_achieved = step_bytes / (ms_per_step * 1e-3) / 1e9
         peak_copy, peak_read, peak_how = copy_peak(device) if not rehearsal else (None, None, None)
         traffic, traffic_src = None, None
@@ -412,6 +438,8 @@ def main():
             "config": {"workload": desc, "reads": R, "loci": T, "haplotypes": H, "paired_end": paired,
                        "records": total_records, "valid_alignments": total_valid, "reads_with_alignments": total_reads,
                        "ecs": sizes.get("n_ecs"), "nnz_a": sizes.get("nnz_a"),
+                       "multisample": None if not multisample else dict(cells=n_cells, files=64, minimum_count=min_count, triples=sizes.get("nnz_n"),
+                                                                        cells_kept=ms_sizes.get("n_cells_kept"), ecs_kept=ms_sizes.get("n_ecs_kept"), nnz_n=ms_sizes.get("nnz_n")),
                        "sharding": "contiguous reads over %d GPU(s)%s" % (world, ", per-rank EC tables cut into key ranges, exchanged point-to-point over RCCL, merged and finalized per range, rows assembled on rank 0" if world > 1 else ""),
                        "generate_s": round(t_gen, 2), "exactness_pass": exact,
                        "step_emase": None if emase_ms is None else "step + CSR -> per-haplotype CSC (%d row indices) on the device, what bam2emase's .h5 holds: %.2f ms" % (emase_bits, emase_ms)},
@@ -425,7 +453,7 @@ def main():
                          "peak_measured_copy": peak_copy, "peak_measured_read": peak_read, "peak_measured_how": peak_how,
                          "frac_of_measured_copy": (achieved / peak_copy) if peak_copy else None},
         }
-        if not use_dist and not args.no_cpu_baseline:
+        if not use_dist and not args.no_cpu_baseline and not multisample:
             out["cpu_baseline"], oracle_result = cpu_baseline(rid, loc, hf, H, args.cpu_sample_reads, args.cpu_threads)
             if oracle_result is not None:      # the whole workload went through the oracle: hold the GPU's result to it, bit for bit
                 ok, diff = parity_vs_oracle(b, rid, loc, hf, oracle_result)

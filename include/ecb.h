@@ -114,6 +114,9 @@ int ecb_push_device(ecb_handle* h, const void* d_read_id, const void* d_locus, c
  *        | input file index << 22 (bits 22-31; the reference scans one file per worker, :473-480).
  * The host leaves out the last read of every file (the reference never counts it, :306-321). */
 int ecb_push_cells(ecb_handle* h, const uint32_t* meta, uint64_t first_read, size_t n);
+/* The same from device memory (the cell stream of a resident workload: +4 bytes per read); the caller keeps d_meta
+ * alive and unchanged until the next call that waits for the handle (ecb_finalize). */
+int ecb_push_cells_device(ecb_handle* h, const void* d_meta, uint64_t first_read, size_t n);
 #define ECB_CELL_BITS 22
 
 /* Close the stream: rank ECs by first appearance (bam_utils.py:682-698), build CSR A and N. */
