@@ -130,9 +130,10 @@ __device__ __forceinline__ u32 fmix32(u32 h) {           // murmur3 finaliser: a
     return h;
 }
 __device__ __forceinline__ u64 pair_hash64(u32 locus, u32 mask) {
-    const u32 x = fmix32(locus ^ 0x9E3779B9u), y = fmix32(mask * 0x9E3779B1u + 0x7F4A7C15u);
-    const u32 h0 = fmix32(x + y);
-    const u32 h1 = fmix32((x ^ 0x85EBCA77u) - (y << 7 | y >> 25));
+    // two finalisers instead of four: the hash only places an EC in the table (identity is the key), and what the sum over a
+    // read's pairs needs is that the low word spreads over the slots and the high word differs where the low one collides
+    const u32 h0 = fmix32(locus * 0x9E3779B1u + mask * 0x85EBCA77u + 0x7F4A7C15u);
+    const u32 h1 = fmix32((h0 ^ locus) * 0xC2B2AE3Du + mask);
     return ((u64)h1 << 32) | h0;
 }
 // the sums of fmix32 outputs are already uniformly spread: the table hash is the sum itself (made non-zero)
@@ -369,6 +370,7 @@ __device__ __forceinline__ u32 group_mask(int lo, int hi) {
 }
 
 struct TileRegs { u32 rr[RPL], ll[RPL], hh[RPL]; };
+
 
 // Where a key goes when its first slot (home region + low locus bits) is taken by another key: a second start anywhere in the
 // table, then steps of a key-dependent stride that is coprime to the table size -- double hashing.  (Walking on slot by slot
@@ -636,6 +638,10 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
         u32 r_key[RPL], r_bit[RPL];
         u32 m_act = 0, m_head = 0;                 // bit k: valid record of a read of this pass / head
         const u32 lim = own ? (1u << lg) : (open ? npend + 1u : 0u);   // (past my slice only the open read is mine)
+        // Most tiles lie wholly inside the pass: their first record belongs to a read of the pass (the open one, or the first to start)
+        // and their last read still has room -- then every record is "mine" and the per-record test is not made.
+        const u32 rid_first = (u32)__builtin_amdgcn_readfirstlane((int)R.rr[0]), rid_last = (u32)__builtin_amdgcn_readlane((int)R.rr[RPL - 1], 63);
+        const bool all_mine = rid_first - pb < lim && rid_last - pb < lim && rid_last >= rid_first;
         {
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
@@ -679,7 +685,7 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
                             //  LDS keys: both show in the bits from 21 up)
                             hap_or |= ((t & ~KMASK) | f) & (u32)((int)(ok4 << (31 - j)) >> 31);
                             head4 |= (step & 1u) << j;
-                            mine4 |= (relx < lim ? 1u : 0u) << j;
+                            if (!all_mine) mine4 |= (relx < lim ? 1u : 0u) << j;
                         }
                         if constexpr (RANGES) {
                             // reference_start ranges per target (bam_utils.py:282-286), in the pass that has the record in registers anyway:
@@ -720,7 +726,7 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
                 ok4 &= in4; head4 &= in4;
                 bad |= ((p_rel == 0 ? big : 0u) | (head4 & ~ok4)) ? ERR_CONTRACT : 0u;   // (the tile a park resumes in was checked before the park)
                 bad |= (hap_or >> (ECB_HAP_SHIFT + 5)) ? ERR_RANGE : 0u;      // (indices below 32 are checked against n_haplotypes per EC, at emit)
-                m_act |= (ok4 & mine4) << (4 * g); m_head |= head4 << (4 * g);
+                m_act |= (all_mine ? ok4 : (ok4 & mine4)) << (4 * g); m_head |= head4 << (4 * g);
             }
         }
         TICK(0);
@@ -930,7 +936,7 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
                     if (!same) my_new += 1;                             // (counted as "mismatches" in verify mode)
                 }
                 parked = parked_next; taken = true;
-            } else {
+                        } else {
                 // Lookup; founders publish their keys; THEN lanes whose slot was claimed but not (visibly) complete settle it --
                 // the founder such a ln waits for may be a ln of this very wave.  One round in all but a handful of flushes.
                 for (u32 round = 0;; ++round) {
@@ -946,7 +952,7 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
                         // that point, and at the end of the tile (where the moves sink to if left alone) or at the top of the next one
                         // (the parked flag) that meant sitting out the round trips of the founders' stores -- ~3000 clocks per tile on C3.
                         parked = parked_next; taken = true;
-#pragma unroll
+                    #pragma unroll
                         for (int k = 0; k < RPL; ++k) {
                             asm volatile("" : "+v"(R.rr[k])); asm volatile("" : "+v"(R.ll[k])); asm volatile("" : "+v"(R.hh[k]));
                             if constexpr (RANGES) asm volatile("" : "+v"(r_pos[k]));
@@ -1045,7 +1051,7 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
         if (preflush) { revisit = true; continue; }                  // (the tile is still in its registers: nothing was prefetched over it)
         if (!taken) {                                                // no flush behind this tile: the prefetched one is waited for here
             parked = parked_next;
-#pragma unroll
+        #pragma unroll
             for (int k = 0; k < RPL; ++k) {
                 asm volatile("" : "+v"(R.rr[k])); asm volatile("" : "+v"(R.ll[k])); asm volatile("" : "+v"(R.hh[k]));
                 if constexpr (RANGES) asm volatile("" : "+v"(r_pos[k]));
