@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define ECB_ABI_VERSION 2
+#define ECB_ABI_VERSION 3
 
 #define ECB_OK               0
 #define ECB_ERR_ARG         -1   /* bad argument / configuration */

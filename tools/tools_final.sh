@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: everything profiles/ holds for one workload: bench line, rocprofv3 kernel stats, PMC passes, the traffic file bench.py reads.
 # usage: tools_final.sh <workload> <round tag>      (results in gpurun_out/final_<workload>/)
-W=${1:-c3}; TAG=${2:-r02}
+W=${1:-c3}; TAG=${2:-r03}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final_$W; mkdir -p $O
 timeout -k 10 500 python $R/bench.py --workload $W > $O/bench.log 2>$O/bench.err && grep '^{' $O/bench.log > $O/${TAG}_bench_${W}_n1.json
 bash $R/tools/tools_prof.sh $W gpurun_out/final_$W/prof > $O/${TAG}_rocprof_kernel_stats_$W.txt 2>&1; rm -rf $O/prof
