@@ -24,7 +24,7 @@ print(json.dumps({"kernel": "k_stream<false, false>", "workload": sys.argv[3], "
                   "hbm_bytes_per_launch": int((2 * stream_kib + table_kib + write_kib) * 1024),
                   "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/tools_final.sh); the record streams' share of FETCH_SIZE "
                             "(measured with the EC table switched off) doubled, the table's 64-byte lines and WRITE_SIZE taken 1:1 "
-                            "(calibration on known byte counts: profiles/%s_fetch_size_calibration.txt)" % sys.argv[4]}, indent=1))
+                            "(calibration on known byte counts: profiles/r02_fetch_size_calibration.txt)"}, indent=1))
 PY
 rm -rf $O/abl
 ls -la $O
