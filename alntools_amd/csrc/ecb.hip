@@ -8,17 +8,20 @@
 //              workgroup barriers.  Per tile: (a) record filter (bam_utils.py:264-270) and read heads from the host's run
 //              counter (:289-320); (b) one {locus -> haplotype mask} open-addressing table per read in LDS -- ds_cmpst on the
 //              locus, ds_or of the haplotype bit: the duplicate collapse of :322-325 and the per-(EC, target, haplotype) bit
-//              test of :800-819 in two LDS atomics; each table entry is hashed once and summed per read (a commutative set
-//              hash, the stand-in for the sorted string key of :307); (c) one lane per read looks the 126-bit key up in the
-//              global EC table or inserts it, and records the slot of the read.  The lane that creates an EC copies its
-//              (locus, mask) pairs from LDS to the key arena.
+//              test of :800-819 in two LDS atomics.  A pass of that table spans as many tiles as fit; at its end (a "flush") each
+//              table entry is hashed once and summed per read (a commutative set hash that only places the EC: identity is the
+//              key itself, the stand-in for the sorted string key of :307) and (c) one lane per read looks its set up in the
+//              global EC table -- hash, then an exact compare of the stored key -- or inserts it, and records the slot of the
+//              read.  Founders' (locus, mask) pairs are copied from LDS into the slot / the key arena by the whole wave.
 //   k_slow     the same for single reads that do not fit a tile or hit a full table (one workgroup per read).
 //   k_count    reads per EC and first read per EC (:309-312, 688-698) from the per-read slots, without global atomics:
 //              partition by slot range, count in LDS.
 //   finalize   rank ECs by first appearance (bitmap + scan: :682-698), scan of row lengths, sort each row by locus and
 //              emit CSR A / N (:835-847, bin_utils.py:208-211).
 //   k_merge    multi-GPU: re-insert another rank's serialised table (the ordered merge of :680-724).
-//   k_ms_*, k_cv_*   multisample (EC, cell, file) triples; CSR(bitmask) <-> per-haplotype CSC (bin_utils.py:979-1028).
+//   k_ms_*, k_msf*   multisample: (EC, cell, file) triples of the reads (one radix sort); cell order, minimum-count filter, EC re-rank
+//              and CSC N in linear passes over them (bam_utils_multisample.py:503-636, 737-791).
+//   k_cv_*     CSR(bitmask) <-> per-haplotype CSC (bin_utils.py:979-1028).
 //
 // Integer / indexing work only: no MFMA.  The bound is HBM bandwidth; today the stream kernel is VALU-issue bound.
 #include <hip/hip_runtime.h>
@@ -2118,37 +2121,14 @@ __global__ void k_ms_combine(const u64* keys, const u32* idx, const u32* flag, c
 
 
 // ---------------------------------------------------------------------------------------------
-// f-2: CSR(bitmask) <-> per-haplotype CSC (bin_utils.py:979-1028).  Expand to (key, value) pairs, stable radix sort
-// (the LSD sort above), locate rows / columns by binary search on the sorted keys.
+// f-2: CSR(bitmask) <-> per-haplotype CSC (bin_utils.py:979-1028).  CSR -> CSC: a transposition of the non-zeros (k_cv_keys ...
+// k_cv_ptr below).  CSC -> CSR: the set bits expanded to (row * T + column) keys, the stable radix sort (the LSD sort below),
+// runs of equal keys OR-ed, row pointers by binary search on the sorted keys.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ u64 lower_bound_u32(const u32* a, u64 n, u32 v) {
-    u64 lo = 0, hi = n;
-    while (lo < hi) { const u64 m = (lo + hi) >> 1; if (a[m] < v) lo = m + 1; else hi = m; }
-    return lo;
-}
 __device__ __forceinline__ u64 lower_bound_u64(const u64* a, u64 n, u64 v) {
     u64 lo = 0, hi = n;
     while (lo < hi) { const u64 m = (lo + hi) >> 1; if (a[m] < v) lo = m + 1; else hi = m; }
     return lo;
-}
-__global__ void k_cv_popc(const int* data, u64 nnz, u32* cnt) {
-    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (i < nnz) cnt[i] = __popc((u32)data[i]);
-}
-__global__ void k_cv_expand(const int* indptr, u32 n_ecs, const int* indices, const int* data, u64 nnz, const u32* pos,
-                            u32 n_loci, u64* keys, u32* vals) {
-    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (i >= nnz) return;
-    u32 lo = 0, hi = n_ecs;                                  // row of entry i: last e with indptr[e] <= i
-    while (lo < hi) { const u32 m = (lo + hi + 1) >> 1; if ((u64)indptr[m] <= i) lo = m; else hi = m - 1; }
-    u32 m = (u32)data[i], at = pos[i];
-    while (m) { const u32 h = __ffs(m) - 1; m &= m - 1; keys[at] = (u64)h * n_loci + (u32)indices[i]; vals[at] = lo; ++at; }
-}
-__global__ void k_cv_cscptr(const u64* keys, u64 total, u32 n_loci, u32 n_haps, int* cscptr) {
-    const u64 c = blockIdx.x * (u64)blockDim.x + threadIdx.x;          // c = h * (T + 1) + t
-    if (c >= (u64)n_haps * (n_loci + 1)) return;
-    const u32 h = (u32)(c / (n_loci + 1)), t = (u32)(c % (n_loci + 1));
-    cscptr[c] = (int)(lower_bound_u64(keys, total, (u64)h * n_loci + t) - lower_bound_u64(keys, total, (u64)h * n_loci));
 }
 __global__ void k_cv_back_expand(const int* cscptr, const int* cscidx, u64 total, u32 n_loci, u32 n_haps, const u64* hap_start,
                                  u64* keys, u32* vals) {
@@ -2296,10 +2276,6 @@ __global__ void k_clear_slots(Slot* table, const u32* list, u64 n) {
     uint4* s = reinterpret_cast<uint4*>(table + list[i]);
     const uint4 z = make_uint4(0, 0, 0, 0);
     s[0] = z; s[1] = z; s[2] = z; s[3] = z;
-}
-__global__ void k_fill_i32(int* p, u64 n, int v) {
-    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2568,14 +2544,6 @@ __global__ void k_msf_rows(const u32* indptr, const int* indices, const int* dat
     if (e >= n_ecs || !keep_ec[e]) return;
     const u32 a = indptr[e], b = indptr[e + 1], o = indptr2[new_rank[e]];
     for (u32 i = a; i < b; ++i) { indices2[o + (i - a)] = indices[i]; data2[o + (i - a)] = data[i]; }
-}
-__global__ void k_widen(const u32* in, u64 n, u64* out) {
-    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (i < n) out[i] = in[i];
-}
-__global__ void k_narrow(const u64* in, u64 n, u32* out) {
-    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (u32)in[i];
 }
 
 }  // namespace
