@@ -23,7 +23,8 @@
 //              and CSC N in linear passes over them (bam_utils_multisample.py:503-636, 737-791).
 //   k_cv_*     CSR(bitmask) <-> per-haplotype CSC (bin_utils.py:979-1028).
 //
-// Integer / indexing work only: no MFMA.  The bound is HBM bandwidth; today the stream kernel is VALU-issue bound.
+// Integer / indexing work only: no MFMA.  The bound is HBM bandwidth: the stream part of k_stream runs at the chip's streaming rate, what is
+// left above it is the EC table's random lines sharing the memory system with the stream.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
