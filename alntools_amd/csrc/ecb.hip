@@ -425,7 +425,8 @@ struct LdsSetCmp {
     __device__ __forceinline__ int full(Slot* s, u32 n, u32 off) const {
         if (n != np) return CMP_DIFFERENT;
         for (u32 i = 0; i < n; ++i) {
-            const uint2 pr = key_pair_fresh(s, cold->arena, off, i);
+            uint2 pr = i < INL ? s->pair[i] : cold->arena[(u64)off + (i - INL)];      // (plain first: a mask that shows is final)
+            if (pr.y == 0u) pr = key_pair_fresh(s, cold->arena, off, i);
             if (pr.y == 0u) return CMP_INCOMPLETE;
             if (pr.x >= KMASK) return CMP_DIFFERENT;     // (no read of this kernel holds such a locus)
             const u32 key = tag | (pr.x + 1u);
@@ -1519,7 +1520,10 @@ __global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
             bool diff = false, inc = false;
             for (u32 i = tid; i < n && !diff && !inc; i += TPB) {
                 u64* src = reinterpret_cast<u64*>(i < INL ? &sl->pair[i] : A.arena + ((u64)s_off + (i - INL)));
-                const uint2 pr = unpack2(fresh64(src));
+                // (a pair only ever goes from zero to its final value: a plain load that shows a mask shows the pair; only a zero is
+                //  asked again where no cache can answer -- a key of 700 pairs was 700 read-modify-writes per compare)
+                uint2 pr = unpack2(*src);
+                if (pr.y == 0u) pr = unpack2(fresh64(src));
                 if (pr.y == 0u) { inc = true; break; }
                 diff = true;
                 if (pr.x < A.n_loci) {
@@ -2289,99 +2293,134 @@ __global__ void k_clear_slots(Slot* table, const u32* list, u64 n) {
 // members in lower lanes.  Counters of the four waves are added up in wave order afterwards.
 // ---------------------------------------------------------------------------------------------
 constexpr int RS_TPB = 256, RS_ITEMS = 16, RS_TILE = RS_TPB * RS_ITEMS;
-// A workgroup takes RS_TPL tiles one after the other: the (digit, workgroup) counters that every pass scans are a quarter as
-// many as with one tile each (6 M of them for 96 M keys cost 0.64 ms of scan kernels per pass, half of what the scatter itself takes).
-constexpr int RS_TPL = 4;
-constexpr u64 RS_SPAN = (u64)RS_TILE * RS_TPL;
-__global__ __launch_bounds__(RS_TPB) void k_rs_hist(const u64* keys, u64 n, u32 shift, u32 nb, u32* hist) {
-    __shared__ u32 h[256];
-    h[threadIdx.x] = 0;
+constexpr int RS_MAX_PASSES = 8;
+// Round 3: a pass is ONE kernel.  The digit histograms of all passes are taken in one sweep up front (they do not depend on the
+// order of the keys), which gives every pass the first place of each digit; where a TILE's keys of a digit go within that is
+// found while the pass runs, by decoupled look-back: a workgroup takes the next tile (a counter: tiles start in order), publishes
+// its per-digit counts (AGG | count), walks back over the tiles before it adding up their counts until it meets one whose inclusive
+// prefix is known (PFX | prefix), and publishes its own.  One 4-byte word per (tile, digit) carries status and value, written and
+// read with relaxed agent-scope atomics (write-through / L2-bypassing on gfx950: one granule, nothing else to order).  A tile only
+// ever waits for tiles that were started before it, so the walk ends; the polls are bounded all the same.
+// (Before: a histogram kernel, three scan kernels over (digit, workgroup) counters and the scatter per pass -- a third of a pass.)
+constexpr u32 RS_AGG = 1u << 30, RS_PFX = 2u << 30, RS_VAL = (1u << 30) - 1u;
+constexpr u32 RS_SPIN_MAX = 1u << 24;
+struct RsShifts { u32 s[RS_MAX_PASSES]; u32 n; };
+__global__ __launch_bounds__(RS_TPB) void k_rs_hist_all(const u64* keys, u64 n, RsShifts sh, u32* ghist) {
+    __shared__ u32 h[RS_MAX_PASSES][256];
+    for (u32 q = threadIdx.x; q < RS_MAX_PASSES * 256; q += RS_TPB) (&h[0][0])[q] = 0;
     __syncthreads();
-    const u64 t0 = (u64)blockIdx.x * RS_SPAN;
-#pragma unroll 4
-    for (int k = 0; k < RS_ITEMS * RS_TPL; ++k) {
-        const u64 i = t0 + (u64)k * RS_TPB + threadIdx.x;
-        if (i < n) atomicAdd(&h[(u32)(keys[i] >> shift) & 255u], 1u);
+    for (u64 i = blockIdx.x * (u64)RS_TPB + threadIdx.x; i < n; i += (u64)gridDim.x * RS_TPB) {
+        const u64 k = keys[i];
+        for (u32 p = 0; p < sh.n; ++p) atomicAdd(&h[p][(u32)(k >> sh.s[p]) & 255u], 1u);
     }
     __syncthreads();
-    hist[(u64)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+    for (u32 p = 0; p < sh.n; ++p) { const u32 c = h[p][threadIdx.x]; if (c) atomicAdd(&ghist[p * 256 + threadIdx.x], c); }
 }
-__global__ __launch_bounds__(RS_TPB) void k_rs_scatter(const u64* kin, const u32* vin, u64 n, u32 shift, u32 nb, const u32* offs,
-                                                       u64* kout, u32* vout) {
+__global__ __launch_bounds__(256) void k_rs_bases(const u32* ghist, u32 n_passes, u32* base) {      // exclusive scan of every pass's 256 counts
+    __shared__ u32 s_w[4];
+    for (u32 p = 0; p < n_passes; ++p) {
+        const u32 v = ghist[p * 256 + threadIdx.x];
+        const u32 incl = wave_incl_scan(v);
+        if ((threadIdx.x & 63u) == 63u) s_w[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        u32 before = 0;
+        for (u32 k = 0; k < (threadIdx.x >> 6); ++k) before += s_w[k];
+        base[p * 256 + threadIdx.x] = before + incl - v;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(RS_TPB) void k_rs_pass(const u64* kin, const u32* vin, u64 n, u32 shift, const u32* base, u32* desc,
+                                                    u32* ticket, u32* err, u64* kout, u32* vout) {
     // A tile is laid out digit by digit in LDS first and leaves from there: consecutive lanes then write consecutive
-    // addresses of one digit's run (16 elements on average) instead of 64 lanes writing to 64 different runs -- 8- and 4-byte
-    // stores scattered over 256 open lines per workgroup were what a pass cost (2.9 ms for 96 M pairs before, against 0.4 ms of
-    // bytes moved).
+    // addresses of one digit's run (16 elements on average) instead of 64 lanes writing to 64 different runs.
     __shared__ u32 cnt[RS_TPB / 64][256];          // per wave: keys of each digit; then: keys of that digit in the waves before
     __shared__ u32 dstart[256];                    // first place of digit d within the tile
-    __shared__ u32 gbase[256];                     // where this workgroup's next key of digit d goes
+    __shared__ u32 gbase[256];                     // where the tile's first key of digit d goes
     __shared__ u32 s_wsum[RS_TPB / 64];
+    __shared__ u32 s_tile;
     __shared__ u64 skey[RS_TILE];
     __shared__ u32 sval[RS_TILE];
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    gbase[tid] = offs[(u64)tid * nb + blockIdx.x];
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    for (u32 q = tid; q < (RS_TPB / 64) * 256; q += RS_TPB) (&cnt[0][0])[q] = 0;
+    __syncthreads();
+    const u32 tile = s_tile;
+    const u64 t0 = (u64)tile * RS_TILE;
+    if (t0 >= n) return;
+    const u64 w0 = t0 + (u64)w * (RS_TILE / (RS_TPB / 64));
     const u64 lt = (1ull << lane) - 1ull;
-    for (int tile = 0; tile < RS_TPL; ++tile) {
-        const u64 t0 = (u64)blockIdx.x * RS_SPAN + (u64)tile * RS_TILE;
-        if (t0 >= n) break;
-        for (u32 q = tid; q < (RS_TPB / 64) * 256; q += RS_TPB) (&cnt[0][0])[q] = 0;
-        __syncthreads();
-        const u64 w0 = t0 + (u64)w * (RS_TILE / (RS_TPB / 64));
-        u64 key[RS_ITEMS];
-        u32 val[RS_ITEMS], rk[RS_ITEMS];
+    u64 key[RS_ITEMS];
+    u32 val[RS_ITEMS], rk[RS_ITEMS];
 #pragma unroll
-        for (int r = 0; r < RS_ITEMS; ++r) {
-            const u64 i = w0 + (u64)r * 64 + lane;
-            const bool have = i < n;
-            key[r] = have ? kin[i] : 0ull;
-            val[r] = have ? vin[i] : 0u;
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const u64 i = w0 + (u64)r * 64 + lane;
+        const bool have = i < n;
+        key[r] = have ? kin[i] : 0ull;
+        val[r] = have ? vin[i] : 0u;
+        const u32 d = (u32)(key[r] >> shift) & 255u;
+        u64 peers = __ballot(have);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const u64 m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const u32 below = (u32)__popcll(peers & lt);
+        u32 bs = 0;
+        if (have && below == 0u) bs = atomicAdd(&cnt[w][d], (u32)__popcll(peers));
+        bs = __shfl(bs, have ? __ffsll((long long)peers) - 1 : (int)lane);
+        rk[r] = bs + below;
+    }
+    __syncthreads();
+    u32 tot = 0;                                   // digit tid: its keys in the tile, and -- in place of the per-wave counts -- the keys of the waves before
+#pragma unroll
+    for (int k = 0; k < RS_TPB / 64; ++k) { const u32 c = cnt[k][tid]; cnt[k][tid] = tot; tot += c; }
+    // publish the tile's count of digit tid, look back for the keys of that digit in the tiles before, publish the prefix
+    u32* const mine = desc + (u64)tile * 256 + tid;
+    u32 excl = 0;
+    if (tile == 0) {
+        __hip_atomic_store(mine, RS_PFX | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        __hip_atomic_store(mine, RS_AGG | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u32 spins = 0;
+        for (long long t = (long long)tile - 1; t >= 0;) {
+            const u32 v = __hip_atomic_load(desc + (u64)t * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v < RS_AGG) {                        // nothing published there yet
+                if (++spins > RS_SPIN_MAX) { atomicOr(err, 1u); break; }
+                __builtin_amdgcn_s_sleep(1);
+                continue;
+            }
+            excl += v & RS_VAL;
+            if (v >= RS_PFX) break;
+            --t;
+        }
+        __hip_atomic_store(mine, RS_PFX | ((excl + tot) & RS_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    gbase[tid] = base[tid] + excl;
+    {
+        const u32 incl = wave_incl_scan(tot);
+        if (lane == 63) s_wsum[w] = incl;
+        __syncthreads();
+        u32 before = 0;
+        for (u32 k = 0; k < w; ++k) before += s_wsum[k];
+        dstart[tid] = before + incl - tot;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const u64 i = w0 + (u64)r * 64 + lane;
+        if (i < n) {
             const u32 d = (u32)(key[r] >> shift) & 255u;
-            u64 peers = __ballot(have);
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const u64 m = __ballot((d >> b) & 1u);
-                peers &= ((d >> b) & 1u) ? m : ~m;
-            }
-            const u32 below = (u32)__popcll(peers & lt);
-            u32 base = 0;
-            if (have && below == 0u) base = atomicAdd(&cnt[w][d], (u32)__popcll(peers));
-            base = __shfl(base, have ? __ffsll((long long)peers) - 1 : (int)lane);
-            rk[r] = base + below;
+            const u32 lp = dstart[d] + cnt[w][d] + rk[r];
+            skey[lp] = key[r]; sval[lp] = val[r];
         }
-        __syncthreads();
-        u32 tot = 0;                               // digit tid: its keys in the tile, where they start, and -- in place of the per-wave counts -- the keys of the waves before
-#pragma unroll
-        for (int k = 0; k < RS_TPB / 64; ++k) { const u32 c = cnt[k][tid]; cnt[k][tid] = tot; tot += c; }
-        {
-            const u32 incl = wave_incl_scan(tot);
-            if (lane == 63) s_wsum[w] = incl;
-            __syncthreads();
-            u32 before = 0;
-            for (u32 k = 0; k < w; ++k) before += s_wsum[k];
-            dstart[tid] = before + incl - tot;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < RS_ITEMS; ++r) {
-            const u64 i = w0 + (u64)r * 64 + lane;
-            if (i < n) {
-                const u32 d = (u32)(key[r] >> shift) & 255u;
-                const u32 lp = dstart[d] + cnt[w][d] + rk[r];
-                skey[lp] = key[r]; sval[lp] = val[r];
-            }
-        }
-        __syncthreads();
-        const u32 n_tile = (u32)min((u64)RS_TILE, n - t0);
-        for (u32 i = tid; i < n_tile; i += RS_TPB) {
-            const u64 k = skey[i];
-            const u32 d = (u32)(k >> shift) & 255u;
-            const u32 pos = gbase[d] + (i - dstart[d]);
-            kout[pos] = k;
-            vout[pos] = sval[i];
-        }
-        __syncthreads();
-        gbase[tid] += tot;                         // (the next tile's keys of digit tid follow this one's)
-        __syncthreads();
+    }
+    __syncthreads();
+    const u32 n_tile = (u32)min((u64)RS_TILE, n - t0);
+    for (u32 i = tid; i < n_tile; i += RS_TPB) {
+        const u64 k = skey[i];
+        const u32 d = (u32)(k >> shift) & 255u;
+        const u64 pos = (u64)gbase[d] + (i - dstart[d]);
+        if (pos < n) { kout[pos] = k; vout[pos] = sval[i]; }      // (always, unless a look-back gave up: reported through *err)
     }
 }
 __global__ __launch_bounds__(TPB) void k_or_reduce(const u64* keys, u64 n, u64* out) {
@@ -3005,13 +3044,17 @@ int excl_scan(ecb_handle* h, const u32* in, u64 n, u32* out, u64* total) {
 // Stable LSD radix sort of n (key, value) pairs on `st`: only the digits some key has a bit in are sorted on (one OR-reduction
 // and one host wait up front).  k[0] / v[0] hold the input; the result lands in k[*where] / v[*where].  scratch: u32 hist and
 // offs of 256 * tiles each, u32 sums of tiles / 8 + 8, and 8 bytes at d_word.
+// scratch of a sort of n pairs: `hist` = the (tile, digit) words of the look-back, rs_words(n) of them; `offs` = RS_AUX_WORDS words
+// (histograms and first places of all passes, the tile counter, the error word); `sums` unused; d_word = 8 bytes
 struct SortScratch { u32 *hist, *offs, *sums; u64* d_word; };
-inline u64 rs_tiles(u64 n) { return std::max<u64>(1, (n + RS_SPAN - 1) / RS_SPAN); }      // (workgroups of a pass: RS_TPL tiles each)
-inline u64 rs_scan_blocks(u64 n) { return std::max<u64>(1, (256 * rs_tiles(n) + SCAN_BLOCK - 1) / SCAN_BLOCK); }
+inline u64 rs_tiles(u64 n) { return std::max<u64>(1, (n + RS_TILE - 1) / RS_TILE); }
+constexpr u64 RS_AUX_WORDS = 2 * RS_MAX_PASSES * 256 + 64;
+inline u64 rs_words(u64 n) { return std::max<u64>(256 * rs_tiles(n), RS_AUX_WORDS); }
+inline u64 rs_scan_blocks(u64) { return 1; }
 hipError_t radix_sort_pairs64(hipStream_t st, u64* k[2], u32* v[2], u64 n, const SortScratch& sc, int* where, u64 bit_mask = ~0ull) {
     *where = 0;
     if (n < 2) return hipSuccess;
-    if (n >= (1ull << 32)) return hipErrorInvalidValue;
+    if (n >= (1ull << 30)) return hipErrorInvalidValue;          // (a look-back word carries a 30-bit count)
     hipError_t e = hipSuccess;
     u64 ormask = bit_mask;                          // (a caller that names the bits to sort on has no use for the reduction and its host wait)
     if (bit_mask == ~0ull) {
@@ -3020,25 +3063,33 @@ hipError_t radix_sort_pairs64(hipStream_t st, u64* k[2], u32* v[2], u64 n, const
         if ((e = hipMemcpyAsync(&ormask, sc.d_word, 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
     }
-    const u32 nb = (u32)rs_tiles(n);
-    const u64 m = 256ull * nb, sb = rs_scan_blocks(n);
+    RsShifts sh{};
+    for (u32 shift = 0; shift < 64; shift += 8)
+        if ((ormask >> shift) & 255ull) sh.s[sh.n++] = shift;   // (every key has zero in the other digits: already in order)
+    if (!sh.n) return hipSuccess;
+    const u32 nt = (u32)rs_tiles(n);
+    u32 *ghist = sc.offs, *base = sc.offs + RS_MAX_PASSES * 256, *ticket = sc.offs + 2 * RS_MAX_PASSES * 256, *err = ticket + 1;
+    if ((e = hipMemsetAsync(sc.offs, 0, RS_AUX_WORDS * 4, st)) != hipSuccess) return e;
+    k_rs_hist_all<<<(unsigned)std::min<u64>(2048, (n + 16 * RS_TPB - 1) / (16 * RS_TPB)), RS_TPB, 0, st>>>(k[0], n, sh, ghist);
+    k_rs_bases<<<1, 256, 0, st>>>(ghist, sh.n, base);
     int cur = 0;
-    for (u32 shift = 0; shift < 64; shift += 8) {
-        if (!((ormask >> shift) & 255ull)) continue;            // every key has zero here: already in order
-        k_rs_hist<<<nb, RS_TPB, 0, st>>>(k[cur], n, shift, nb, sc.hist);
-        k_scan_sums<<<(unsigned)sb, TPB, 0, st>>>(sc.hist, m, sc.sums);
-        k_scan_top<<<1, TPB, 0, st>>>(sc.sums, sb, sc.d_word);
-        k_scan_apply<<<(unsigned)sb, TPB, 0, st>>>(sc.hist, m, sc.sums, sc.offs);
-        k_rs_scatter<<<nb, RS_TPB, 0, st>>>(k[cur], v[cur], n, shift, nb, sc.offs, k[cur ^ 1], v[cur ^ 1]);
+    for (u32 p = 0; p < sh.n; ++p) {
+        if ((e = hipMemsetAsync(sc.hist, 0, (u64)nt * 256 * 4, st)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(ticket, 0, 4, st)) != hipSuccess) return e;
+        k_rs_pass<<<nt, RS_TPB, 0, st>>>(k[cur], v[cur], n, sh.s[p], base + p * 256, sc.hist, ticket, err, k[cur ^ 1], v[cur ^ 1]);
         cur ^= 1;
     }
     *where = cur;
-    return hipGetLastError();
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    u32 gave_up = 0;                                // (a look-back that ran out of polls leaves the order undefined: never silently)
+    if ((e = hipMemcpyAsync(&gave_up, err, 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    return gave_up ? hipErrorUnknown : hipSuccess;
 }
 int handle_sort(ecb_handle* h, u64* k[2], u32* v[2], u64 n, int* where) {
     SortScratch sc{};
     u64* tot = nullptr;
-    POOL(h, P_RS_HIST, sc.hist, 256 * rs_tiles(n)); POOL(h, P_RS_OFFS, sc.offs, 256 * rs_tiles(n));
+    POOL(h, P_RS_HIST, sc.hist, rs_words(n)); POOL(h, P_RS_OFFS, sc.offs, RS_AUX_WORDS);
     POOL(h, P_RS_SUMS, sc.sums, rs_scan_blocks(n) + 8); POOL(h, P_TOTALS, tot, 8);
     sc.d_word = tot + 6;
     const hipError_t e = radix_sort_pairs64(h->stream, k, v, n, sc, where);
@@ -4097,7 +4148,7 @@ int ecb_ms_filter(ecb_handle* h, uint32_t n_cells, int64_t minimum_count, ecb_ms
         while (sbits < 32 && (1ull << sbits) < S) ++sbits;
         SortScratch ss{};
         u64* tot = nullptr;
-        POOL(h, P_RS_HIST, ss.hist, 256 * rs_tiles(K)); POOL(h, P_RS_OFFS, ss.offs, 256 * rs_tiles(K));
+        POOL(h, P_RS_HIST, ss.hist, rs_words(K)); POOL(h, P_RS_OFFS, ss.offs, RS_AUX_WORDS);
         POOL(h, P_RS_SUMS, ss.sums, rs_scan_blocks(K) + 8); POOL(h, P_TOTALS, tot, 8);
         ss.d_word = tot + 6;
         u64* kk[2] = {k0, k1}; u32* vv[2] = {v0, v1};
@@ -4263,7 +4314,7 @@ extern "C" int ecb_csr_to_hapcsc_device(int device, uint32_t n_ecs, uint32_t n_l
     const u32 nb = (u32)nblk(nnz, CVB);
     u64 *k0 = S.get<u64>(CvScratch::KEYS0, nnz), *k1 = S.get<u64>(CvScratch::KEYS1, nnz);
     u32 *v0 = S.get<u32>(CvScratch::VALS0, nnz), *v1 = S.get<u32>(CvScratch::VALS1, nnz);
-    SortScratch ss{S.get<u32>(CvScratch::HIST, 256 * rs_tiles(nnz)), S.get<u32>(CvScratch::OFFS, 256 * rs_tiles(nnz)),
+    SortScratch ss{S.get<u32>(CvScratch::HIST, rs_words(nnz)), S.get<u32>(CvScratch::OFFS, RS_AUX_WORDS),
                    S.get<u32>(CvScratch::SUMS, rs_scan_blocks(nnz) + 8), words + 3};
     u32 *blk = S.get<u32>(CvScratch::BLK, (u64)n_haps * nb), *scan = S.get<u32>(CvScratch::SCAN, (u64)n_haps * nb);
     u32 *sums2 = S.get<u32>(CvScratch::SUMS2, (u64)n_haps * nb / SCAN_BLOCK + 8), *headval = S.get<u32>(CvScratch::HEAD, (u64)n_haps * n_loci);
@@ -4313,7 +4364,7 @@ extern "C" int ecb_hapcsc_to_csr_device(int device, uint32_t n_ecs, uint32_t n_l
     hipMemcpy(d_hs, hs.data(), (n_haps + 1) * 8, hipMemcpyHostToDevice);
     k_cv_back_expand<<<nblk(total, TPB), TPB, 0, st>>>((const int*)d_cscptr, (const int*)d_cscidx, total, n_loci, n_haps, d_hs, keys, vals);
     {
-        SortScratch ss{sc.get<u32>(256 * rs_tiles(total)), sc.get<u32>(256 * rs_tiles(total)), sc.get<u32>(rs_scan_blocks(total) + 8), sc.get<u64>(1)};
+        SortScratch ss{sc.get<u32>(rs_words(total)), sc.get<u32>(RS_AUX_WORDS), sc.get<u32>(rs_scan_blocks(total) + 8), sc.get<u64>(1)};
         if (!ss.hist || !ss.offs || !ss.sums || !ss.d_word) return fail(nullptr, ECB_ERR_HIP, "out of device memory");
         u64* kk[2] = {keys, keys2}; u32* vv[2] = {vals, vals2};
         int where = 0;
