@@ -151,19 +151,22 @@ def _deal_out(reader, enc, world, builder, track, group_send):
     chunks once and gives every process its own (``bam_utils.py:1174-1304, 646-680``).  The owner of the records being decoded
     moves on from rank r to r + 1 when the decoder is (r + 1) / world of the way through the file, at the next read boundary;
     rank 0 pushes its own share as it goes.  ``group_send(dst, arrays or None)`` ships one batch (``None``: nothing more)."""
-    owner, base = 0, 0                                # the rank being fed, and the run counter of its first read
+    owner, base, dealt = 0, 0, 0                      # the rank being fed, the run counter of its first read, records it has had
+    prev = 0xFFFFFFFF                                 # run counter of the record before the batch
     prog = getattr(reader, "progress", None)
     for t in iter_tuple_batches(reader, enc):
         rid = t["read_id"]
         cols = [rid, t["locus"], t["hapflag"]] + ([t["pos"]] if track else [])
+        before = np.concatenate([np.asarray([prev], dtype=rid.dtype), rid[:-1]])
+        starts = np.flatnonzero((rid != before) & (rid != 0xFFFFFFFF))      # records that start a read
         lo = 0
         while True:
             target = min(world - 1, int(world * prog())) if prog else 0
             cut = len(rid)
-            if target > owner:                       # hand over at the first read that starts in what is left of this batch
-                first = int(rid[lo]) if rid[lo] != 0xFFFFFFFF else -1
-                heads = np.flatnonzero(rid[lo:].astype(np.int64) > first) if first >= 0 else np.flatnonzero(rid[lo:] != 0xFFFFFFFF)
-                cut = lo + int(heads[0]) if len(heads) else len(rid)
+            if target > owner:                       # hand over at the next read that starts (a rank that has had nothing keeps what starts here)
+                cand = starts[starts >= lo] if dealt else starts[starts > lo]
+                if len(cand):
+                    cut = int(cand[0])
             if cut > lo:
                 part = [c[lo:cut] for c in cols]
                 local = np.where(part[0] == 0xFFFFFFFF, np.uint32(0xFFFFFFFF), part[0] - np.uint32(base)).astype(np.uint32)
@@ -171,11 +174,13 @@ def _deal_out(reader, enc, world, builder, track, group_send):
                     builder.push(local, part[1], part[2], part[3] if track else None)
                 else:
                     group_send(owner, [local] + part[1:])
+                dealt += cut - lo
             if cut == len(rid):
                 break
             owner += 1                               # (the read at `cut` is the new owner's read 0)
             base = int(rid[cut])
-            lo = cut
+            lo, dealt = cut, 0
+        prev = int(rid[-1])
     for r in range(1, world):
         group_send(r, None)
 

@@ -605,6 +605,84 @@ def test_sparse_format_round_trip_on_device(golden_dir):
         assert np.array_equal(da2.cpu().numpy(), m.dataA)
 
 
+def test_sparse_format_conversion_refuses_a_malformed_matrix(golden_dir):
+    """``ecb_csr_to_hapcsc_device`` takes matrices of unknown origin (``ec2emase`` of a ``.bin`` from disk): a locus beyond n_loci, a
+    mask that is zero or has a bit beyond the haplotypes, row pointers out of order -- ECB_ERR_CONTRACT, nothing written past a buffer;
+    the count-only first call of the C ABI (NULL outputs) still gives the number of set bits; 31 haplotypes, empty rows and a matrix
+    without non-zeros go through."""
+    import ctypes as C
+    import torch
+    from alntools_amd import bin_utils
+    dev = torch.device("cuda:0")
+    m = bin_utils.ecload(os.path.join(golden_dir, "g2_c1.bin"))
+    good = [np.ascontiguousarray(a).astype(np.int32) for a in (m.indptrA, m.indicesA, m.dataA)]
+    T, H = m.num_loci, m.num_haplotypes
+
+    def run(ip, ix, da, T=T, H=H):
+        return ecb.csr_to_hapcsc(*(torch.from_numpy(a).to(dev) for a in (ip, ix, da)), T, H)
+
+    cptr, cidx = run(*good)
+    bits = int(sum(int(((good[2] >> h) & 1).sum()) for h in range(H)))
+    assert cidx.numel() == bits
+    lib, tot = ecb.load(), C.c_uint64()
+    t = [torch.from_numpy(a).to(dev) for a in good]
+    assert lib.ecb_csr_to_hapcsc_device(0, len(good[0]) - 1, T, H, C.c_void_p(t[0].data_ptr()), C.c_void_p(t[1].data_ptr()),
+                                        C.c_void_p(t[2].data_ptr()), None, None, C.byref(tot)) == 0 and tot.value == bits
+    for what in ("locus", "zero mask", "wide mask", "pointers"):
+        ip, ix, da = (a.copy() for a in good)
+        if what == "locus":
+            ix[len(ix) // 2] = T
+        elif what == "zero mask":
+            da[3] = 0
+        elif what == "wide mask":
+            da[5] = 1 << H
+        else:
+            ip[7], ip[8] = ip[8], ip[7] - 1
+        with pytest.raises(ecb.EcbError) as e:
+            run(ip, ix, da)
+        assert e.value.code == -5, what
+    # 31 haplotypes (bit 30), rows without entries, one column used by every row
+    ip = np.array([0, 2, 2, 3, 3, 5], dtype=np.int32)
+    ix = np.array([1, 4, 4, 0, 4], dtype=np.int32)
+    da = np.array([1 << 30, 3, (1 << 30) | 1, 7, 1 << 29], dtype=np.int32)
+    cptr, cidx = run(ip, ix, da, T=6, H=31)
+    cp, ci = cptr.cpu().numpy(), cidx.cpu().numpy()
+    starts = np.concatenate([[0], np.cumsum(cp[:, -1])])
+    for h, exp in ((30, {1: [0], 4: [2]}), (0, {4: [0, 2], 0: [4]}), (29, {4: [4]}), (5, {})):
+        for tcol in range(6):
+            got = ci[starts[h] + cp[h, tcol]:starts[h] + cp[h, tcol + 1]].tolist()
+            assert got == exp.get(tcol, []), (h, tcol)
+    cptr, cidx = run(np.zeros(4, dtype=np.int32), np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32), T=5, H=2)
+    assert cidx.numel() == 0 and int(cptr.abs().sum()) == 0
+    assert lib.ecb_release_scratch(0) == 0
+
+
+def test_cells_pushed_from_device_memory_equal_cells_pushed_from_the_host():
+    import torch
+    spec = synth.SynthSpec(50_000, 3_000, 4)
+    dev = torch.device("cuda:0")
+    t = synth.generate(spec, 0, spec.n_reads, device=dev)
+    g = np.arange(t["n_reads"], dtype=np.uint64)
+    meta = (((g * np.uint64(2654435761)) % np.uint64(97)) | ((g * np.uint64(3) // np.uint64(t["n_reads"])) << np.uint64(22))).astype(np.uint32)
+    res = []
+    for device_side in (False, True):
+        with ecb.EcBuilder(spec.n_loci, spec.n_haps, multisample=True) as b:
+            b.push_device(t["read_id"], t["locus"], t["hapflag"])
+            if device_side:
+                half = len(meta) // 2                                                 # in two pieces, the second first
+                m_dev = torch.from_numpy(meta.view(np.int32)).to(dev)
+                b.push_cells_device(m_dev[half:], half)
+                b.push_cells_device(m_dev[:half], 0)
+            else:
+                b.push_cells(meta, 0)
+            b.finalize()
+            res.append((b.export_pairs(), b.ms_filter(97, 300)))
+    for k in ("ec", "cell", "file", "count", "first"):
+        assert np.array_equal(res[0][0][k], res[1][0][k]), k
+    for k in ("kept_cells", "indptrA", "indicesA", "dataA", "indptrN", "indicesN", "dataN"):
+        assert np.array_equal(res[0][1][k], res[1][1][k]), k
+
+
 def test_sparse_format_round_trip_at_scale():
     import torch
     spec = synth.SynthSpec(3_000_000, 40_000, 8, paired=True)

@@ -381,3 +381,71 @@ def test_native_multisample_scan_matches_the_python_scan(golden_dir, tmp_path):
     bamio.write_bam(str(tmp_path / "nocell.bam"), refs, [("plain_name", 0, 0, 1, -1, -1)])
     with pytest.raises(ValueError):
         bum.scan_file(bamdec.NativeBamReader(str(tmp_path / "nocell.bam")), None)
+
+
+def test_rank_zero_deals_a_decoded_file_out_in_contiguous_read_ranges():
+    """``bam_utils._deal_out`` (the multi-GPU convert: rank 0 decodes once): whatever the batch boundaries and wherever the decoder's
+    progress crosses r / N, every rank is dealt whole reads, in order, numbered from 0, and the shards put back together are the stream."""
+    from alntools_amd import bam_utils
+
+    rng = np.random.RandomState(5)
+    n_reads = 400
+    lens = rng.randint(1, 9, n_reads)
+    rid = np.repeat(np.arange(n_reads, dtype=np.uint32), lens)
+    rid = np.concatenate([np.full(3, 0xFFFFFFFF, dtype=np.uint32), rid])          # records before the first read (invalid ones)
+    n = len(rid)
+    loc = rng.randint(0, 50, n).astype(np.uint32)
+    hf = rng.randint(0, 1 << 20, n).astype(np.uint32)
+    pos = rng.randint(0, 1000, n).astype(np.int32)
+
+    for world, batch in ((3, 57), (4, 1), (2, n), (5, 7)):
+        class Reader(object):
+            at = 0
+
+            def progress(self):
+                return min(1.0, self.at / float(n))
+
+        rd = Reader()
+
+        def batches(reader, enc):
+            for a in range(0, n, batch):
+                reader.at = min(n, a + batch)
+                yield dict(read_id=rid[a:a + batch], locus=loc[a:a + batch], hapflag=hf[a:a + batch], pos=pos[a:a + batch])
+
+        got = {r: [] for r in range(world)}
+        done = []
+
+        class Builder(object):
+            def push(self, r, l, h, p):
+                got[0].append((np.array(r), np.array(l), np.array(h), np.array(p)))
+
+        def send(dst, arrays):
+            if arrays is None:
+                done.append(dst)
+            else:
+                got[dst].append(tuple(np.array(a) for a in arrays))
+
+        orig = bam_utils.iter_tuple_batches
+        bam_utils.iter_tuple_batches = batches
+        try:
+            bam_utils._deal_out(rd, None, world, Builder(), True, send)
+        finally:
+            bam_utils.iter_tuple_batches = orig
+        assert sorted(done) == list(range(1, world))
+        back, base = [], 0
+        for r in range(world):
+            if not got[r]:
+                continue
+            cols = [np.concatenate([b[i] for b in got[r]]) for i in range(4)]
+            local = cols[0].astype(np.int64)
+            local[cols[0] == 0xFFFFFFFF] = -1
+            if r:
+                assert local[0] == 0 and local.min() == 0                      # a shard starts at a read boundary, its reads numbered from 0
+            assert np.all(np.diff(local) >= 0) and np.all(np.diff(local) <= 1)
+            glob = np.where(local < 0, np.int64(0xFFFFFFFF), local + base).astype(np.uint32)
+            back.append((glob, cols[1], cols[2], cols[3]))
+            base += int(local.max()) + 1
+        for i, exp in enumerate((rid, loc, hf, pos)):
+            assert np.array_equal(np.concatenate([b[i] for b in back]), exp), (world, batch, i)
+        if batch < n // world:                                                   # (progress moves while the file is read: more than one rank gets reads)
+            assert sum(1 for r in range(world) if got[r]) >= 2
