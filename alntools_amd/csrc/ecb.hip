@@ -4284,7 +4284,7 @@ extern "C" int ecb_release_scratch(int device) {
 extern "C" int ecb_csr_to_hapcsc_device(int device, uint32_t n_ecs, uint32_t n_loci, uint32_t n_haps, const void* d_indptr,
                                         const void* d_indices, const void* d_data, void* d_cscptr, void* d_cscidx,
                                         uint64_t* total) {
-    if (!d_indptr || !d_indices || !d_data || !total || !n_ecs || !n_loci || !n_haps || n_haps > 31) return fail(nullptr, ECB_ERR_ARG, "bad argument");
+    if (!d_indptr || !total || !n_ecs || !n_loci || !n_haps || n_haps > 31) return fail(nullptr, ECB_ERR_ARG, "bad argument");
     if ((u64)n_haps * n_loci >= (1ull << 32)) return fail(nullptr, ECB_ERR_LIMIT, "haplotypes x loci does not fit 32 bits");
     if (device < 0 || device >= CV_MAX_DEV || hipSetDevice(device) != hipSuccess) return fail(nullptr, ECB_ERR_NO_DEVICE, "no such device");
     hipStream_t st = nullptr;
@@ -4292,6 +4292,7 @@ extern "C" int ecb_csr_to_hapcsc_device(int device, uint32_t n_ecs, uint32_t n_l
     if (hipMemcpy(&nnz_i, (const int*)d_indptr + n_ecs, 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "read nnz");
     if (nnz_i < 0) return fail(nullptr, ECB_ERR_CONTRACT, "malformed CSR: negative row pointer");
     const u64 nnz = (u64)nnz_i;
+    if (nnz && (!d_indices || !d_data)) return fail(nullptr, ECB_ERR_ARG, "bad argument");       // (a matrix without non-zeros has no arrays to point at)
     std::lock_guard<std::mutex> guard(g_cv_lock);
     CvScratch& S = g_cv[device];
     u64* words = S.get<u64>(CvScratch::WORDS, 4);                  // [0] set bits, [1] the scan's total, [2] error bits
