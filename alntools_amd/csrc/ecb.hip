@@ -103,6 +103,7 @@ struct Counters {
     u64 arena_reg[ARENA_REGIONS];    // next free pair of every arena region
     u64 next_slice;                  // k_stream: next unclaimed slice of the batch (zeroed per launch)
     u64 n_mismatch;                  // exactness pass (ecb_verify_device): reads whose set differs from their EC's key
+    u32 last_rid, pad_;              // read_id of the last record of the batch k_sum_counts closed (ecb_hint_reads: the host learns it here)
 };
 
 // The key arena is cut into equal regions with a cursor each; a wave allocates from the region its index picks and moves
@@ -1090,12 +1091,14 @@ __global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream
 }
 
 // resume points of a fresh batch: slice b starts (and has counted its records up to) record b * chunk
-__global__ void k_init_resume(u64* resume, u64 slices, u64 chunk) {
+// (ctr: the per-launch words of the batch's first launch are zeroed here too -- three memsets fewer in front of k_stream)
+__global__ void k_init_resume(u64* resume, u64 slices, u64 chunk, Counters* ctr = nullptr) {
     const u64 b = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (b < slices) { resume[2 * b] = b * chunk; resume[2 * b + 1] = b * chunk; }
+    if (b == 0 && ctr) { ctr->n_queue = 0; ctr->full = 0; ctr->next_slice = 0; }
 }
 
-__global__ __launch_bounds__(1024) void k_sum_counts(const u32* wave_counts, u64 waves, Counters* ctr, u32 verify, u64 offered) {
+__global__ __launch_bounds__(1024) void k_sum_counts(const u32* wave_counts, u64 waves, Counters* ctr, u32 verify, u64 offered, const u32* d_last = nullptr) {
     __shared__ u64 s[3][16];
     u64 a = 0, v = 0, e = 0;
     for (u64 i = threadIdx.x; i < waves; i += 1024) { a += wave_counts[3 * i]; v += wave_counts[3 * i + 1]; e += wave_counts[3 * i + 2]; }
@@ -1108,6 +1111,7 @@ __global__ __launch_bounds__(1024) void k_sum_counts(const u32* wave_counts, u64
         for (int k = 0; k < 16; ++k) { a += s[0][k]; v += s[1][k]; e += s[2][k]; }
         if (verify) ctr->n_mismatch += e;                  // the exactness pass counts differing reads, and recounts nothing
         else { ctr->all += a + offered; ctr->valid += v; ctr->n_ecs += e; }
+        if (d_last) ctr->last_rid = *d_last;
     }
 }
 
@@ -2627,6 +2631,7 @@ struct ecb_handle {
     u32 prev_rid = 0xFFFFFFFFu;       // read_id of the last record pushed so far
     u64 n_reads = 0;
     u64 reads_hi = 0;                 // read_slot entries [0, reads_hi) may be set (n_reads, or more mid-batch)
+    u64 reads_hint = 0;               // ecb_hint_reads: the stream holds at most this many reads (0 = not said)
     u64 extra_all = 0, extra_valid = 0, extra_reads = 0;   // counters merged in from other ranks
     u64 n_mismatch = 0;               // ECB_F_VERIFY: reads the exactness pass found in a wrong EC, over all pushes
 
@@ -2883,11 +2888,18 @@ int verify_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d
 // one batch of whole reads, device-resident
 int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf, const int* d_pos, u64 n) {
     if (n == 0) return ECB_OK;
+    // How many reads the stream holds after this batch: the read id of its last record, fetched before anything is launched -- or,
+    // when the caller has said how many reads the whole stream holds at most (ecb_hint_reads), that bound now and the
+    // exact number with the counters, at the batch's one wait.
+    const bool hinted = h->reads_hint != 0;
     u32 last_rid = 0;
-    HIPCHK(h, hipMemcpyAsync(&last_rid, d_rid + (n - 1), sizeof(u32), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    const u64 reads_after = (u64)(u32)(last_rid + 1u);
-    if (reads_after < h->n_reads) return fail(h, ECB_ERR_CONTRACT, "read_id went backwards across pushes");
+    u64 reads_after = std::max<u64>(h->reads_hint, h->n_reads);
+    if (!hinted) {
+        HIPCHK(h, hipMemcpyAsync(&last_rid, d_rid + (n - 1), sizeof(u32), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        reads_after = (u64)(u32)(last_rid + 1u);
+        if (reads_after < h->n_reads) return fail(h, ECB_ERR_CONTRACT, "read_id went backwards across pushes");
+    }
     int rc = ensure_read_slot(h, reads_after);
     if (rc != ECB_OK) return rc;
     h->reads_hi = reads_after;
@@ -2899,7 +2911,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     const u64 waves = P.slices, chunk = P.chunk, blocks = P.blocks, pwaves = P.pwaves;
     u64* d_resume = nullptr;
     POOL(h, P_RESUME, d_resume, 2 * waves);
-    k_init_resume<<<nblk(waves, TPB), TPB, 0, h->stream>>>(d_resume, waves, chunk);
+    k_init_resume<<<nblk(waves, TPB), TPB, 0, h->stream>>>(d_resume, waves, chunk, h->ctr);
     u32* d_wcounts = nullptr;
     POOL(h, P_WCOUNTS, d_wcounts, 3 * pwaves);
     if (h->wave_arena_n < pwaves) {                 // (only ever grows to the resident wave count; zero = nothing reserved)
@@ -2925,17 +2937,18 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
                  getenv("ECB_ABLATE") ? (u32)atoi(getenv("ECB_ABLATE")) : 0u};
     h->ctr_synced = false;
     u64 offered = n;                                    // records offered to the filter (bam_utils.py:261): all of the batch
-    for (;;) {
-        HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));   // per launch
-        HIPCHK(h, hipMemsetAsync(&h->ctr->full, 0, sizeof(u32), h->stream));
-        HIPCHK(h, hipMemsetAsync(&h->ctr->next_slice, 0, sizeof(u64), h->stream));
-        a.table = h->table; a.cap_mask = h->cap - 1;
-        HIPCHK(h, hipMemsetAsync(d_wcounts, 0, 3 * pwaves * sizeof(u32), h->stream));
+    for (u32 launch = 0;; ++launch) {
+        if (launch) {                                   // per launch (the first one's: k_init_resume)
+            HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));
+            HIPCHK(h, hipMemsetAsync(&h->ctr->full, 0, sizeof(u32), h->stream));
+            HIPCHK(h, hipMemsetAsync(&h->ctr->next_slice, 0, sizeof(u64), h->stream));
+        }
+        a.table = h->table; a.cap_mask = h->cap - 1;     // (d_wcounts: every wave of the launch stores its three words when it ends)
         if (h->prof) hipEventRecord(h->ev0, h->stream);
         if (h->rng) k_stream<false, true><<<(unsigned)blocks, TPB, 0, h->stream>>>(a);     // ... with the range update fused in
         else k_stream<false><<<(unsigned)blocks, TPB, 0, h->stream>>>(a);
         if (h->prof) hipEventRecord(h->ev1, h->stream);
-        k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, pwaves, h->ctr, 0u, offered);
+        k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, pwaves, h->ctr, 0u, offered, d_rid + (n - 1));
         offered = 0;                                    // (a relaunch after a park continues the same batch)
         HIPCHK(h, hipGetLastError());
         rc = sync_counters(h);
@@ -2972,6 +2985,11 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
         if (rc != ECB_OK) return rc;
         h->n_mismatch += bad;
         if (bad) return fail(h, ECB_ERR_VERIFY, "exactness pass: %llu read(s) of this batch sit in an EC whose key is not their target set", (unsigned long long)bad);
+    }
+    if (hinted) {
+        last_rid = h->hctr.last_rid;
+        reads_after = (u64)(u32)(last_rid + 1u);
+        if (reads_after < h->n_reads) return fail(h, ECB_ERR_CONTRACT, "read_id went backwards across pushes");
     }
     h->prev_rid = last_rid;
     h->n_reads = reads_after;
@@ -3398,7 +3416,9 @@ int ecb_reset(ecb_handle* h) {
     }
     { int rc_ = clear_counters(h); if (rc_ != ECB_OK) return rc_; }
     if (h->wave_arena) HIPCHK(h, hipMemsetAsync(h->wave_arena, 0, 2 * h->wave_arena_n * sizeof(u64), h->stream));
-    if (h->read_slot && h->reads_hi) HIPCHK(h, hipMemsetAsync(h->read_slot, 0xFF, h->reads_hi * sizeof(u32), h->stream));
+    // (read_slot keeps the last run's slot ids: every read of the next stream has its entry written by k_stream or k_slow
+    //  before anything reads it -- k_count, the exports and the exactness pass look at reads [0, n_reads) of a stream that was
+    //  looked up without an error -- and entries of a fresh allocation are PENDING.  384 MB of stores per run at config 3.)
     if (h->rng) {
         const u64 ns = (u64)h->cfg.n_loci * h->cfg.n_haplotypes;
         k_fill_minmax<<<nblk(ns, TPB), TPB, 0, h->stream>>>(h->rng, ns);
@@ -3410,6 +3430,13 @@ int ecb_reset(ecb_handle* h) {
     h->finalized = false; h->counted = false; h->adopted = false; h->sizes = ecb_sizes{}; h->n_list = 0;
     h->list_counted = false; h->list_from_counts = false; h->assembled = false;
     h->n_mismatch = 0; h->ms_filtered = false;
+    return ECB_OK;
+}
+
+int ecb_hint_reads(ecb_handle* h, uint64_t max_reads) {
+    if (!h) return ECB_ERR_ARG;
+    if (max_reads >= (1ull << 32)) return fail(h, ECB_ERR_LIMIT, "more than 2^32 - 1 reads");
+    h->reads_hint = max_reads;
     return ECB_OK;
 }
 

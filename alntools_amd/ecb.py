@@ -25,7 +25,7 @@ FLAG_NEXT_POS_NEG = 0x2000
 
 #: every symbol include/ecb.h declares
 SYMBOLS = ("ecb_abi_version", "ecb_device_count", "ecb_create", "ecb_destroy", "ecb_reset", "ecb_last_error",
-           "ecb_push", "ecb_push_device", "ecb_push_cells", "ecb_push_cells_device", "ecb_verify_device", "ecb_finalize", "ecb_export",
+           "ecb_push", "ecb_push_device", "ecb_hint_reads", "ecb_push_cells", "ecb_push_cells_device", "ecb_verify_device", "ecb_finalize", "ecb_export",
            "ecb_export_device", "ecb_export_ranges", "ecb_export_range_minmax", "ecb_export_pairs", "ecb_ms_filter", "ecb_ms_export",
            "ecb_export_read_ec", "ecb_table_sizes",
            "ecb_table_export_device", "ecb_table_merge_device", "ecb_table_export_parts_device",
@@ -89,6 +89,7 @@ def load():
     lib.ecb_last_error.restype = C.c_char_p
     lib.ecb_push.argtypes = [vp, vp, vp, vp, vp, sz]
     lib.ecb_push_device.argtypes = [vp, vp, vp, vp, vp, sz]
+    lib.ecb_hint_reads.argtypes = [vp, u64]
     lib.ecb_push_cells.argtypes = [vp, vp, u64, sz]
     lib.ecb_push_cells_device.argtypes = [vp, vp, u64, sz]
     lib.ecb_verify_device.argtypes = [vp, vp, vp, vp, sz, C.POINTER(u64), C.POINTER(u64)]
@@ -236,6 +237,11 @@ class EcBuilder(object):
                 raise ValueError("device tuple streams must be contiguous 4-byte CUDA tensors of equal length")
         self._chk(self._lib.ecb_push_device(self._h, _dev_ptr(read_id), _dev_ptr(locus), _dev_ptr(hapflag),
                                             _dev_ptr(pos), n))
+
+    def hint_reads(self, max_reads):
+        """The stream holds at most ``max_reads`` reads: ``push_device`` then waits for the device once per call, not twice
+        (``ecb_hint_reads``; running past the bound is a contract error; 0 takes the bound back)."""
+        self._chk(self._lib.ecb_hint_reads(self._h, int(max_reads)))
 
     def verify_device(self, read_id, locus, hapflag):
         """Independent exactness pass over the device-resident stream that was pushed: -> (reads whose target set differs

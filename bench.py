@@ -265,6 +265,8 @@ def main():
     # (a shard of 1/4 or 1/8 of config 3 still founds 2.3 - 3 M of its 3.7 M ECs: 2^23 slots keep it under half full)
     ec_cap = 1 << int(os.environ.get("ECB_EC_CAP_LOG2", ("23" if world >= 4 else "24") if args.workload in ("c3", "c3h", "c4", "c4h") else "22"))
     b = ecb.EcBuilder(T, H, device=local, ec_capacity=ec_cap, arena_capacity=1 << 26)
+    hint = 0 if os.environ.get("ECB_NO_HINT") else st["reads"]      # (a caller that knows how many reads its stream holds says so: one host wait per push)
+    b.hint_reads(hint)
     eng = ecdist.GpuEngine(b, device)
     if rehearsal:
         eng = ecdist.HostStagedEngine(eng)
@@ -310,6 +312,7 @@ def main():
         del g, u, cell, inv
         b.close()
         b = ecb.EcBuilder(T, H, device=local, ec_capacity=ec_cap, arena_capacity=1 << 26, multisample=True)
+        b.hint_reads(hint)
     per_range = os.environ.get("ECB_DIST_FINALIZE", "ranges") != "root"      # ("root": the merged tables go to rank 0, which finalizes alone)
 
     def step():

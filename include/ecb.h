@@ -108,6 +108,11 @@ int ecb_push(ecb_handle* h, const uint32_t* read_id, const uint32_t* locus, cons
              const int32_t* pos, size_t n);
 int ecb_push_device(ecb_handle* h, const void* d_read_id, const void* d_locus, const void* d_hapflag,
                     const void* d_pos, size_t n);
+/* Optional: the whole stream holds at most max_reads reads (reads with a record that passes the filter).  With the bound
+ * known, a push of device-resident tuples sizes its per-read state from it and no longer asks the device for the batch's
+ * last read id before it launches anything: one host wait per push instead of two.  A stream that runs past the bound is
+ * ECB_ERR_CONTRACT.  Kept across ecb_reset; 0 takes it back. */
+int ecb_hint_reads(ecb_handle* h, uint64_t max_reads);
 
 /* Multisample only (ECB_F_MULTISAMPLE): per read, in read order, for reads [first_read, first_read + n):
  *   meta = cell id (bits 0-21; dictionary-encoded by the host from the read name, bam_utils_multisample.py:270-280)

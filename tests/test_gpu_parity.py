@@ -120,6 +120,56 @@ def test_device_resident_push_and_table_growth():
     _check(out, sizes, _expect(t, spec.n_loci, spec.n_haps))
 
 
+def test_reads_bound_given_up_front_and_a_handle_reused_for_a_shorter_stream():
+    """``ecb_hint_reads``: with the stream's read count bounded up front a device push does not ask the device for the batch's last
+    read id; the result is the same, in one batch or several, with a table that has to grow, on a handle that held a LONGER
+    stream before (its per-read slot ids are not cleared by ``reset``: every read of the new stream must overwrite its own),
+    and a stream that runs past the bound is a contract error, not a write past the per-read array."""
+    import torch
+    dev = torch.device("cuda:0")
+    big = synth.SynthSpec(50000, 3000, 8)
+    small = synth.SynthSpec(21000, 700, 4, paired=True)
+    tb, ts = synth.generate(big, 0, big.n_reads), synth.generate(small, 0, small.n_reads)
+    db = {k: torch.from_numpy(tb[k].view(np.int32)).to(dev) for k in ("read_id", "locus", "hapflag")}
+    exp_b = _expect(tb, big.n_loci, big.n_haps)
+    n_reads_b = int(tb["read_id"][-1]) + 1
+    with ecb.EcBuilder(big.n_loci, big.n_haps, ec_capacity=4096) as b:       # (grows while the hinted stream is pushed)
+        b.hint_reads(n_reads_b)
+        cuts = [0]
+        for frac in (0.3, 0.55, 1.0):                                        # whole reads per batch
+            c = int(len(tb["read_id"]) * frac)
+            while c < len(tb["read_id"]) and tb["read_id"][c] == tb["read_id"][c - 1]:
+                c += 1
+            cuts.append(c)
+        for a, e in zip(cuts[:-1], cuts[1:]):
+            b.push_device(db["read_id"][a:e].clone(), db["locus"][a:e].clone(), db["hapflag"][a:e].clone())
+        s = b.finalize()
+        _check(b.export(), s, exp_b)
+        # the same handle, a shorter stream of another shape (fewer loci: the builder is per (n_loci, n_haps), so a second one)
+        b.reset()
+        cut = cuts[1]
+        b.hint_reads(int(tb["read_id"][cut - 1]) + 1)
+        b.push_device(db["read_id"][:cut].clone(), db["locus"][:cut].clone(), db["hapflag"][:cut].clone())
+        s = b.finalize()
+        part = {k: tb[k][:cut] for k in ("read_id", "locus", "hapflag")}
+        exp_p = orc.ec_from_tuples(part["read_id"], part["locus"], part["hapflag"], big.n_loci, big.n_haps)
+        _check(b.export(), s, exp_p)
+        got = b.export_read_ec()
+        assert len(got) == int(tb["read_id"][cut - 1]) + 1
+        # ... and without the bound again (the handle asks the device, as before)
+        b.reset()
+        b.hint_reads(0)
+        b.push_device(db["read_id"], db["locus"], db["hapflag"])
+        s = b.finalize()
+        _check(b.export(), s, exp_b)
+    ds = {k: torch.from_numpy(ts[k].view(np.int32)).to(dev) for k in ("read_id", "locus", "hapflag")}
+    with ecb.EcBuilder(small.n_loci, small.n_haps) as b:
+        b.hint_reads(int(ts["read_id"][-1]) + 1 - 5)                         # five reads too few
+        with pytest.raises(ecb.EcbError) as e:
+            b.push_device(ds["read_id"], ds["locus"], ds["hapflag"])
+        assert e.value.code == -5                      # ECB_ERR_CONTRACT
+
+
 def test_table_of_2_to_the_27_slots_counts_like_a_small_one():
     """Beyond 2^26 slots k_count's ranges hold 2^14 / 2^15 slots each (LDS counters as dynamic shared memory): same results."""
     import torch
