@@ -2139,6 +2139,185 @@ __device__ __forceinline__ u64 lower_bound_u64(const u64* a, u64 n, u64 v) {
     while (lo < hi) { const u64 m = (lo + hi) >> 1; if (a[m] < v) lo = m + 1; else hi = m; }
     return lo;
 }
+// ---- per-haplotype CSC -> CSR(bitmask): a union per column, then a transposition ----------------------------------------------
+//   k_cvu_colsum    S[l] = sum over haplotypes of their column pointers (S[l + 1] - S[l] row indices name column l); the pointers
+//                   are checked here
+//   k_cvu_pieces    a column is one piece of work, or -- above CVU_PIECE row indices -- several: equal ranges of EC ids
+//   k_cvu_items / k_cvu_bounds   the list of pieces; where every haplotype's list of the column enters a piece's EC range
+//                   (binary searches: lists of a column that is cut must be ascending, as scipy and the forward conversion write them)
+//   k_cvu_union     one workgroup per piece: the piece's row indices from every haplotype's list go into an LDS hash
+//                   {EC -> haplotype mask}; within a piece no order is needed and an EC listed twice ORs into the same bit.
+//                   First launch: distinct ECs per column; second, behind a scan of those: the entries go out column by column as
+//                   (EC << 32 | locus, mask) -- within a column in any order --
+//   then a stable sort on the EC digits alone makes rows with ascending loci, and k_cvb_out / k_cvb_rowptr write the CSR.
+// A row index outside its piece's EC range (a cut column whose lists are not ascending) is noticed: the caller then takes the
+// general, sort-everything path below.  A piece with more row indices than the table takes (EC ids bunched in one range) goes
+// entry by entry: the first haplotype's copy of an EC gathers the mask by binary searches in the other haplotypes' lists.
+constexpr u32 CVU_PIECE = 1536;     // row indices a piece aims at
+constexpr u32 CVU_MAX = 3072;       // row indices the LDS table takes
+constexpr u32 CVU_TSZ = 4096;       // table slots (a power of two; small pieces use a power-of-two part of it): 32 KB, four workgroups per CU
+constexpr u32 CVU_TPB = 512;
+constexpr u32 CVU_K = CVU_MAX / CVU_TPB;      // row indices per thread, all loaded before the first goes into the table
+constexpr u32 CVB_ERR_PTR = 1u, CVB_ERR_EC = 2u, CVB_ERR_ORDER = 4u;
+__global__ void k_cvb_last(const int* cscptr, u32 n_loci, u32 n_haps, int* last) {
+    const u32 h = threadIdx.x;
+    if (h < n_haps) last[h] = cscptr[(u64)h * (n_loci + 1) + n_loci];
+}
+__global__ void k_cvu_colsum(const int* cscptr, u32 n_loci, u32 n_haps, u32* S, u32* err) {
+    const u64 l = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (l > n_loci) return;
+    u32 sum = 0, bad = 0;
+    for (u32 h = 0; h < n_haps; ++h) {
+        const int* ptr = cscptr + (u64)h * (n_loci + 1);
+        const int v = ptr[l];
+        if (v < 0 || (l == 0 && v != 0) || (l > 0 && ptr[l - 1] > v)) bad = CVB_ERR_PTR;
+        sum += (u32)v;
+    }
+    S[l] = sum;
+    if (bad) atomicOr(err, bad);
+}
+__global__ void k_cvu_pieces(const u32* S, u32 n_loci, u32* pieces) {
+    const u64 l = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (l >= n_loci) return;
+    const u32 n = S[l + 1] - S[l];
+    pieces[l] = n <= CVU_PIECE + CVU_PIECE / 2 ? (n ? 1u : 0u) : (n + CVU_PIECE - 1u) / CVU_PIECE;
+}
+__global__ void k_cvu_items(const u32* pieces, const u32* pbase, u32 n_loci, u32* item_col) {
+    const u64 l = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (l >= n_loci) return;
+    const u32 n = pieces[l], at = pbase[l];
+    for (u32 r = 0; r < n; ++r) item_col[at + r] = (u32)l;
+}
+// EC range of piece r of a column cut into np pieces: [r * w, (r + 1) * w), w = ceil(n_ecs / np)
+__device__ __forceinline__ u32 cvu_width(u32 n_ecs, u32 np) { return (u32)(((u64)n_ecs + np - 1u) / np); }
+__global__ void k_cvu_bounds(const int* cscptr, const int* cscidx, const u64* hs, const u32* pieces, const u32* pbase, const u32* item_col,
+                             u32 n_items, u32 n_loci, u32 n_haps, u32 n_ecs, u32* bnd) {
+    const u64 t = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (t >= (u64)n_items * n_haps) return;
+    const u32 i = (u32)(t / n_haps), h = (u32)(t % n_haps);
+    const u32 l = item_col[i], np = pieces[l], r = i - pbase[l];
+    const int* ptr = cscptr + (u64)h * (n_loci + 1);
+    const u64 nh = hs[h + 1] - hs[h];
+    u64 a = min((u64)(u32)ptr[l], nh), b = min((u64)(u32)ptr[l + 1], nh);
+    if (r) {                                                 // first row index of the list at or above the piece's first EC
+        const u64 lo = (u64)r * cvu_width(n_ecs, np);
+        const int* base = cscidx + hs[h];
+        while (a < b) { const u64 m = a + ((b - a) >> 1); if ((u64)(u32)base[m] < lo) a = m + 1; else b = m; }
+    }
+    bnd[t] = (u32)a;
+}
+// is EC e in haplotype hh's list of column l?  (lists ascending; a list that is not is reported and the answer discarded)
+__device__ __forceinline__ bool cvb_contains(const int* cscptr, const int* cscidx, const u64* hs, u32 n_loci, u32 hh, u32 l, u32 e) {
+    const int* p = cscptr + (u64)hh * (n_loci + 1);
+    const u64 nh = hs[hh + 1] - hs[hh];
+    u64 a = min((u64)(u32)p[l], nh), b = min((u64)(u32)p[l + 1], nh);
+    const int* base = cscidx + hs[hh];
+    while (a < b) { const u64 m = a + ((b - a) >> 1); const u32 v = (u32)base[m]; if (v < e) a = m + 1; else if (v > e) b = m; else return true; }
+    return false;
+}
+template <bool EMIT>
+__global__ __launch_bounds__(CVU_TPB) void k_cvu_union(const int* cscptr, const int* cscidx, const u64* hs, const u32* pieces, const u32* pbase,
+                                                       const u32* item_col, const u32* bnd, u32 n_items, u32 n_loci, u32 n_haps, u32 n_ecs,
+                                                       u32* colcnt, const u32* colbase, u32* colcur, u64 nnz, u64* keys, u32* vals, u32* err) {
+    __shared__ u32 tkey[CVU_TSZ];
+    __shared__ u32 tmask[CVU_TSZ];
+    __shared__ u32 seg[64];                                  // per haplotype: first and one-past-last row index of the piece (within the haplotype)
+    __shared__ u32 segp[33];                                 // ... and how many row indices the haplotypes before it bring
+    __shared__ u64 shs[32];
+    __shared__ u32 s_n, s_base;
+    const u32 i = blockIdx.x;
+    const u32 l = item_col[i], np = pieces[l], r = i - pbase[l];
+    const u32 w = cvu_width(n_ecs, np);
+    const u32 e_lo = (u32)min((u64)r * w, (u64)n_ecs), e_hi = r + 1u == np ? n_ecs : (u32)min((u64)(r + 1u) * w, (u64)n_ecs);
+    if (threadIdx.x < n_haps) {
+        const u32 h = threadIdx.x;
+        const u64 h0 = hs[h], nh = hs[h + 1] - h0;
+        shs[h] = h0;
+        seg[2 * h] = bnd[(u64)i * n_haps + h];
+        seg[2 * h + 1] = r + 1u < np ? bnd[(u64)(i + 1u) * n_haps + h] : (u32)min((u64)(u32)cscptr[(u64)h * (n_loci + 1) + l + 1], nh);
+    }
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) { u32 run = 0; for (u32 h = 0; h < n_haps; ++h) { segp[h] = run; run += seg[2 * h + 1] - seg[2 * h]; } segp[n_haps] = run; }
+    __syncthreads();
+    const u32 tot = segp[n_haps];
+    if (tot == 0) return;
+    if (tot > CVU_MAX) {
+        // entry by entry: the first haplotype's copy of an EC speaks for it
+        for (u32 h = 0; h < n_haps; ++h) {
+            const int* base = cscidx + hs[h];
+            for (u32 j = seg[2 * h] + threadIdx.x; j < seg[2 * h + 1]; j += CVU_TPB) {
+                const u32 e = (u32)base[j];
+                u32 bad = e >= n_ecs ? CVB_ERR_EC : 0u;
+                if (e < e_lo || e >= e_hi || (j > seg[2 * h] && (u32)base[j - 1] >= e)) bad |= CVB_ERR_ORDER;
+                if (bad) { atomicOr(err, bad); continue; }
+                bool first = true;
+                for (u32 hh = h; hh-- > 0 && first;) first = !cvb_contains(cscptr, cscidx, hs, n_loci, hh, l, e);
+                if (!first) continue;
+                if (!EMIT) { atomicAdd(&colcnt[l], 1u); continue; }
+                u32 mask = 1u << h;
+                for (u32 hh = h + 1; hh < n_haps; ++hh) if (cvb_contains(cscptr, cscidx, hs, n_loci, hh, l, e)) mask |= 1u << hh;
+                const u64 pos = (u64)colbase[l] + atomicAdd(&colcur[l], 1u);
+                if (pos < nnz) { keys[pos] = ((u64)e << 32) | l; vals[pos] = mask; }
+            }
+        }
+        return;
+    }
+    u32 tsz = 64;                                            // slots in use: a power of two, at least 4/3 of the row indices
+    while (tsz < tot + tot / 3u + 1u) tsz <<= 1;
+    // all of a thread's row indices are fetched before the first is inserted (their loads overlap), haplotype after haplotype in one index space
+    u32 ev[CVU_K], hv[CVU_K];
+#pragma unroll
+    for (u32 k = 0; k < CVU_K; ++k) {
+        const u32 u = threadIdx.x + k * CVU_TPB;
+        hv[k] = 0xFFFFFFFFu; ev[k] = 0;
+        if (u < tot) {
+            u32 h = 0;
+            while (segp[h + 1] <= u) ++h;
+            hv[k] = h;
+            ev[k] = (u32)cscidx[shs[h] + seg[2 * h] + (u - segp[h])];
+        }
+    }
+    for (u32 q = threadIdx.x; q < tsz; q += CVU_TPB) { tkey[q] = 0xFFFFFFFFu; tmask[q] = 0u; }      // (while the loads are under way)
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < CVU_K; ++k) {
+        if (hv[k] == 0xFFFFFFFFu) continue;
+        const u32 e = ev[k];                                 // (never 0xFFFFFFFF once it is below n_ecs)
+        if (e >= n_ecs) { atomicOr(err, CVB_ERR_EC); continue; }
+        if (e < e_lo || e >= e_hi) { atomicOr(err, CVB_ERR_ORDER); continue; }
+        u32 q = (e * 0x9E3779B1u) >> 7 & (tsz - 1u);
+        for (u32 it = 0; it < tsz; ++it) {                   // (fewer keys than slots: a free one is always found)
+            const u32 old = atomicCAS(&tkey[q], 0xFFFFFFFFu, e);
+            if (old == 0xFFFFFFFFu || old == e) { atomicOr(&tmask[q], 1u << hv[k]); break; }
+            q = (q + 1u) & (tsz - 1u);
+        }
+    }
+    __syncthreads();
+    // the distinct ECs of the piece: counted, then (EMIT) given consecutive places in the column's stretch of the output
+    u32 mine = 0;
+    for (u32 q = threadIdx.x; q < tsz; q += CVU_TPB) mine += tkey[q] != 0xFFFFFFFFu ? 1u : 0u;
+    const u32 at = mine ? atomicAdd(&s_n, mine) : 0u;
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) { if (EMIT) s_base = colbase[l] + atomicAdd(&colcur[l], s_n); else atomicAdd(&colcnt[l], s_n); }
+    if (!EMIT) return;
+    __syncthreads();
+    u32 rnk = at;
+    for (u32 q = threadIdx.x; q < tsz; q += CVU_TPB) {
+        const u32 e = tkey[q];
+        if (e == 0xFFFFFFFFu) continue;
+        const u64 pos = (u64)s_base + rnk++;
+        if (pos < nnz) { keys[pos] = ((u64)e << 32) | l; vals[pos] = tmask[q]; }
+    }
+}
+__global__ void k_cvb_out(const u64* keys, const u32* vals, u64 nnz, int* indices, int* data) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < nnz) { indices[i] = (int)(u32)keys[i]; data[i] = (int)vals[i]; }
+}
+__global__ void k_cvb_rowptr(const u64* keys, u64 nnz, u32 n_ecs, int* indptr) {
+    const u64 r = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (r <= n_ecs) indptr[r] = (int)lower_bound_u64(keys, nnz, r << 32);
+}
 __global__ void k_cv_back_expand(const int* cscptr, const int* cscidx, u64 total, u32 n_loci, u32 n_haps, const u64* hap_start,
                                  u64* keys, u32* vals) {
     const u64 g = blockIdx.x * (u64)blockDim.x + threadIdx.x;
@@ -4370,21 +4549,10 @@ extern "C" int ecb_csr_to_hapcsc_device(int device, uint32_t n_ecs, uint32_t n_l
     return ECB_OK;
 }
 
-extern "C" int ecb_hapcsc_to_csr_device(int device, uint32_t n_ecs, uint32_t n_loci, uint32_t n_haps, const void* d_cscptr,
-                                        const void* d_cscidx, uint64_t total, void* d_indptr, void* d_indices, void* d_data,
-                                        uint64_t* nnz_out) {
-    if (!d_cscptr || !d_cscidx || !d_indptr || !d_indices || !d_data || !nnz_out || !n_ecs || !n_loci || !n_haps || n_haps > 31 || !total)
-        return fail(nullptr, ECB_ERR_ARG, "bad argument");
-    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, ECB_ERR_NO_DEVICE, "no such device");
-    hipStream_t st = nullptr;
-    // start of every haplotype's block = running sum of its last column pointer
-    std::vector<int> last(n_haps);
-    for (u32 h = 0; h < n_haps; ++h)
-        if (hipMemcpy(&last[h], (const int*)d_cscptr + (u64)h * (n_loci + 1) + n_loci, 4, hipMemcpyDeviceToHost) != hipSuccess)
-            return fail(nullptr, ECB_ERR_HIP, "read csc pointers");
-    std::vector<u64> hs(n_haps + 1, 0);
-    for (u32 h = 0; h < n_haps; ++h) hs[h + 1] = hs[h] + (u64)last[h];
-    if (hs[n_haps] != total) return fail(nullptr, ECB_ERR_ARG, "total does not match the column pointers");
+namespace {
+// the general case: lists in any order, an EC more than once in a list -- every row index becomes a 64-bit key, all of them are sorted
+int hapcsc_to_csr_general(hipStream_t st, u32 n_ecs, u32 n_loci, u32 n_haps, const void* d_cscptr, const void* d_cscidx, u64 total,
+                          const std::vector<u64>& hs, void* d_indptr, void* d_indices, void* d_data, uint64_t* nnz_out) {
     Scratch sc;
     u64 *d_hs = sc.get<u64>(n_haps + 1), *keys = sc.get<u64>(total), *keys2 = sc.get<u64>(total);
     u32 *vals = sc.get<u32>(total), *vals2 = sc.get<u32>(total), *flag = sc.get<u32>(total), *pos = sc.get<u32>(total);
@@ -4404,6 +4572,80 @@ extern "C" int ecb_hapcsc_to_csr_device(int device, uint32_t n_ecs, uint32_t n_l
     if (cv_scan(st, flag, total, pos, &nnz, sc) != ECB_OK) return fail(nullptr, ECB_ERR_HIP, "scan");
     k_cv_back_emit<<<nblk(total, TPB), TPB, 0, st>>>(keys2, vals2, flag, pos, total, n_loci, (int*)d_indices, (int*)d_data);
     k_cv_back_rowptr<<<nblk((u64)n_ecs + 1, TPB), TPB, 0, st>>>(keys2, pos, total, nnz, n_ecs, n_loci, (int*)d_indptr);
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "csc -> csr");
+    *nnz_out = nnz;
+    return ECB_OK;
+}
+}  // namespace
+
+extern "C" int ecb_hapcsc_to_csr_device(int device, uint32_t n_ecs, uint32_t n_loci, uint32_t n_haps, const void* d_cscptr,
+                                        const void* d_cscidx, uint64_t total, void* d_indptr, void* d_indices, void* d_data,
+                                        uint64_t* nnz_out) {
+    if (!d_cscptr || !d_cscidx || !d_indptr || !d_indices || !d_data || !nnz_out || !n_ecs || !n_loci || !n_haps || n_haps > 31 || !total)
+        return fail(nullptr, ECB_ERR_ARG, "bad argument");
+    if (total >= (1ull << 32)) return fail(nullptr, ECB_ERR_LIMIT, "more than 2^32-1 row indices");
+    if (device < 0 || device >= CV_MAX_DEV || hipSetDevice(device) != hipSuccess) return fail(nullptr, ECB_ERR_NO_DEVICE, "no such device");
+    hipStream_t st = nullptr;
+    std::lock_guard<std::mutex> guard(g_cv_lock);
+    CvScratch& S = g_cv[device];
+    // start of every haplotype's block = running sum of its last column pointer
+    u64* words = S.get<u64>(CvScratch::WORDS, 40);                 // [0] error bits  [1] the scan's total  [3] the sort's  [4 ..) last pointers, then block starts
+    if (!words) return fail(nullptr, ECB_ERR_HIP, "out of device memory");
+    int* d_last = reinterpret_cast<int*>(words + 4);
+    std::vector<int> last(n_haps);
+    k_cvb_last<<<1, 64, 0, st>>>((const int*)d_cscptr, n_loci, n_haps, d_last);
+    if (hipMemcpy(last.data(), d_last, n_haps * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "read csc pointers");
+    std::vector<u64> hs(n_haps + 1, 0);
+    for (u32 h = 0; h < n_haps; ++h) {
+        if (last[h] < 0) return fail(nullptr, ECB_ERR_CONTRACT, "malformed CSC: negative column pointer");
+        hs[h + 1] = hs[h] + (u64)last[h];
+    }
+    if (hs[n_haps] != total) return fail(nullptr, ECB_ERR_ARG, "total does not match the column pointers");
+    u32 ebits = 0;
+    while (ebits < 32 && ((u64)1 << ebits) < n_ecs) ++ebits;
+    u64* d_hs = S.get<u64>(CvScratch::X0, n_haps + 1);
+    u32 *Ssum = S.get<u32>(CvScratch::X1, (u64)n_loci + 1);
+    u32 *colcnt = S.get<u32>(CvScratch::HEAD, 5ull * n_loci + 8), *sums = S.get<u32>(CvScratch::SUMS2, (u64)n_loci / SCAN_BLOCK + 8);
+    if (!d_hs || !Ssum || !colcnt || !sums) return fail(nullptr, ECB_ERR_HIP, "out of device memory");
+    u32 *colbase = colcnt + n_loci, *colcur = colbase + n_loci, *pieces = colcur + n_loci, *pbase = pieces + n_loci;
+    u32* d_err = reinterpret_cast<u32*>(words);
+    if (hipMemcpyAsync(d_hs, hs.data(), (n_haps + 1) * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemsetAsync(words, 0, 24, st) != hipSuccess || hipMemsetAsync(colcnt, 0, 3ull * n_loci * 4, st) != hipSuccess)
+        return fail(nullptr, ECB_ERR_HIP, "csc -> csr (set-up)");
+    k_cvu_colsum<<<nblk((u64)n_loci + 1, TPB), TPB, 0, st>>>((const int*)d_cscptr, n_loci, n_haps, Ssum, d_err);
+    k_cvu_pieces<<<nblk(n_loci, TPB), TPB, 0, st>>>(Ssum, n_loci, pieces);
+    cv_scan_queue(st, pieces, n_loci, pbase, sums, words + 2);
+    u64 back[3] = {0, 0, 0};
+    if (hipMemcpy(back, words, 24, hipMemcpyDeviceToHost) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "csc -> csr (pointers)");
+    if ((u32)back[0]) return fail(nullptr, ECB_ERR_CONTRACT, "malformed CSC: column pointers do not start at zero or go backwards");
+    const u64 n_items = back[2];
+    if (n_items == 0 || n_items >= (1ull << 31)) return fail(nullptr, ECB_ERR_LIMIT, "csc -> csr: pieces of work");
+    u32 *item_col = S.get<u32>(CvScratch::X2, n_items + 1), *bnd = S.get<u32>(CvScratch::X3, (n_items + 1) * n_haps);
+    if (!item_col || !bnd) return fail(nullptr, ECB_ERR_HIP, "out of device memory");
+    k_cvu_items<<<nblk(n_loci, TPB), TPB, 0, st>>>(pieces, pbase, n_loci, item_col);
+    k_cvu_bounds<<<nblk(n_items * n_haps, TPB), TPB, 0, st>>>((const int*)d_cscptr, (const int*)d_cscidx, d_hs, pieces, pbase, item_col, (u32)n_items,
+                                                             n_loci, n_haps, n_ecs, bnd);
+    k_cvu_union<false><<<(unsigned)n_items, CVU_TPB, 0, st>>>((const int*)d_cscptr, (const int*)d_cscidx, d_hs, pieces, pbase, item_col, bnd, (u32)n_items,
+                                                              n_loci, n_haps, n_ecs, colcnt, colbase, colcur, 0, nullptr, nullptr, d_err);
+    cv_scan_queue(st, colcnt, n_loci, colbase, sums, words + 1);
+    if (hipMemcpy(back, words, 16, hipMemcpyDeviceToHost) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "csc -> csr (union)");
+    if ((u32)back[0] & CVB_ERR_EC) return fail(nullptr, ECB_ERR_CONTRACT, "malformed CSC: a row index beyond the number of ECs");
+    if ((u32)back[0] & CVB_ERR_ORDER)                              // a long column whose lists are not ascending: sort everything
+        return hapcsc_to_csr_general(st, n_ecs, n_loci, n_haps, d_cscptr, d_cscidx, total, hs, d_indptr, d_indices, d_data, nnz_out);
+    const u64 nnz = back[1];
+    u64 *k0 = S.get<u64>(CvScratch::KEYS0, nnz), *k1 = S.get<u64>(CvScratch::KEYS1, nnz);
+    u32 *v0 = S.get<u32>(CvScratch::VALS0, nnz), *v1 = S.get<u32>(CvScratch::VALS1, nnz);
+    SortScratch ss{S.get<u32>(CvScratch::HIST, rs_words(nnz)), S.get<u32>(CvScratch::OFFS, RS_AUX_WORDS),
+                   S.get<u32>(CvScratch::SUMS, rs_scan_blocks(nnz) + 8), words + 3};
+    if (!k0 || !k1 || !v0 || !v1 || !ss.hist || !ss.offs || !ss.sums) return fail(nullptr, ECB_ERR_HIP, "out of device memory");
+    k_cvu_union<true><<<(unsigned)n_items, CVU_TPB, 0, st>>>((const int*)d_cscptr, (const int*)d_cscidx, d_hs, pieces, pbase, item_col, bnd, (u32)n_items,
+                                                             n_loci, n_haps, n_ecs, colcnt, colbase, colcur, nnz, k0, v0, d_err);
+    u64* kk[2] = {k0, k1}; u32* vv[2] = {v0, v1};
+    int where = 0;
+    // stable, on the EC alone: what left column by column arrives row by row with its loci ascending
+    if (radix_sort_pairs64(st, kk, vv, nnz, ss, &where, (ebits >= 32 ? 0xFFFFFFFFull : (1ull << ebits) - 1ull) << 32) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "sort");
+    k_cvb_out<<<nblk(nnz, TPB), TPB, 0, st>>>(kk[where], vv[where], nnz, (int*)d_indices, (int*)d_data);
+    k_cvb_rowptr<<<nblk((u64)n_ecs + 1, TPB), TPB, 0, st>>>(kk[where], nnz, n_ecs, (int*)d_indptr);
     if (hipStreamSynchronize(st) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "csc -> csr");
     *nnz_out = nnz;
     return ECB_OK;

@@ -707,6 +707,74 @@ def test_sparse_format_conversion_refuses_a_malformed_matrix(golden_dir):
     assert lib.ecb_release_scratch(0) == 0
 
 
+def test_per_haplotype_csc_of_any_origin_converts_back(golden_dir):
+    """``ecb_hapcsc_to_csr_device`` (``emase2ec`` of an ``.h5`` from disk): lists in scipy's canonical order take the union-and-transpose
+    path; lists whose rows are out of order, or hold an EC twice, are noticed and sorted -- the same CSR either way; column pointers
+    that go backwards and a row index beyond the ECs are ECB_ERR_CONTRACT; columns without entries, haplotypes without entries, one
+    column that every EC uses and lists far longer than a workgroup's stretch go through."""
+    import torch
+    from alntools_amd import bin_utils
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(77)
+    m = bin_utils.ecload(os.path.join(golden_dir, "g2_c1.bin"))
+    T, H, E = m.num_loci, m.num_haplotypes, m.num_reads
+    ip, ix, da = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (m.indptrA, m.indicesA, m.dataA))
+    cptr, cidx = ecb.csr_to_hapcsc(ip, ix, da, T, H)
+    cp, ci = cptr.cpu().numpy().copy(), cidx.cpu().numpy().copy()
+    starts = np.concatenate([[0], np.cumsum(cp[:, -1])]).astype(np.int64)
+
+    def back(cp_, ci_, n_ecs=E):
+        a, b, c = ecb.hapcsc_to_csr(torch.from_numpy(cp_).to(dev), torch.from_numpy(ci_).to(dev), n_ecs)
+        return a.cpu().numpy(), b.cpu().numpy(), c.cpu().numpy()
+
+    def same(got):
+        return np.array_equal(got[0], m.indptrA) and np.array_equal(got[1], m.indicesA) and np.array_equal(got[2], m.dataA)
+
+    assert same(back(cp, ci))
+    # every list shuffled: the general path
+    sh = ci.copy()
+    for h in range(H):
+        for t in range(T):
+            a, b = starts[h] + cp[h, t], starts[h] + cp[h, t + 1]
+            if b - a > 1:
+                sh[a:b] = rng.permutation(sh[a:b])
+    assert not np.array_equal(sh, ci) and same(back(cp, sh))
+    # an EC twice in a list (a duplicate entry ORs into the same bit): one list gets its first row index once more
+    h0, t0 = next((h, t) for h in range(H) for t in range(T) if cp[h, t + 1] > cp[h, t])
+    at = int(starts[h0] + cp[h0, t0])
+    dup_ci = np.concatenate([ci[:at], ci[at:at + 1], ci[at:]])
+    dup_cp = cp.copy()
+    dup_cp[h0, t0 + 1:] += 1
+    assert same(back(dup_cp, dup_ci))
+    for what in ("pointers", "row index"):
+        cp2, ci2 = cp.copy(), ci.copy()
+        if what == "pointers":
+            cp2[1, 5], cp2[1, 6] = cp2[1, 6] + 1, cp2[1, 5]
+        else:
+            ci2[len(ci2) // 3] = E
+        with pytest.raises(ecb.EcbError) as e:
+            back(cp2, ci2)
+        assert e.value.code == -5, what
+    # a made-up matrix: 3 000 ECs x 40 loci x 5 haplotypes, haplotype 3 empty, loci 7 - 19 unused, locus 2 in every EC on haplotype 0
+    # and 1 (two lists of 3 000 rows: a dozen workgroups' stretches each), the rest sparse
+    E2, T2, H2 = 3000, 40, 5
+    dense = np.zeros((E2, T2), dtype=np.int32)
+    dense[:, 2] = 3
+    for h in (0, 1, 2, 4):
+        r, c = rng.integers(0, E2, 4000), rng.integers(20, T2, 4000)
+        dense[r, c] |= 1 << h
+    from scipy import sparse
+    ref = sparse.csr_matrix(dense)
+    ref.sort_indices()
+    cps, cis = [], []
+    for h in range(H2):
+        mh = sparse.csc_matrix((dense >> h) & 1)
+        mh.sort_indices()
+        cps.append(mh.indptr.astype(np.int32)); cis.append(mh.indices.astype(np.int32))
+    g = back(np.stack(cps), np.concatenate(cis), E2)
+    assert np.array_equal(g[0], ref.indptr) and np.array_equal(g[1], ref.indices) and np.array_equal(g[2], ref.data)
+
+
 def test_cells_pushed_from_device_memory_equal_cells_pushed_from_the_host():
     import torch
     spec = synth.SynthSpec(50_000, 3_000, 4)
