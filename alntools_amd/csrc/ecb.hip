@@ -2487,6 +2487,10 @@ constexpr int RS_MAX_PASSES = 8;
 // (Before: a histogram kernel, three scan kernels over (digit, workgroup) counters and the scatter per pass -- a third of a pass.)
 constexpr u32 RS_AGG = 1u << 30, RS_PFX = 2u << 30, RS_VAL = (1u << 30) - 1u;
 constexpr u32 RS_SPIN_MAX = 1u << 24;
+#ifndef ECB_RS_LOOK
+#define ECB_RS_LOOK 4
+#endif
+constexpr int RS_LOOK = ECB_RS_LOOK;          // tiles looked back at per round trip
 struct RsShifts { u32 s[RS_MAX_PASSES]; u32 n; };
 __global__ __launch_bounds__(RS_TPB) void k_rs_hist_all(const u64* keys, u64 n, RsShifts sh, u32* ghist) {
     __shared__ u32 h[RS_MAX_PASSES][256];
@@ -2565,16 +2569,27 @@ __global__ __launch_bounds__(RS_TPB) void k_rs_pass(const u64* kin, const u32* v
     } else {
         __hip_atomic_store(mine, RS_AGG | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         u32 spins = 0;
-        for (long long t = (long long)tile - 1; t >= 0;) {
-            const u32 v = __hip_atomic_load(desc + (u64)t * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (v < RS_AGG) {                        // nothing published there yet
+        bool done = false;
+        for (long long t = (long long)tile - 1; t >= 0 && !done;) {
+            // four tiles back per round trip (their words are independent loads); consumed in order, up to the first that has nothing yet
+            u32 v[RS_LOOK];
+#pragma unroll
+            for (int k = 0; k < RS_LOOK; ++k)
+                v[k] = t - k >= 0 ? __hip_atomic_load(desc + (u64)(t - k) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            int used = 0;
+#pragma unroll
+            for (int k = 0; k < RS_LOOK; ++k) {
+                if (done || used != k || t - k < 0) continue;
+                if (v[k] < RS_AGG) continue;         // nothing published there yet: this one again in the next round
+                excl += v[k] & RS_VAL;
+                used = k + 1;
+                if (v[k] >= RS_PFX) done = true;
+            }
+            t -= used;
+            if (!used) {
                 if (++spins > RS_SPIN_MAX) { atomicOr(err, 1u); break; }
                 __builtin_amdgcn_s_sleep(1);
-                continue;
             }
-            excl += v & RS_VAL;
-            if (v >= RS_PFX) break;
-            --t;
         }
         __hip_atomic_store(mine, RS_PFX | ((excl + tot) & RS_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
