@@ -2475,7 +2475,11 @@ __global__ void k_clear_slots(Slot* table, const u32* list, u64 n) {
 // wave's LDS counter of that digit by the group's size, and a key's rank is that counter value plus the number of group
 // members in lower lanes.  Counters of the four waves are added up in wave order afterwards.
 // ---------------------------------------------------------------------------------------------
-constexpr int RS_TPB = 256, RS_ITEMS = 16, RS_TILE = RS_TPB * RS_ITEMS;
+#ifndef ECB_RS_TPB
+#define ECB_RS_TPB 1024
+#endif
+constexpr int RS_TPB = ECB_RS_TPB, RS_TILE = 4096, RS_ITEMS = RS_TILE / RS_TPB;
+static_assert(RS_TPB >= 256 && RS_TPB % 64 == 0 && RS_TILE % RS_TPB == 0, "one thread per digit among the first 256");
 constexpr int RS_MAX_PASSES = 8;
 // Round 3: a pass is ONE kernel.  The digit histograms of all passes are taken in one sweep up front (they do not depend on the
 // order of the keys), which gives every pass the first place of each digit; where a TILE's keys of a digit go within that is
@@ -2501,7 +2505,7 @@ __global__ __launch_bounds__(RS_TPB) void k_rs_hist_all(const u64* keys, u64 n, 
         for (u32 p = 0; p < sh.n; ++p) atomicAdd(&h[p][(u32)(k >> sh.s[p]) & 255u], 1u);
     }
     __syncthreads();
-    for (u32 p = 0; p < sh.n; ++p) { const u32 c = h[p][threadIdx.x]; if (c) atomicAdd(&ghist[p * 256 + threadIdx.x], c); }
+    if (threadIdx.x < 256u) for (u32 p = 0; p < sh.n; ++p) { const u32 c = h[p][threadIdx.x]; if (c) atomicAdd(&ghist[p * 256 + threadIdx.x], c); }
 }
 __global__ __launch_bounds__(256) void k_rs_bases(const u32* ghist, u32 n_passes, u32* base) {      // exclusive scan of every pass's 256 counts
     __shared__ u32 s_w[4];
@@ -2559,12 +2563,17 @@ __global__ __launch_bounds__(RS_TPB) void k_rs_pass(const u64* kin, const u32* v
     }
     __syncthreads();
     u32 tot = 0;                                   // digit tid: its keys in the tile, and -- in place of the per-wave counts -- the keys of the waves before
+    const bool dig = tid < 256u;                   // (threads beyond the 256 digits only rank and move keys)
+    const u32 dt = dig ? tid : 0u;
+    if (dig) {
 #pragma unroll
-    for (int k = 0; k < RS_TPB / 64; ++k) { const u32 c = cnt[k][tid]; cnt[k][tid] = tot; tot += c; }
+        for (int k = 0; k < RS_TPB / 64; ++k) { const u32 c = cnt[k][tid]; cnt[k][tid] = tot; tot += c; }
+    }
     // publish the tile's count of digit tid, look back for the keys of that digit in the tiles before, publish the prefix
-    u32* const mine = desc + (u64)tile * 256 + tid;
+    u32* const mine = desc + (u64)tile * 256 + dt;
     u32 excl = 0;
-    if (tile == 0) {
+    if (!dig) {
+    } else if (tile == 0) {
         __hip_atomic_store(mine, RS_PFX | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         __hip_atomic_store(mine, RS_AGG | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2575,7 +2584,7 @@ __global__ __launch_bounds__(RS_TPB) void k_rs_pass(const u64* kin, const u32* v
             u32 v[RS_LOOK];
 #pragma unroll
             for (int k = 0; k < RS_LOOK; ++k)
-                v[k] = t - k >= 0 ? __hip_atomic_load(desc + (u64)(t - k) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                v[k] = t - k >= 0 ? __hip_atomic_load(desc + (u64)(t - k) * 256 + dt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
             int used = 0;
 #pragma unroll
             for (int k = 0; k < RS_LOOK; ++k) {
@@ -2593,14 +2602,14 @@ __global__ __launch_bounds__(RS_TPB) void k_rs_pass(const u64* kin, const u32* v
         }
         __hip_atomic_store(mine, RS_PFX | ((excl + tot) & RS_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    gbase[tid] = base[tid] + excl;
+    if (dig) gbase[tid] = base[tid] + excl;
     {
         const u32 incl = wave_incl_scan(tot);
-        if (lane == 63) s_wsum[w] = incl;
+        if (lane == 63) s_wsum[w] = incl;          // (waves beyond the fourth: zeros)
         __syncthreads();
         u32 before = 0;
         for (u32 k = 0; k < w; ++k) before += s_wsum[k];
-        dstart[tid] = before + incl - tot;
+        if (dig) dstart[tid] = before + incl - tot;
     }
     __syncthreads();
 #pragma unroll
