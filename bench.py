@@ -204,6 +204,66 @@ def copy_peak(device, nbytes=4 << 30, reps=5):
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9, None, "torch.Tensor.copy_ (tools/micro/bin/libcopy_peak.so not built)"
 
 
+def sensors_under_load(step, fence, device_index, reps=8):
+    """What the card's own sensors say while ``step`` runs (``reps`` untimed steps after the timed ones; a sampling thread reads
+    the amdgpu hwmon files every half millisecond): shader and memory clock, socket power against its cap, temperatures.  Boxes of
+    one pool move the same machine code at different speeds; this is the context a time was measured in, not part of the metric.
+    -> dict, or None where the files are not there to read."""
+    import glob
+    import threading
+    import torch
+    want = None
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        want = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+    except Exception:
+        pass
+    cands = []
+    for hw in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+        if os.path.exists(os.path.join(hw, "freq1_input")):
+            pci = os.path.basename(os.path.realpath(os.path.join(hw, "..", "..")))
+            cands.append((0 if (want and pci == want) else 1, hw))
+    if not cands:
+        return None
+    hw = sorted(cands)[0][1]
+
+    def rd(name):
+        try:
+            with open(os.path.join(hw, name)) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return None
+    temps = {}
+    for t in sorted(glob.glob(os.path.join(hw, "temp*_input"))):
+        lab = t.replace("_input", "_label")
+        temps[os.path.basename(t)] = open(lab).read().strip() if os.path.exists(lab) else os.path.basename(t)[:-6]
+    rows, stop = [], threading.Event()
+
+    def sample():
+        while not stop.is_set():
+            rows.append((rd("freq1_input"), rd("freq2_input"), rd("power1_input")) + tuple(rd(k) for k in temps))
+            time.sleep(0.0005)
+    fence()
+    th = threading.Thread(target=sample, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    stop.set()
+    th.join()
+
+    def stat(col, scale):
+        v = [r[col] * scale for r in rows if r[col] is not None]
+        return {"avg": round(sum(v) / len(v), 1), "min": round(min(v), 1), "max": round(max(v), 1)} if v else None
+    cap = rd("power1_cap")
+    return {"sclk_mhz": stat(0, 1e-6), "mclk_mhz": stat(1, 1e-6), "socket_power_w": stat(2, 1e-6),
+            "power_cap_w": round(cap * 1e-6, 1) if cap else None,
+            "temperature_c": {lab: stat(3 + i, 1e-3) for i, lab in enumerate(temps.values())},
+            "samples": len(rows), "over": "%d untimed steps, %.1f ms" % (reps, dt * 1e3), "source": hw}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -418,6 +478,12 @@ def main():
             step_bytes += 4.0 * total_reads + 8.0 * ms_sizes.get("nnz_n", 0)
         step_achieved = step_bytes / (ms_per_step * 1e-3) / 1e9
         peak_copy, peak_read, peak_how = copy_peak(device) if not rehearsal else (None, None, None)
+        sensors = None
+        if world == 1 and not rehearsal and not os.environ.get("ECB_ABLATE"):
+            try:
+                sensors = sensors_under_load(step, fence, local)
+            except Exception as e:      # (never the reason a bench line is missing)
+                sensors = {"error": repr(e)}
         traffic, traffic_src = None, None
         tfile = os.path.join(ROOT, "profiles", "traffic_%s_n%d.json" % (args.workload, world))
         if os.path.exists(tfile):
@@ -456,6 +522,7 @@ def main():
                          "peak_measured_copy": peak_copy, "peak_measured_read": peak_read, "peak_measured_how": peak_how,
                          "frac_of_measured_copy": (achieved / peak_copy) if peak_copy else None},
         }
+        out["config"]["sensors_under_load"] = sensors
         if not use_dist and not args.no_cpu_baseline and not multisample:
             out["cpu_baseline"], oracle_result = cpu_baseline(rid, loc, hf, H, args.cpu_sample_reads, args.cpu_threads)
             if oracle_result is not None:      # the whole workload went through the oracle: hold the GPU's result to it, bit for bit
