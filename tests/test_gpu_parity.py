@@ -775,6 +775,60 @@ def test_per_haplotype_csc_of_any_origin_converts_back(golden_dir):
     assert np.array_equal(g[0], ref.indptr) and np.array_equal(g[1], ref.indices) and np.array_equal(g[2], ref.data)
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_per_haplotype_csc_with_long_and_bunched_columns(seed):
+    """The union-per-column path of ``ecb_hapcsc_to_csr_device`` on shapes that stress its cuts: a column far longer than a piece of
+    work whose ECs are spread over all ids (cut into EC ranges, hashed in LDS), one whose ECs are bunched into a narrow range (one piece
+    overflows its table: the entry-by-entry path with binary searches), up to 31 haplotypes, empty haplotypes and columns; and the same
+    matrix with the long columns' lists shuffled (noticed; the sort-everything path).  Against scipy."""
+    import torch
+    from scipy import sparse
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(1000 + seed)
+    E, T, H = (200_000, 30, 4) if seed == 1 else ((90_000, 12, 31) if seed == 2 else (400_000, 200, 8))
+    rows, cols, bits = [], [], []
+
+    def add(r, c, h):
+        rows.append(np.asarray(r, dtype=np.int64)); cols.append(np.full(len(r), c, dtype=np.int64)); bits.append(np.full(len(r), h, dtype=np.int64))
+    for h in range(H):
+        if h == 1:
+            continue                                                   # a haplotype without entries
+        add(rng.choice(E, size=min(E, 20_000), replace=False), 0, h)   # long, spread over all ids
+        add(rng.choice(5_000, size=4_000, replace=False), 1, h)        # long, bunched at low ids
+        for c in range(3, T):                                          # (column 2 stays empty)
+            add(rng.choice(E, size=int(rng.integers(0, 60)), replace=False), c, h)
+    r, c, b = np.concatenate(rows), np.concatenate(cols), np.concatenate(bits)
+    ref = sparse.coo_matrix(((1 << b).astype(np.int64), (r, c)), shape=(E, T)).tocsr()      # (distinct bits per (row, column, haplotype): the sum is the OR)
+    ref.sort_indices()
+    cps, cis = [], []
+    for h in range(H):
+        sel = b == h
+        mh = sparse.coo_matrix((np.ones(int(sel.sum()), dtype=np.int8), (r[sel], c[sel])), shape=(E, T)).tocsc()
+        mh.sort_indices()
+        cps.append(mh.indptr.astype(np.int32)); cis.append(mh.indices.astype(np.int32))
+    cp, ci = np.stack(cps), np.concatenate(cis)
+
+    def back(ci_):
+        a, x, d = ecb.hapcsc_to_csr(torch.from_numpy(cp).to(dev), torch.from_numpy(ci_).to(dev), E)
+        return a.cpu().numpy(), x.cpu().numpy(), d.cpu().numpy()
+
+    def same(g):
+        return np.array_equal(g[0], ref.indptr) and np.array_equal(g[1], ref.indices) and np.array_equal(g[2], ref.data.astype(np.int32))
+
+    assert same(back(ci))
+    starts = np.concatenate([[0], np.cumsum(cp[:, -1])]).astype(np.int64)
+    sh = ci.copy()
+    for h in range(H):
+        for col in (0, 1):
+            a, e = starts[h] + cp[h, col], starts[h] + cp[h, col + 1]
+            if e - a > 1:
+                sh[a:e] = rng.permutation(sh[a:e])
+    assert same(back(sh))
+    # ... and forward again: the per-haplotype CSC of the CSR is the one it came from
+    cptr, cidx = ecb.csr_to_hapcsc(*(torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (ref.indptr.astype(np.int32), ref.indices.astype(np.int32), ref.data.astype(np.int32))), T, H)
+    assert np.array_equal(cptr.cpu().numpy(), cp) and np.array_equal(cidx.cpu().numpy(), ci)
+
+
 def test_cells_pushed_from_device_memory_equal_cells_pushed_from_the_host():
     import torch
     spec = synth.SynthSpec(50_000, 3_000, 4)
