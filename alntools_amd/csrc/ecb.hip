@@ -21,7 +21,8 @@
 //   k_merge    multi-GPU: re-insert another rank's serialised table (the ordered merge of :680-724).
 //   k_ms_*, k_msf*   multisample: (EC, cell, file) triples of the reads (one radix sort); cell order, minimum-count filter, EC re-rank
 //              and CSC N in linear passes over them (bam_utils_multisample.py:503-636, 737-791).
-//   k_cv_*     CSR(bitmask) <-> per-haplotype CSC (bin_utils.py:979-1028).
+//   k_cv_*     CSR(bitmask) -> per-haplotype CSC as a transposition of the non-zeros; k_cvu_* / k_cvb_*: back, as a union per column
+//              in LDS hash tables and the same transposition (bin_utils.py:979-1028).
 //
 // Integer / indexing work only: no MFMA.  The bound is HBM bandwidth: the stream part of k_stream runs at the chip's streaming rate, what is
 // left above it is the EC table's random lines sharing the memory system with the stream.
@@ -368,11 +369,6 @@ __device__ __forceinline__ u32 wave_incl_scan(u32 v) {
 __device__ __forceinline__ u32 wave_sum(u32 v) { return (u32)__builtin_amdgcn_readlane((int)wave_incl_scan(v), 63); }
 __device__ __forceinline__ u32 lane_above(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }   // wave_shr:1 (lane 0 gets 0)
 __device__ __forceinline__ int clamp04(int x, int, int) { return min(max(x, 0), 4); }   // v_med3_i32
-// bits [lo, hi) of a 4-record group, lo/hi given relative to the group's first record
-__device__ __forceinline__ u32 group_mask(int lo, int hi) {
-    lo = max(lo, 0); hi = min(hi, 4);
-    return hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
-}
 
 struct TileRegs { u32 rr[RPL], ll[RPL], hh[RPL]; };
 
@@ -1942,48 +1938,96 @@ __global__ void k_popc(const u32* in, u64 n, u32* out) {
     if (i < n) out[i] = __popc(in[i]);
 }
 
-// exclusive scan of u32 (three launches): per-block sums, scan of the sums, per-block scan + offset
-constexpr int SCAN_ITEMS = 8;
-constexpr int SCAN_BLOCK = TPB * SCAN_ITEMS;
-__device__ __forceinline__ u32 block_excl_scan(u32 v, u32* total) {   // over TPB threads
-    __shared__ u32 s_w[TPB / 64];
-    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    u32 incl = v;
+// Exclusive scan of u32, ONE pass over the data: a workgroup takes the next stretch of 16 384 values (a ticket: stretches start in
+// order), publishes its sum, and one of its waves walks back over the stretches before it, 64 status words per step, adding their
+// sums up to the nearest one whose inclusive prefix is known -- decoupled look-back, as in the radix sort below.  A status word is
+// 2 bits of state and a 62-bit value, written and read with relaxed agent-scope atomics; the words and the ticket are zeroed by the
+// launcher (scan_launch).  (Rounds 1-3a: per-block sums, a scan of the sums, per-block scan + offset -- three launches, the input read
+// twice, and 4-byte loads at a 32-byte lane stride; 18 such scans were 1.4 ms of the config-4 path.)
+// (stride: the input may be one member of an array of small structs -- element i is in[i * stride])
+constexpr int SCB_TPB = 1024, SCB_ITEMS = 16, SCB = SCB_TPB * SCB_ITEMS;
+constexpr u64 SC_AGG = 1ull << 62, SC_PFX = 2ull << 62, SC_VAL = (1ull << 62) - 1ull;
+inline u64 scan_blocks(u64 n) { return std::max<u64>(1, (n + SCB - 1) / SCB); }
+inline u64 scan_words(u64 n) { return 2 * (scan_blocks(n) + 2); }             // u32 words of scratch a scan of n values needs
+__global__ __launch_bounds__(SCB_TPB) void k_scan_lb(const u32* in, u64 n, u32* out, u64* st, u64 nb, u64* d_total, u32 stride) {
+    __shared__ u64 s_b, s_excl;
+    __shared__ u32 s_w[SCB_TPB / 64];
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    if (tid == 0) s_b = atomicAdd(reinterpret_cast<unsigned long long*>(&st[nb]), 1ull);
+    __syncthreads();
+    const u64 b = s_b;
+    if (b >= nb) return;
+    const u64 base = b * SCB + (u64)tid * SCB_ITEMS;
+    u32 v[SCB_ITEMS];
+    const bool whole = base + SCB_ITEMS <= n;
+    if (stride == 1u && whole && (reinterpret_cast<uintptr_t>(in) & 15u) == 0u) {
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(incl, d); if (lane >= (u32)d) incl += t; }
+        for (int k = 0; k < SCB_ITEMS / 4; ++k) {
+            const uint4 q = reinterpret_cast<const uint4*>(in + base)[k];
+            v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < SCB_ITEMS; ++k) v[k] = base + k < n ? in[(base + k) * stride] : 0u;
+    }
+    u32 s = 0;
+#pragma unroll
+    for (int k = 0; k < SCB_ITEMS; ++k) s += v[k];
+    const u32 incl = wave_incl_scan(s);
     if (lane == 63) s_w[w] = incl;
     __syncthreads();
-    u32 add = 0, tot = 0;
-    for (u32 k = 0; k < TPB / 64; ++k) { if (k < w) add += s_w[k]; tot += s_w[k]; }
-    __syncthreads();
-    *total = tot;
-    return add + incl - v;
-}
-// (stride: the input may be one member of an array of small structs -- element i is in[i * stride])
-__global__ __launch_bounds__(TPB) void k_scan_sums(const u32* in, u64 n, u32* sums, u32 stride = 1) {
-    const u64 b0 = (u64)blockIdx.x * SCAN_BLOCK;
-    u32 s = 0;
-    for (int k = 0; k < SCAN_ITEMS; ++k) { const u64 i = b0 + (u64)threadIdx.x * SCAN_ITEMS + k; if (i < n) s += in[i * stride]; }
-    u32 tot; block_excl_scan(s, &tot);
-    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
-}
-__global__ __launch_bounds__(TPB) void k_scan_top(u32* sums, u64 nb, u64* grand) {   // one block; the grand total in 64 bits
-    u64 carry = 0;
-    for (u64 b0 = 0; b0 < nb; b0 += TPB) {
-        const u64 i = b0 + threadIdx.x;
-        const u32 v = i < nb ? sums[i] : 0u;
-        u32 tot; const u32 ex = block_excl_scan(v, &tot);
-        if (i < nb) sums[i] = (u32)carry + ex;
-        carry += tot;
+    u32 before = 0, tot = 0;
+#pragma unroll
+    for (u32 k = 0; k < SCB_TPB / 64; ++k) { const u32 c = s_w[k]; if (k < w) before += c; tot += c; }
+    if (w == 0) {
+        u64 excl = 0;
+        if (lane == 0) __hip_atomic_store(&st[b], (b == 0 ? SC_PFX : SC_AGG) | (u64)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b > 0) {
+            long long t = (long long)b - 1;                  // the nearest stretch not yet added
+            for (u32 spins = 0; spins < (1u << 24);) {
+                const long long idx = t - (long long)lane;
+                const u64 x = idx >= 0 ? __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : SC_PFX;      // (before the first: prefix 0)
+                const u64 ready = __ballot(x != 0ull), pfx = __ballot(x >= SC_PFX);
+                u64 take = 0;                                // lanes whose value goes in
+                if (pfx) {
+                    const int p = __ffsll((long long)pfx) - 1;
+                    const u64 need = p == 63 ? ~0ull : (1ull << (p + 1)) - 1ull;
+                    if ((ready & need) == need) take = need;
+                } else if (ready == ~0ull) take = ~0ull;
+                if (!take) { ++spins; __builtin_amdgcn_s_sleep(1); continue; }
+                u64 val = (take >> lane & 1ull) ? (x & SC_VAL) : 0ull;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) val += __shfl_xor(val, d);
+                excl += val;
+                if (pfx) break;
+                t -= 64;
+            }
+            if (lane == 0) __hip_atomic_store(&st[b], SC_PFX | ((excl + tot) & SC_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) { s_excl = excl; if (b + 1 == nb && d_total) *d_total = excl + tot; }
     }
-    if (threadIdx.x == 0) *grand = carry;
+    __syncthreads();
+    u32 run = (u32)s_excl + before + incl - s;
+    if (whole && (reinterpret_cast<uintptr_t>(out) & 15u) == 0u) {
+#pragma unroll
+        for (int k = 0; k < SCB_ITEMS / 4; ++k) {
+            uint4 q;
+            q.x = run; run += v[4 * k]; q.y = run; run += v[4 * k + 1]; q.z = run; run += v[4 * k + 2]; q.w = run; run += v[4 * k + 3];
+            reinterpret_cast<uint4*>(out + base)[k] = q;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < SCB_ITEMS; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
+    }
 }
-__global__ __launch_bounds__(TPB) void k_scan_apply(const u32* in, u64 n, const u32* sums, u32* out, u32 stride = 1) {
-    const u64 b0 = (u64)blockIdx.x * SCAN_BLOCK;
-    u32 v[SCAN_ITEMS], s = 0;
-    for (int k = 0; k < SCAN_ITEMS; ++k) { const u64 i = b0 + (u64)threadIdx.x * SCAN_ITEMS + k; v[k] = i < n ? in[i * stride] : 0u; s += v[k]; }
-    u32 tot; u32 ex = block_excl_scan(s, &tot) + sums[blockIdx.x];
-    for (int k = 0; k < SCAN_ITEMS; ++k) { const u64 i = b0 + (u64)threadIdx.x * SCAN_ITEMS + k; if (i < n) out[i] = ex; ex += v[k]; }
+// queue a scan on `st`: scratch = scan_words(n) u32 words (8-byte aligned); the total (64 bits) lands in *d_total (may be null)
+inline hipError_t scan_launch(hipStream_t st, const u32* in, u64 n, u32* out, u32* scratch, u64* d_total, u32 stride = 1) {
+    const u64 nb = scan_blocks(n);
+    u64* words = reinterpret_cast<u64*>(scratch);
+    hipError_t e = hipMemsetAsync(words, 0, (nb + 1) * 8, st);
+    if (e != hipSuccess) return e;
+    k_scan_lb<<<(unsigned)nb, SCB_TPB, 0, st>>>(in, n, out, words, nb, d_total, stride);
+    return hipGetLastError();
 }
 
 // (slot and row length of rank r go out as one 8-byte word: the scatter is what this kernel costs, and two 4-byte stores to
@@ -3243,12 +3287,9 @@ void free_results(ecb_handle* h) {   // result buffers live in the pool: nothing
 // exclusive scan of u32 values, queued on the handle's stream; the sum (64 bits) is left in *d_total on the device
 // (a sum of 2^32 or more: the caller's limit check, `out` wrapped)
 int excl_scan_dev(ecb_handle* h, const u32* in, u64 n, u32* out, u64* d_total, u32 stride = 1) {
-    const u64 nb = std::max<u64>(1, (n + SCAN_BLOCK - 1) / SCAN_BLOCK);
     u32* sums = nullptr;
-    POOL(h, P_SUMS, sums, nb);
-    k_scan_sums<<<(unsigned)nb, TPB, 0, h->stream>>>(in, n, sums, stride);
-    k_scan_top<<<1, TPB, 0, h->stream>>>(sums, nb, d_total);
-    k_scan_apply<<<(unsigned)nb, TPB, 0, h->stream>>>(in, n, sums, out, stride);
+    POOL(h, P_SUMS, sums, scan_words(n));
+    HIPCHK(h, scan_launch(h->stream, in, n, out, sums, d_total, stride));
     return ECB_OK;
 }
 // ... and with the sum brought to the host (one wait)
@@ -4461,13 +4502,10 @@ int ecb_profile_read(ecb_handle* h, double* ms, uint64_t* launches, uint64_t* re
 // ---- f-2 conversions (stateless; scratch is allocated per call: this is not the hot path) ------------------------
 namespace {
 int cv_scan(hipStream_t st, const u32* in, u64 n, u32* out, u64* total, Scratch& sc) {
-    const u64 nb = std::max<u64>(1, (n + SCAN_BLOCK - 1) / SCAN_BLOCK);
-    u32* sums = sc.get<u32>(nb + 4);
+    u32* sums = sc.get<u32>(scan_words(n) + 4);
     if (!sums) return ECB_ERR_HIP;
-    u64* grand = reinterpret_cast<u64*>(sums + ((nb + 1) & ~(u64)1));
-    k_scan_sums<<<(unsigned)nb, TPB, 0, st>>>(in, n, sums);
-    k_scan_top<<<1, TPB, 0, st>>>(sums, nb, grand);
-    k_scan_apply<<<(unsigned)nb, TPB, 0, st>>>(in, n, sums, out);
+    u64* grand = reinterpret_cast<u64*>(sums + scan_words(n));
+    if (scan_launch(st, in, n, out, sums, grand) != hipSuccess) return ECB_ERR_HIP;
     if (hipMemcpyAsync(total, grand, 8, hipMemcpyDeviceToHost, st) != hipSuccess) return ECB_ERR_HIP;
     return hipStreamSynchronize(st) == hipSuccess ? ECB_OK : ECB_ERR_HIP;
 }
@@ -4494,13 +4532,8 @@ struct CvScratch {
 constexpr int CV_MAX_DEV = 64;
 CvScratch g_cv[CV_MAX_DEV];
 std::mutex g_cv_lock;
-// exclusive scan on `st`, nothing waits: sums = n / SCAN_BLOCK + 1 words of scratch, the total (64 bits) lands in *d_grand
-void cv_scan_queue(hipStream_t st, const u32* in, u64 n, u32* out, u32* sums, u64* d_grand) {
-    const u64 nb = std::max<u64>(1, (n + SCAN_BLOCK - 1) / SCAN_BLOCK);
-    k_scan_sums<<<(unsigned)nb, TPB, 0, st>>>(in, n, sums);
-    k_scan_top<<<1, TPB, 0, st>>>(sums, nb, d_grand);
-    k_scan_apply<<<(unsigned)nb, TPB, 0, st>>>(in, n, sums, out);
-}
+// exclusive scan on `st`, nothing waits: sums = scan_words(n) words of scratch, the total (64 bits) lands in *d_grand
+void cv_scan_queue(hipStream_t st, const u32* in, u64 n, u32* out, u32* sums, u64* d_grand) { (void)scan_launch(st, in, n, out, sums, d_grand); }
 }  // namespace
 
 extern "C" int ecb_release_scratch(int device) {
@@ -4548,7 +4581,7 @@ extern "C" int ecb_csr_to_hapcsc_device(int device, uint32_t n_ecs, uint32_t n_l
     SortScratch ss{S.get<u32>(CvScratch::HIST, rs_words(nnz)), S.get<u32>(CvScratch::OFFS, RS_AUX_WORDS),
                    S.get<u32>(CvScratch::SUMS, rs_scan_blocks(nnz) + 8), words + 3};
     u32 *blk = S.get<u32>(CvScratch::BLK, (u64)n_haps * nb), *scan = S.get<u32>(CvScratch::SCAN, (u64)n_haps * nb);
-    u32 *sums2 = S.get<u32>(CvScratch::SUMS2, (u64)n_haps * nb / SCAN_BLOCK + 8), *headval = S.get<u32>(CvScratch::HEAD, (u64)n_haps * n_loci);
+    u32 *sums2 = S.get<u32>(CvScratch::SUMS2, scan_words((u64)n_haps * nb) + 2), *headval = S.get<u32>(CvScratch::HEAD, (u64)n_haps * n_loci);
     if (!k0 || !k1 || !v0 || !v1 || !ss.hist || !ss.offs || !ss.sums || !blk || !scan || !sums2 || !headval) return fail(nullptr, ECB_ERR_HIP, "out of device memory");
     if (hipMemsetAsync(words, 0, 24, st) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "memset");
     k_cv_keys<<<nblk(n_ecs, TPB), TPB, 0, st>>>((const int*)d_indptr, n_ecs, (const int*)d_indices, (const int*)d_data, nnz, n_loci, n_haps,
@@ -4629,7 +4662,7 @@ extern "C" int ecb_hapcsc_to_csr_device(int device, uint32_t n_ecs, uint32_t n_l
     while (ebits < 32 && ((u64)1 << ebits) < n_ecs) ++ebits;
     u64* d_hs = S.get<u64>(CvScratch::X0, n_haps + 1);
     u32 *Ssum = S.get<u32>(CvScratch::X1, (u64)n_loci + 1);
-    u32 *colcnt = S.get<u32>(CvScratch::HEAD, 5ull * n_loci + 8), *sums = S.get<u32>(CvScratch::SUMS2, (u64)n_loci / SCAN_BLOCK + 8);
+    u32 *colcnt = S.get<u32>(CvScratch::HEAD, 5ull * n_loci + 8), *sums = S.get<u32>(CvScratch::SUMS2, scan_words(n_loci) + 2);
     if (!d_hs || !Ssum || !colcnt || !sums) return fail(nullptr, ECB_ERR_HIP, "out of device memory");
     u32 *colbase = colcnt + n_loci, *colcur = colbase + n_loci, *pieces = colcur + n_loci, *pbase = pieces + n_loci;
     u32* d_err = reinterpret_cast<u32*>(words);
