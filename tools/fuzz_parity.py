@@ -37,10 +37,12 @@ for seed in range(first, first + n_cases):
     # device-resident push + the exactness pass
     d = [torch.from_numpy(t[k].view(np.int32)).to(dev) for k in ("read_id", "locus", "hapflag")]
     with ecb.EcBuilder(n_loci, n_haps) as b:
+        if seed & 1:                                   # every other case with the stream's reads bounded up front (one wait per push)
+            b.hint_reads(int(exp["n_reads"]) if "n_reads" in exp else len(t["read_id"]))
         b.push_device(*d)
         sizes = b.finalize(); out = b.export()
         _check(out, sizes, exp)
-        b.reset(); b.push_device(*d)
+        b.reset(); b.push_device(*d)                   # (a handle that keeps its per-read slot ids across the reset)
         bad, _ = b.verify_device(*d)
         assert bad == 0, tag
     # the key-range protocol on one card: shards cut at read boundaries, merged per range, finalized per range, assembled
