@@ -17,7 +17,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wal
 def needs_build():
     if not os.path.exists(OUT):
         return True
-    newest = max(os.path.getmtime(p) for p in (SRC, os.path.join(HERE, "..", "include", "ecb.h")))
+    newest = max(os.path.getmtime(p) for p in (SRC, os.path.join(HERE, "csrc", "k_stream.inc"), os.path.join(HERE, "..", "include", "ecb.h")))
     return os.path.getmtime(OUT) < newest
 
 

@@ -52,9 +52,8 @@ constexpr u32 MAX_PROBE = 256;       // EC-table probes before a read is deferre
 constexpr u32 PENDING = 0xFFFFFFFFu;
 constexpr u32 ARENA_CHUNK = 512;     // pairs a wave reserves from the key arena per global atomic
 constexpr u32 ARENA_REGIONS = 64;    // the key arena has this many allocation cursors (see arena_alloc)
-constexpr u32 KBITS = 26;           // k_stream's LDS keys: locus + 1 in the low KBITS bits, the read's index within the pass above them
-constexpr u32 KMASK = (1u << KBITS) - 1u;
-constexpr u32 MAX_LOCI = KMASK - 1u;
+constexpr u32 MAX_LOCI = (1u << 26) - 2u;         // k_stream's LDS keys hold locus + 1 below the read's index within the pass: 26 bits (k_stream.inc) ...
+constexpr u32 MAX_LOCI_SHORT = (1u << 25) - 2u;   // ... 25 in the kernel for short reads (seven bits of read index)
 constexpr u32 INL = 5;               // (locus, mask) pairs of an EC's key held in its table slot; longer keys continue in the arena
 constexpr u32 DEAD_KEY = 0xFFFFFFFFu;   // Slot::n1 of a slot whose key could not be stored (arena exhausted: the run fails)
 constexpr u32 SPIN_MAX = 1u << 16;   // polls of a claimed slot's n1 before giving up (ERR_INTERNAL: the launch winds down; never seen)
@@ -261,64 +260,7 @@ constexpr int RPL = ECB_RPL;         // records per lane per tile: groups of 4 c
 static_assert(RPL == 8, "only 8 records per lane is validated (16 was measured: 233 VGPRs, 2 waves/SIMD, 11-25 % slower; it also needs a 32-bit ent[])");
 constexpr int NG = RPL / 4;          // groups; group g of lane l holds records 256 g + 4 l .. + 3 of the tile
 constexpr int WT = 64 * RPL;         // records per wave tile
-constexpr int WMAXR = 64;            // reads finished per wave tile (one lane each in phase (c))
 constexpr int NWAVE = TPB / 64;
-#ifndef ECB_WAVES_PER_SIMD
-#define ECB_WAVES_PER_SIMD 5   // 96 VGPRs, 7.4 KB of LDS per wave: five workgroups per CU (measured against four with 128 / 9.4 KB: -7.5 % on C3)
-#endif
-#ifndef ECB_LGMAX
-#define ECB_LGMAX 6            // a pass takes at most 1 << ECB_LGMAX reads (one lane each in phase (c): 6 at most)
-#endif
-#ifndef ECB_EST_MUL
-#define ECB_EST_MUL 4          // ... and is laid out for this many tiles like the one that ended the pass before
-#endif
-static_assert(ECB_LGMAX >= 0 && ECB_LGMAX <= 6, "one lane per read in phase (c)");
-constexpr int CMAX = 80;                              // (locus, mask) entries an unfinished read may carry into the next tile
-#ifndef ECB_TSLOTS
-#define ECB_TSLOTS (ECB_WAVES_PER_SIMD > 4 ? 640 : 896)
-#endif
-constexpr int TSLOTS = ECB_TSLOTS;                    // LDS table slots per wave and pass (at most WT + CMAX = 592 entries): 1.75 or 1.25 x 512
-static_assert((TSLOTS == 896 || TSLOTS == 640) && WT + CMAX < TSLOTS && (TSLOTS * 8) % (16 * 64) == 0, "home regions / a free slot / clear loop");
-constexpr u32 SBITS = 10;                             // bits of a table-slot index
-constexpr u32 SMASK = (1u << SBITS) - 1u;
-static_assert(TSLOTS <= (1 << SBITS), "ent[] packs slot | read << SBITS into 16 bits");
-struct alignas(16) WaveLds {
-    // ONE {(read, locus) -> haplotype mask} table for the reads of a pass: key = locus + 1 | read index << KBITS, mask = OR of
-    // haplotype bits.  Read r of nb probes from r * G' + (key & (G - 1)), G = 512 >> ceil(log2 nb), G' = 1.75 G: the loci of a
-    // read are mostly consecutive target ids, which the low bits never collide on, the reads' home regions are disjoint, and a
-    // read with more loci than its region simply probes on into its neighbour's (the keys say whose an entry is).  The geometry
-    // is two wave-uniform numbers; per-read extents (a scatter of head positions through LDS, a repack, a gather per record) were
-    // a fifth of the kernel's instructions.
-    // Two arrays, not one of pairs: at an 8-byte stride the compare-and-swaps of a wave land on the even banks only.
-#ifdef ECB_TAB_INTERLEAVED
-    uint2 tab[TSLOTS];
-#else
-    u32 tkey[TSLOTS];
-    u32 tmask[TSLOTS];               // (contiguous with tkey: cleared together with 16-byte stores)
-#endif
-    u64 acc[WMAXR];                  // per read: set-hash sum
-    uint2 carry[CMAX];               // the entries of the read that is still open at the end of a tile (x = locus + 1, y = mask)
-    unsigned short ent[WT + CMAX];   // table entries created in this pass: slot | read << SBITS
-    unsigned short npair[WMAXR];     // per read: number of (locus, mask) pairs
-    u32 ws[8];                       // wave scalars that are touched once in a while (scalar registers are scarcer than the few LDS reads):
-};                                   //   [0,1] head record of the open read   [2,3] key-arena reservation: next pair   [4] ... pairs left   [5,6] where a park resumes
-static_assert(sizeof(WaveLds) * NWAVE * ECB_WAVES_PER_SIMD <= 160 * 1024, "ECB_WAVES_PER_SIMD workgroups per CU");
-__device__ __forceinline__ u64 ws_get64(const WaveLds& L, int i) {
-    const u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)L.ws[i]), hi = (u32)__builtin_amdgcn_readfirstlane((int)L.ws[i + 1]);
-    return ((u64)hi << 32) | lo;
-}
-__device__ __forceinline__ void ws_put64(WaveLds& L, int i, u64 v, u32 lane) { if (lane == 0) { L.ws[i] = (u32)v; L.ws[i + 1] = (u32)(v >> 32); } }
-#ifdef ECB_TAB_INTERLEAVED
-__device__ __forceinline__ u32* tab_key(WaveLds& L, u32 q) { return &L.tab[q].x; }
-__device__ __forceinline__ u32* tab_mask(WaveLds& L, u32 q) { return &L.tab[q].y; }
-__device__ __forceinline__ uint2 tab_get(const WaveLds& L, u32 q) { return L.tab[q]; }
-__device__ __forceinline__ uint4* tab_base(WaveLds& L) { return reinterpret_cast<uint4*>(L.tab); }
-#else
-__device__ __forceinline__ u32* tab_key(WaveLds& L, u32 q) { return &L.tkey[q]; }
-__device__ __forceinline__ u32* tab_mask(WaveLds& L, u32 q) { return &L.tmask[q]; }
-__device__ __forceinline__ uint2 tab_get(const WaveLds& L, u32 q) { return make_uint2(L.tkey[q], L.tmask[q]); }
-__device__ __forceinline__ uint4* tab_base(WaveLds& L) { return reinterpret_cast<uint4*>(L.tkey); }
-#endif
 // What k_stream needs once in a while sits behind ONE pointer (scalar registers are what this kernel runs out of: every
 // kernel argument occupies a pair for the whole launch, and what does not fit is shuffled through vector lanes).
 struct StreamCold {
@@ -372,74 +314,6 @@ __device__ __forceinline__ int clamp04(int x, int, int) { return min(max(x, 0), 
 
 struct TileRegs { u32 rr[RPL], ll[RPL], hh[RPL]; };
 
-
-// Where a key goes when its first slot (home region + low locus bits) is taken by another key: a second start anywhere in the
-// table, then steps of a key-dependent stride that is coprime to the table size -- double hashing.  (Walking on slot by slot
-// from the first probe made a tile with one read of several hundred distinct loci quadratic: its entries filled its
-// neighbours' regions in one long run.)  it = probes made so far beyond the first.
-__device__ __forceinline__ u32 next_slot(u32 key, u32 q, u32 it) {
-    if (it == 0u) return __umulhi(key * 0x9E3779B1u, (u32)TSLOTS);
-    constexpr u32 ODD_FACTOR = TSLOTS == 640 ? 5u : 7u;            // 640 = 2^7 x 5, 896 = 2^7 x 7
-    u32 s = 1u + 2u * ((key >> 5) & 31u);
-    if (s % ODD_FACTOR == 0u) s += 2u;
-    q += s;
-    return q >= (u32)TSLOTS ? q - (u32)TSLOTS : q;
-}
-
-// "is the key of this slot the target set of my read?" -- the read's set is what the pass's LDS table holds under its tag,
-// probed from home + (key & pm) exactly as phase (b) inserted it.  Both sides hold distinct loci, so equal sizes and every
-// stored pair found with the same mask means the sets are equal.
-struct LdsSetCmp {
-    const WaveLds* L;
-    u32 home, pm, tag, np;           // first slot of the read's home region, G - 1, read index << KBITS, number of pairs
-    const StreamCold* cold;          // (the key arena, for keys longer than a slot: looked up when one turns up)
-    __device__ __forceinline__ int quick(const SlotView& v) const {
-        if (v.n != np) return CMP_DIFFERENT;
-        uint2 t[INL];                                    // the INL first probes are issued together: one LDS round trip for the lot
-#pragma unroll
-        for (u32 i = 0; i < INL; ++i) t[i] = tab_get(*L, i < v.n ? home + ((v.p[i].x + 1u) & pm) : home);
-        bool eq = true;
-#pragma unroll
-        for (u32 i = 0; i < INL; ++i) eq &= i >= v.n || (t[i].x == (tag | (v.p[i].x + 1u)) && t[i].y == v.p[i].y);
-        if (eq && v.n <= INL) return CMP_EQUAL;          // (the common end: every stored pair sits where its locus probes first, same mask)
-        if (!eq) {                                       // rare: a mask not written yet, a locus that probed on, or another key altogether
-#pragma unroll
-            for (u32 i = 0; i < INL; ++i) if (i < v.n && v.p[i].y == 0u) return CMP_INCOMPLETE;
-#pragma unroll
-            for (u32 i = 0; i < INL; ++i)
-                if (i < v.n && (t[i].x == 0u || (t[i].x == (tag | (v.p[i].x + 1u)) && t[i].y != v.p[i].y))) return CMP_DIFFERENT;   // certainly not in my set
-            return CMP_UNSURE;                           // something else sits at the first probe: full() walks on
-        }
-        for (u32 i = INL; i < v.n; ++i) {                // the rest of a long key, from the arena
-            const uint2 pr = unpack2(__hip_atomic_load(reinterpret_cast<u64*>(cold->arena + (u64)v.off + (i - INL)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            if (pr.y == 0u) return CMP_INCOMPLETE;
-            const uint2 tt = tab_get(*L, home + ((pr.x + 1u) & pm));
-            if (tt.x == (tag | (pr.x + 1u)) && tt.y == pr.y) continue;
-            return (tt.x == 0u || tt.x == (tag | (pr.x + 1u))) ? CMP_DIFFERENT : CMP_UNSURE;
-        }
-        return CMP_EQUAL;
-    }
-    __device__ __forceinline__ int full(Slot* s, u32 n, u32 off) const {
-        if (n != np) return CMP_DIFFERENT;
-        for (u32 i = 0; i < n; ++i) {
-            uint2 pr = i < INL ? s->pair[i] : cold->arena[(u64)off + (i - INL)];      // (plain first: a mask that shows is final)
-            if (pr.y == 0u) pr = key_pair_fresh(s, cold->arena, off, i);
-            if (pr.y == 0u) return CMP_INCOMPLETE;
-            if (pr.x >= KMASK) return CMP_DIFFERENT;     // (no read of this kernel holds such a locus)
-            const u32 key = tag | (pr.x + 1u);
-            u32 q = home + ((pr.x + 1u) & pm);
-            bool found = false;
-            for (u32 it = 0; it < (u32)TSLOTS; ++it) {   // (the table always has a free slot)
-                const uint2 t = tab_get(*L, q);
-                if (t.x == key) { found = t.y == pr.y; break; }
-                if (t.x == 0u) break;
-                q = next_slot(key, q, it);
-            }
-            if (!found) return CMP_DIFFERENT;
-        }
-        return CMP_EQUAL;
-    }
-};
 
 // -DECB_TIMING: profiling build.  Every wave adds up the shader clocks it spends in each phase of a tile (stalls are
 // charged to the phase whose s_waitcnt sits them out); k_stream adds them into StreamArgs::timing[8].
@@ -512,579 +386,17 @@ __device__ __forceinline__ void load_pos(const int* pos, u64 tb, u64 te, u32 lan
     }
 }
 
-// VERIFY = false: the hot kernel.  VERIFY = true: the exactness pass (same tiling, compares instead of inserting).
-//
-// A wave walks its slice in tiles of WT records that start at multiples of WT: every record is loaded exactly once (plus
-// the tail a slice's last read hangs into the next slice).  Reads are NOT looked up tile by tile: a *pass* collects the
-// {(read, locus) -> mask} entries of up to 1 << lg reads (at most WMAXR) from as many consecutive tiles as fit, and only then
-// is every entry hashed and every finished read looked up, one lane each -- a *flush*.  (One flush per tile left three
-// quarters of phase (c)'s lanes idle on config 3 -- fifteen reads per tile -- and paid the EC table's round trip, the per-pass
-// LDS clear and the hashing loop's ramp four times as often.)  A pass is flushed behind a tile when, going by that tile, the
-// next one would bring more records than the table has room for entries or more reads than the pass has room for; a tile whose
-// records turn out not to fit after all (every record may make an entry) is held back, still in its registers, until the pass
-// has been flushed.  The read that is open at a flush is not read again: its entries so
-// far are carried in LDS into the next pass and inserted there with the next tile's records.  A read that would carry more
-// than CMAX entries goes to k_slow.  A tile with more reads than the pass has room for (short reads) is worked off in
-// several visits: every further visit loads the tile again.
-// (RANGES: the reference_start ranges of ECB_F_RANGES updated in the same pass -- more registers, four waves per SIMD)
-template <bool VERIFY, bool RANGES = false>
-__global__ __launch_bounds__(TPB, RANGES ? 4 : ECB_WAVES_PER_SIMD) void k_stream(StreamArgs A) {
-    __shared__ WaveLds wl[NWAVE];
-    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    WaveLds& L = wl[w];
-    // Persistent waves: the launch holds only as many waves as are resident at once, and every wave takes the next
-    // unclaimed slice of the stream when it has finished one.  (Slices bound to workgroups at launch left a SIMD slot
-    // idle until the slowest of a workgroup's four waves was done, and the last round ragged: a fifth of the kernel.)
-    const u64 pw = (u64)blockIdx.x * NWAVE + w;   // this wave
-    const StreamCold* const C = A.cold;
-    static_assert(WT == 512, "tile index = record index >> 9");
-    u32 my_valid = 0, my_new = 0;                 // per lane; a wave sees far fewer than 2^32 records  (records OFFERED, bam_utils.py:261,
-                                                  //  are simply the batch's length: the host adds it)
-    u32 bad = 0;
-    // this wave's current reservation in the key arena: what the last launch left of it is used first (a stream pushed in
-    // many small batches would otherwise leave the tail of a 512-pair chunk behind per wave and launch)
-    if (!VERIFY && lane == 0) { const u64* wa = C->wave_arena; const u64 ca = wa[2 * pw]; L.ws[2] = (u32)ca; L.ws[3] = (u32)(ca >> 32); L.ws[4] = (u32)wa[2 * pw + 1]; }
-#ifdef ECB_TIMING
-    u64 tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
-#endif
-    // this wave's per-pass LDS state: table, hash sums, pair counts -- cleared here and behind every flush
-    auto clear_pass = [&](u32 ln) {
-        uint4* z = tab_base(L);
-        u32 zz;
-        asm volatile("v_mov_b32 %0, 0" : "=v"(zz));          // (a zero the compiler cannot keep in four registers across the loop)
-        const uint4 zv = make_uint4(zz, zz, zz, zz);
-#pragma unroll
-        for (int t = 0; t < (TSLOTS * 8) / (16 * 64); ++t) z[t * 64 + ln] = zv;
-        *reinterpret_cast<uint2*>(&L.acc[ln]) = make_uint2(zz, zz); L.npair[ln] = (unsigned short)zz;
-    };
-    clear_pass(lane);                             // (every slice leaves the table as it found it: empty)
-    wave_sync();
-  for (;;) {
-    u32 wid = 0;                                  // the slice (fewer than 2^32 of them: a slice is at least a tile)
-    if (lane == 0) wid = (u32)atomicAdd(&A.ctr->next_slice, 1ull);
-    wid = (u32)__builtin_amdgcn_readfirstlane((int)wid);
-    const u64 chunk = C->chunk;
-    const u64 c0 = (u64)wid * chunk;              // (a multiple of WT)
-    if (c0 >= A.n) break;
-    const u64 c1 = min(c0 + chunk, A.n);
-    // resume point: the first record not yet consumed by a finished read (a fresh slice: c0; after a park: the head of the
-    // read that was open, or the tile that was next), and how far the slice's records have been counted
-    const u64 p = C->resume[2 * (u64)wid], counted0 = C->resume[2 * (u64)wid + 1];
-    if (p >= A.n || p == ~0ull) continue;         // finished before a relaunch
-    // The loop below thinks in tiles (32-bit indices: scalar registers are scarce): tile t covers records [512 t, 512 t + 512)
-    u32 tix = (u32)(p >> 9);                      // the tile to work on
-    const u32 c1t = (u32)((c1 + (u64)(WT - 1)) >> 9);             // my slice ends before this tile
-    const u32 last_t = (u32)((A.n - 1) >> 9);                     // the stream's last tile ...
-    const u32 last_rel = (u32)(A.n - ((u64)last_t << 9));         // ... and how many records it holds
-    const u32 counted_t = (u32)((counted0 + (u64)(WT - 1)) >> 9); // tiles before this one have been counted (after a park)
-    int p_rel = (int)(p - ((u64)tix << 9));       // (only matters in the first tile after a park)
-    // read id of the record before the tile; the first head at or after p starts read prev + 1, and records before it that
-    // are not heads belong to the read before (not mine)
-    u32 prev = p == 0 ? C->prev_rid : A.rid[p - 1];
-    // The pass: reads pb .. pb + npend - 1 are complete and wait for their lookup, read pb + npend is open (if `open`; the
-    // record index of its head: L.ws[0..1]).  Invariant at the start of a tile's first visit: pb + npend + open == prev + 1,
-    // the id of the next read to start.
-    // The record the slice is taken up at after a park: the head of read pb, or a tile boundary before it -- L.ws[5..6].
-    u32 pb = prev + 1u, npend = 0, n_ent = 0;     // n_ent: entries in L.ent (complete reads' and the open read's)
-    ws_put64(L, 5, p, lane);
-    bool open = false;
-    u32 carry_n = 0;                              // entries in L.carry: the open read's, waiting to go into the fresh table
-    u32 lg = ECB_LGMAX;                           // the pass has room for 1 << lg reads (see WaveLds: the table's geometry)
-    bool revisit = false;                         // the tile has been visited before (more reads in it than a pass takes)
-    TileRegs R;
-    load_tile(A, (u64)tix << 9, min(((u64)tix << 9) + (u64)WT, A.n), lane, R);
-    int r_pos[RANGES ? RPL : 1];                  // ECB_F_RANGES: reference_start of the tile's records, prefetched with them
-    if constexpr (RANGES) load_pos(C->pos, (u64)tix << 9, min(((u64)tix << 9) + (u64)WT, A.n), lane, r_pos);
-    u32 parked = __hip_atomic_load(&A.ctr->full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("" : "+v"(parked));          // (settled before the loop: otherwise the loop header carries an s_waitcnt vmcnt(0) that every tile pays)
-    bool slice_done = false;
-
-    while (!slice_done) {
-        // the EC table filled up somewhere: the host grows it and relaunches.  What the pass holds is dropped: the slice is taken up
-        // again at the head of the pass's first read (L.ws[5..6]), and looking a read up twice changes nothing.
-        if (__builtin_amdgcn_readfirstlane((int)parked)) break;
-                                      // (readfirstlane: every lane loaded the same word; said so, the loop is uniform to the compiler --
-                                      //  as a per-lane condition it dragged exec-mask bookkeeping through every block of the tile)
-        // (opaque per tile: the LDS addresses and constants derived from the lane index are cheap to recompute; hoisted out of
-        //  the loop they sat in registers the tile needs, and what did not fit was spilled and re-loaded BEHIND the prefetch)
-        u32 ln = lane;
-        asm volatile("" : "+v"(ln));
-        tix = (u32)__builtin_amdgcn_readfirstlane((int)tix);
-        prev = (u32)__builtin_amdgcn_readfirstlane((int)prev);
-        pb = (u32)__builtin_amdgcn_readfirstlane((int)pb);
-        npend = (u32)__builtin_amdgcn_readfirstlane((int)npend);
-        n_ent = (u32)__builtin_amdgcn_readfirstlane((int)n_ent);
-        lg = (u32)__builtin_amdgcn_readfirstlane((int)lg);
-        // The table's geometry (see WaveLds): two wave-uniform numbers
-        const u32 pm = (512u >> lg) - 1u, gp = (512u >> lg) + (TSLOTS == 896 ? (256u >> lg) : 0u) + (128u >> lg);
-        bool do_flush = false, again = false, more = false;
-        bool preflush = false;                     // this tile's records might not fit the pass's table: flush first, then take the tile again
-        bool taken = false;                        // the prefetched tile has been waited for (on this path)
-        u32 parked_next = parked;
-        u32 last_pos = 0xFFFFFFFFu;                // tile-relative head of the tile's last read, if it started here (it may stay open)
-        u32 last_rid = prev;
-        u32 est = 64;                              // reads a tile brings, going by this one: the next pass's geometry
-        const bool ends = tix == last_t;           // batches end on a read boundary
-        const bool own = tix < c1t;               // heads in this tile start reads of my slice (tiles do not straddle its end)
-        const int te_rel = ends ? (int)last_rel : WT;
-        // records offered / valid are counted tile by tile: every tile of my slice once (after a park the tiles before the
-        // one that was next have been counted: `counted0` is a tile boundary)
-        const bool count_tile = own && tix >= counted_t && !revisit;
-        const bool plain = p_rel == 0 && te_rel == WT;      // a whole tile, nothing masked: all but the first after a park / the last of the stream
-        // ---- (a) filter, heads -------------------------------------------------------------------
-        // Written with integer bit arithmetic throughout: every instruction costs an issue slot, and
-        // compare -> mask -> select chains were a third of this kernel's instruction count.
-        // Per record: its LDS key (locus + 1 | index of its read within the pass << KBITS) and its haplotype bit -- all that
-        // phase (b) needs of it; which records phase (b) takes at all (valid, of a read of this pass) is settled here too:
-        // reads are numbered consecutively by the run counter, so "one of the pass's reads" is one unsigned comparison.
-        u32 r_key[RPL], r_bit[RPL];
-        u32 m_act = 0, m_head = 0;                 // bit k: valid record of a read of this pass / head
-        const u32 lim = own ? (1u << lg) : (open ? npend + 1u : 0u);   // (past my slice only the open read is mine)
-        // Most tiles lie wholly inside the pass: their first record belongs to a read of the pass (the open one, or the first to start)
-        // and their last read still has room -- then every record is "mine" and the per-record test is not made.
-        const u32 rid_first = (u32)__builtin_amdgcn_readfirstlane((int)R.rr[0]), rid_last = (u32)__builtin_amdgcn_readlane((int)R.rr[RPL - 1], 63);
-        const bool all_mine = rid_first - pb < lim && rid_last - pb < lim && rid_last >= rid_first;
-        {
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const int i0 = g * 256 + 4 * (int)ln;
-                // the record before this group's first: the previous ln's last record of the group, or (ln 0) the
-                // previous group's very last record
-                const u32 up = lane_above(R.rr[4 * g + 3]);
-                const u32 wrap = g == 0 ? prev : (u32)__builtin_amdgcn_readlane((int)R.rr[4 * (g > 0 ? g - 1 : 0) + 3], 63);
-                u32 in4 = 0xFu, te4 = 0xFu;                                      // records of the tile / at or after p
-                if (!plain) {
-                    te4 = (1u << clamp04(te_rel - i0, 0, 4)) - 1u;
-                    in4 = te4 & ~((1u << clamp04(p_rel - i0, 0, 4)) - 1u);
-                }
-                const u32 prev0 = ln == 0 ? wrap : up;
-                u32 ok4 = 0, head4 = 0, hap_or = 0, mine4 = 0;
-#pragma unroll
-                for (int j = 3; j >= 0; --j) {
-                    // record filter (bam_utils.py:264-270): not unmapped, and if paired: read1, proper, mate on the same
-                    // reference, next_pos >= 0  <=>  ((f ^ 2) & 0x3082) == 0.  Worked out in the sign bit: x - 1 is negative only
-                    // for x = 0, a shift puts a flag bit there, and one funnel shift moves the verdict into the group's mask.
-                    const u32 f = R.hh[4 * g + j];
-                    const u32 pair_ok = ((f & 0x3082u) ^ 0x2u) - 1u;                              // bit 31
-                    const u32 ok31 = ~(f << 29) & (~(f << 31) | pair_ok);                        // bit 31: !unmapped && (!paired || pair_ok)
-                    ok4 = __builtin_amdgcn_alignbit(ok4, ok31, 31);                              // ok4 = ok4 << 1 | verdict
-                }
-                // The rest is per record position, and only for positions at which SOME lane holds a valid record: in a paired-end
-                // stream every second record is a mate the filter drops -- wave-uniform branches, two positions each.
-#pragma unroll
-                for (int par = 0; par < 2; ++par) {
-                    if (__ballot((ok4 & (par ? 0xAu : 0x5u)) != 0u) != 0ull) {
-#pragma unroll
-                        for (int j = par; j < 4; j += 2) {
-                            const int k = 4 * g + j;
-                            const u32 f = R.hh[k];
-                            const u32 step = R.rr[k] - (j == 0 ? prev0 : R.rr[k > 0 ? k - 1 : 0]);
-                            const u32 relx = R.rr[k] - pb;                   // (records of reads before the pass's first: huge)
-                            const u32 t = R.ll[k] + 1u;
-                            r_key[k] = t | (relx << KBITS);
-                            r_bit[k] = 1u << ((f >> ECB_HAP_SHIFT) & 31u);
-                            // (a haplotype index of 32 or more would alias a low one, a locus of KMASK or more the read tag of the
-                            //  LDS keys: both show in the bits from 21 up)
-                            hap_or |= ((t & ~KMASK) | f) & (u32)((int)(ok4 << (31 - j)) >> 31);
-                            head4 |= (step & 1u) << j;
-                            if (!all_mine) mine4 |= (relx < lim ? 1u : 0u) << j;
-                        }
-                        if constexpr (RANGES) {
-                            // reference_start ranges per target (bam_utils.py:282-286), in the pass that has the record in registers anyway:
-                            // the 2 x n_loci x n_haps bounds stay in L2, and a record only issues an atomic when it moves a bound (almost
-                            // none do after the first few thousand).  Re-running a tile (park, further visits) changes nothing: min / max.
-                            if (!revisit) {
-                                const u32 nl = C->n_loci, nh = C->n_haps;
-                                int2* const rng = C->rng;
-                                u32 sl[2]; int2 cur[2]; bool go[2];
-#pragma unroll
-                                for (int j = par; j < 4; j += 2) {
-                                    const int k = 4 * g + j;
-                                    const u32 lc = R.ll[k], hap = (R.hh[k] >> ECB_HAP_SHIFT) & 0xFFu;
-                                    go[j >> 1] = ((ok4 >> j) & 1u) && lc < nl && hap < nh;       // (out of range: reported at emit)
-                                    sl[j >> 1] = lc * nh + hap;
-                                    cur[j >> 1] = make_int2(0, 0);
-                                    if (go[j >> 1]) cur[j >> 1] = rng[sl[j >> 1]];
-                                }
-#pragma unroll
-                                for (int j = par; j < 4; j += 2) {
-                                    const int ps = r_pos[RANGES ? 4 * g + j : 0];
-                                    if (go[j >> 1] && ps < cur[j >> 1].x) atomicMin(&rng[sl[j >> 1]].x, ps);
-                                    if (go[j >> 1] && ps > cur[j >> 1].y) atomicMax(&rng[sl[j >> 1]].y, ps);
-                                }
-                            }
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = par; j < 4; j += 2) {   // (no lane has a record at these positions: any value will do, none is used)
-                            asm volatile("" : "=v"(r_key[4 * g + j])); asm volatile("" : "=v"(r_bit[4 * g + j]));
-                        }
-                    }
-                }
-                // the run counter may only step by 0 or 1, and only on a valid record: then, and only then, the steps seen at the
-                // valid positions add up to the whole difference
-                const u32 big = (u32)(R.rr[4 * g + 3] - prev0 != (u32)__popc(head4));
-                if (count_tile) my_valid += __popc(ok4 & te4);
-                ok4 &= in4; head4 &= in4;
-                bad |= ((p_rel == 0 ? big : 0u) | (head4 & ~ok4)) ? ERR_CONTRACT : 0u;   // (the tile a park resumes in was checked before the park)
-                bad |= (hap_or >> (ECB_HAP_SHIFT + 5)) ? ERR_RANGE : 0u;      // (indices below 32 are checked against n_haplotypes per EC, at emit)
-                m_act |= (all_mine ? ok4 : (ok4 & mine4)) << (4 * g); m_head |= head4 << (4 * g);
-            }
-        }
-        TICK(0);
-        if (__ballot(bad != 0u)) break;            // never index LDS with a broken run counter
-        const u32 cnts = wave_sum((u32)__popc(m_head) | ((u32)__popc(m_act) << 16));
-        const u32 nheads = cnts & 0xFFFFu, n_mine = cnts >> 16;   // heads; records that go into the pass's table
-        last_rid = (u32)__builtin_amdgcn_readlane((int)R.rr[RPL - 1], 63);   // (of a full tile; a short one ends the stream)
-        // Reads with records in this tile that are mine: the open one (index npend of the pass) and one per head whose read has not
-        // been dealt with on an earlier visit -- heads number their reads prev + 1 ..., the next read to start is pb + npend + open.
-        // All but the last are complete here; the last one is too if the stream ends with the tile.  In a tile past my slice only
-        // the open read is mine, and it is complete as soon as a head shows up.
-        const u32 o1 = open ? 1u : 0u;
-        const u32 n_new = own ? (prev + 1u + nheads) - (pb + npend + o1) : 0u;
-        const u32 n_in = o1 + n_new;
-        est = n_in;
-        // Every record may make an entry of its own.  Behind a flush a tile always fits (CMAX carried entries + WT records); a pass that
-        // has taken tiles before was judged, after the last of them, to have room for one more like it -- when that turns out wrong
-        // (rare), the pass is flushed with the tile untouched in its registers and the tile is then taken again.
-        if (n_ent + carry_n + n_mine > (u32)(WT + CMAX)) { preflush = true; do_flush = true; }
-        else {
-        if (own) {
-            if (npend + n_in > (1u << lg)) { again = true; npend = 1u << lg; open = false; }      // (the reads that fit are all complete: more follow)
-            else if (n_in) { npend += ends ? n_in : n_in - 1u; open = !ends; }
-        } else if (open && (nheads || ends)) { npend += 1u; open = false; }
-        more = !ends && (tix + 1u < c1t || open);
-        TICK(1);
-        // ---- prefetch the next tile while this one is hashed and looked up --------------------------
-        // Into the SAME registers: phase (a) has turned the tile into keys and bits, nothing reads R again.  The lane offset of
-        // the loads is made to depend on phase (a)'s results, so that the scheduler cannot start them while R is still being read
-        // (it did, and a second set of 24 registers plus 24 moves per tile was the price).
-        if (more || again) {
-            u32 lp = ln;
-#pragma unroll
-            for (int k = 0; k < RPL; ++k) asm volatile("" : "+v"(lp) : "v"(r_key[k]), "v"(r_bit[k]));
-            asm volatile("" : "+v"(lp) : "v"(m_act), "v"(m_head), "v"(bad), "v"(my_valid));
-            const u64 nt = (u64)(again ? tix : tix + 1u) << 9;
-            load_tile(A, nt, min(nt + (u64)WT, A.n), lp, R);
-            if constexpr (RANGES) load_pos(C->pos, nt, min(nt + (u64)WT, A.n), lp, r_pos);
-            parked_next = __hip_atomic_load(&A.ctr->full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (!again) {                                               // head of the tile's last read (kept if it stays open): the tile's last head
-            const u64 h1 = __ballot((m_head >> 4) != 0u), h0 = __ballot((m_head & 15u) != 0u);
-            if (h1 | h0) {
-                const u32 l = 63u - (u32)__builtin_clzll(h1 ? h1 : h0);
-                const u32 bits = (u32)__builtin_amdgcn_readlane((int)m_head, (int)l);
-                const u32 k = 31u - (u32)__builtin_clz(h1 ? bits & 0xF0u : bits & 0xFu);
-                last_pos = (k & 3u) + (k >> 2) * 256u + 4u * l;
-            }
-            if (open && last_pos != 0xFFFFFFFFu) ws_put64(L, 0, ((u64)tix << 9) + last_pos, ln);   // (else: the open read stays the open read)
-        }
-
-        // ---- (b) the pass's {(read, locus) -> haplotype mask} table in LDS ------------------------------------
-        // Staged so that the 8 records' LDS round trips overlap: compare-and-swap on the key, OR of the bit.
-        // A ln whose CAS created an entry queues it; every entry is hashed once, at the flush, when all masks are final.
-        TICK(2);
-        if (!ABL(A, 1u)) {
-            // What the open read brought along from the pass before goes in WITH the records, as one more compare-and-swap per lane in the same
-            // round (a chain of LDS round trips of its own cost a fifth of the tile): entry c of the carry list is lane c's
-            // ninth "record" -- its haplotype "bit" is the whole mask so far.  (More than 64 of them: a second such round.)
-            const bool cin = carry_n != 0u;                      // (only right behind a flush: the open read is read 0 of the pass, tag 0)
-            u32 q[RPL + 1], old[RPL + 1], act = m_act;
-            bool anyc = false;                                   // some lane found its first slot taken by another (read, locus)
-            u32 c_key = 0, c_bit = 0;
-            if (cin && ln < carry_n) { const uint2 cv = L.carry[ln]; c_key = cv.x; c_bit = cv.y; act |= 1u << RPL; }
-            // Two rounds: the even record positions (and the carried entry), then the odd ones -- nine compare-and-swap
-            // results in flight at once are more registers than the kernel has, and in a paired-end stream the odd (or the
-            // even) positions are the mate records, which the filter drops: a round no lane has a record in is skipped.
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const u32 hmask = h ? 0x0AAu : 0x155u;           // positions of this round (bit RPL: the carried entry)
-                if (__ballot((act & hmask) != 0u) == 0ull) continue;
-#pragma unroll
-                for (int k = h; k <= RPL; k += 2) {  // (lanes without a record here swap nothing: they expect a value no slot ever holds, at a slot of their own)
-                    const u32 key = k < RPL ? r_key[k < RPL ? k : 0] : c_key;
-                    q[k] = (act >> k & 1u) ? (key >> KBITS) * gp + (key & pm) : ln;
-                }
-#pragma unroll
-                for (int k = h; k <= RPL; k += 2)
-                    old[k] = atomicCAS(tab_key(L, q[k]), (act >> k & 1u) ? 0u : 0xFFFFFFFFu, k < RPL ? r_key[k < RPL ? k : 0] : c_key);
-#pragma unroll
-                for (int k = h; k <= RPL; k += 2) {
-                    const u32 key = k < RPL ? r_key[k < RPL ? k : 0] : c_key, bit = k < RPL ? r_bit[k < RPL ? k : 0] : c_bit;
-                    const bool on = act >> k & 1u;
-                    const bool made = on && old[k] == 0u;                // this lane created the (read, locus) entry
-                    const bool hit = made || (on && old[k] == key);
-                    anyc |= on && !hit;
-                    atomicOr(tab_mask(L, q[k]), hit ? bit : 0u);         // duplicate (read, target) records vanish here: bam_utils.py:322-325
-                    const u64 mm = __ballot(made);
-                    if (made) L.ent[n_ent + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u))] =
-                        (unsigned short)(q[k] | ((key >> KBITS) << SBITS));
-                    n_ent += (u32)__popcll(mm);
-                }
-            }
-            if (__ballot(anyc) || (cin && carry_n > 64u)) {
-                // Rare: probe on.  Every record goes through the whole protocol once more (its first slot again, then the ones
-                // behind it): the lanes the rounds above served find their own entry and OR the same bit into it.
-                if (__ballot(anyc)) {
-#pragma unroll
-                    for (int k = 0; k <= RPL; ++k) {
-                        const u32 key = k < RPL ? r_key[k < RPL ? k : 0] : c_key, bit = k < RPL ? r_bit[k < RPL ? k : 0] : c_bit;
-                        u32 qq = (key >> KBITS) * gp + (key & pm);
-                        bool made = false;
-                        if (act >> k & 1u) {
-                            u32 o, it = 0;                       // (the table always has a free slot: the bound only keeps corrupted
-                            for (;;) {                           //  state from spinning a wave for ever)
-                                o = atomicCAS(tab_key(L, qq), 0u, key);
-                                if (o == 0u || o == key || it >= (u32)TSLOTS) break;
-                                qq = next_slot(key, qq, it); ++it;
-                            }
-                            if (o != 0u && o != key) bad |= ERR_INTERNAL;
-                            else { made = (o == 0u); atomicOr(tab_mask(L, qq), bit); }
-                        }
-                        const u64 mm = __ballot(made);
-                        if (made) L.ent[n_ent + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u))] =
-                            (unsigned short)(qq | ((key >> KBITS) << SBITS));
-                        n_ent += (u32)__popcll(mm);
-                    }
-                }
-                if (cin && carry_n > 64u) {                          // carried entries 64 .. CMAX - 1: a (rare) round of their own
-                    const bool go = ln + 64u < carry_n;
-                    const uint2 cv = L.carry[go ? ln + 64u : 0u];
-                    u32 qq = cv.x & pm;
-                    bool made = false;
-                    if (go) {
-                        u32 o, it = 0;
-                        for (;;) {
-                            o = atomicCAS(tab_key(L, qq), 0u, cv.x);
-                            if (o == 0u || o == cv.x || it >= (u32)TSLOTS) break;
-                            qq = next_slot(cv.x, qq, it); ++it;
-                        }
-                        if (o != 0u && o != cv.x) bad |= ERR_INTERNAL;
-                        else { made = (o == 0u); atomicOr(tab_mask(L, qq), cv.y); }
-                    }
-                    const u64 mm = __ballot(made);
-                    if (made) L.ent[n_ent + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u))] = (unsigned short)qq;
-                    n_ent += (u32)__popcll(mm);
-                }
-            }
-            carry_n = 0;
-        }
-        TICK(3);
-        // Flush now?  The stream or my slice ends here; the tile is not done (more reads in it than the pass had room for); or, going
-        // by this tile, the next one would bring more records than the table has room for entries, or more reads than the pass has room for.
-        do_flush = (npend != 0u || open) &&
-                   (!more || again || n_ent + n_mine > (u32)(WT + CMAX) || npend + (open ? 1u : 0u) + n_new > (1u << lg));
-        }
-
-        bool giant = false;
-        u32 new_carry = 0;
-        if (do_flush) {
-            wave_sync();
-            // every entry is hashed once, now that its mask is final; the entries of a read that stays open are not: they go to
-            // the carry list instead (same pass over the queue, no LDS round trips of their own)
-            u32 cn = 0;
-            const u32 rl_last = npend;                               // the open read's index in the pass: its entries are kept
-            const bool keep = open;
-            for (u32 e0 = 0; e0 < n_ent; e0 += 64) {
-                const u32 e = e0 + ln;
-                const bool have = e < n_ent;
-                const u32 en = have ? L.ent[e] : 0u, qq = en & SMASK, rl = en >> SBITS;
-                const uint2 en2 = tab_get(L, qq);
-                const bool kept = have && keep && rl == rl_last;
-                if (have && !kept) {
-                    atomicAdd(&L.acc[rl], pair_hash64((en2.x & KMASK) - 1u, en2.y));
-                    atomicAdd(reinterpret_cast<u32*>(&L.npair[rl & ~1u]), (rl & 1u) ? 0x10000u : 1u);   // two 16-bit counters per word
-                }
-                if (keep) {
-                    const u64 mm = __ballot(kept);
-                    const u32 at = cn + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u));
-                    if (kept && at < (u32)CMAX) L.carry[at] = make_uint2(en2.x & KMASK, en2.y);
-                    cn += (u32)__popcll(mm);
-                }
-            }
-            if (keep) { new_carry = cn; giant = cn > (u32)CMAX; }
-            wave_sync();
-
-            TICK(4);
-            // ---- (c) one ln per read: EC lookup with exact key compare; a new EC gets its key from the pass's LDS table ---------
-            u64 j = 0;
-            u32 st = ST_NONE, probes = 0, np = 0, fseen = 0;       // fseen: ~(first read) as the slot's line showed it (0 = nothing yet)
-            u64 lo = 0;
-            const bool on = ln < npend && !ABL(A, 3u);
-            const u32 rd = pb + ln;
-            LdsSetCmp cmp;
-            cmp.L = &L; cmp.cold = C; cmp.home = ln * gp; cmp.pm = pm; cmp.tag = ln << KBITS; cmp.np = 0;
-            if (on) {
-                np = L.npair[ln];
-                cmp.np = np;
-                lo = finish_hash(L.acc[ln], np);
-                j = lo & A.cap_mask;
-                if ((u64)rd >= A.reads_hi) bad |= ERR_CONTRACT;          // the run counter ran past what this batch announced
-                else st = ST_LOOK;
-            }
-            if (VERIFY) {                                               // exactness pass: set of this read == key of its EC ?
-                if (st == ST_LOOK) {
-                    const u32 sl = A.read_slot[rd];
-                    bool same = false;
-                    if (sl != PENDING) {
-                        const uint4* q = reinterpret_cast<const uint4*>(A.table + sl);
-                        const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
-                        if (a.z != 0u && a.z != DEAD_KEY) {
-                            int r = cmp.quick(make_view(a, b, c, d));
-                            if (r == CMP_UNSURE) r = cmp.full(A.table + sl, a.z - 1u, a.w);
-                            same = r == CMP_EQUAL;
-                        }
-                    }
-                    if (!same) my_new += 1;                             // (counted as "mismatches" in verify mode)
-                }
-                parked = parked_next; taken = true;
-                        } else {
-                // Lookup; founders publish their keys; THEN lanes whose slot was claimed but not (visibly) complete settle it --
-                // the founder such a ln waits for may be a ln of this very wave.  One round in all but a handful of flushes.
-                for (u32 round = 0;; ++round) {
-                    if (st == ST_LOOK) {
-                        if (ABL(A, 64u)) { st = ST_HIT; fseen = 0xFFFFFFFFu; }   // (profiling: no table access at all, no first-read atomic)
-                        else if (ABL(A, 4u)) st = ST_HIT;
-                        else st = table_lookup(A.table, A.cap_mask, lo, j, probes, cmp, ABL(A, 24u), &fseen);
-                    }
-                    if (round == 0u) {
-                        TICK(5);
-                        // Take over the prefetched tile HERE, right behind the lookup's own wait and before this flush issues any store.
-                        // vmcnt counts in order: wherever the compiler first touches these registers it waits for everything issued before
-                        // that point, and at the end of the tile (where the moves sink to if left alone) or at the top of the next one
-                        // (the parked flag) that meant sitting out the round trips of the founders' stores -- ~3000 clocks per tile on C3.
-                        parked = parked_next; taken = true;
-                    #pragma unroll
-                        for (int k = 0; k < RPL; ++k) {
-                            asm volatile("" : "+v"(R.rr[k])); asm volatile("" : "+v"(R.ll[k])); asm volatile("" : "+v"(R.hh[k]));
-                            if constexpr (RANGES) asm volatile("" : "+v"(r_pos[k]));
-                        }
-                        asm volatile("" : "+v"(parked));
-                    }
-                    const u64 cmask = __ballot(st == ST_CREATED);
-                    if (cmask) {
-                        const bool cr = st == ST_CREATED;
-                        const u32 want = cr && np > INL ? np - INL : 0u;    // pairs beyond the slot's own go to the key arena
-                        u32 off = 0;
-                        if (__ballot(want != 0u)) {
-                            const u32 incl = wave_incl_scan(want);
-                            const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
-                            u64 chunk_at = ws_get64(L, 2);
-                            u32 chunk_left = (u32)__builtin_amdgcn_readfirstlane((int)L.ws[4]);
-                            if (total > chunk_left) {                       // reserve another stretch of the key arena
-                                const u32 take = max(total, ARENA_CHUNK);
-                                u64 at = 0;
-                                if (ln == 0) at = arena_alloc(A.ctr, C->arena_cap, take, (u32)pw);
-                                chunk_at = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(at >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)at);
-                                chunk_left = take;
-                                if (chunk_at == ~0ull) { bad |= ERR_ARENA; chunk_left = 0; }
-                            }
-                            if (!(bad & ERR_ARENA)) {
-                                off = (u32)(chunk_at + (incl - want));       // the arena holds < 2^32 pairs (Slot::off)
-                                chunk_at += total; chunk_left -= total;
-                            }
-                            ws_put64(L, 2, chunk_at, ln);
-                            if (ln == 0) L.ws[4] = chunk_left;
-                        }
-                        const bool dead = (bad & ERR_ARENA) != 0u;           // no room for a long key: the run fails; the slots are marked, not left claimed
-                        // The keys are copied by the whole wave from the pass's entry queue (every (read, locus) entry once, any
-                        // order: rows are sorted when they are emitted), not by the founding ln walking its read's table:
-                        // that serial walk with 1-3 lanes alive was ~400 issue slots per tile, a quarter of the kernel.
-                        const u32 j32 = (u32)j;
-                        uint2* const arena = C->arena;
-                        if (!dead) for (u32 e0 = 0; e0 < n_ent; e0 += 64) {
-                            const u32 e = e0 + ln;
-                            const u32 en = e < n_ent ? L.ent[e] : 0u, qq = en & SMASK, rl = en >> SBITS;
-                            const u32 o = __shfl(off, rl), jj = __shfl(j32, rl);            // (all lanes: the loop bound is uniform)
-                            if (e < n_ent && (cmask >> rl & 1ull) && !ABL(A, 32u)) {    // (32: profiling, no key stores)
-                                const u32 was = atomicSub(reinterpret_cast<u32*>(&L.npair[rl & ~1u]), (rl & 1u) ? 0x10000u : 1u);
-                                const u32 pos = ((rl & 1u) ? was >> 16 : was & 0xFFFFu) - 1u;   // a place of its own among the read's pairs
-                                uint2* dst = pos < INL ? &A.table[jj].pair[pos] : arena + ((u64)o + (pos - INL));
-                                const uint2 en2 = tab_get(L, qq);
-                                store_wt64(reinterpret_cast<u64*>(dst), pack2(make_uint2((en2.x & KMASK) - 1u, en2.y)));
-                            }
-                        }
-                        if (cr) { publish_key(A.table + j, dead ? DEAD_KEY : np + 1u, off); st = ST_HIT; }   // (no wait: readers tell a whole key from its masks)
-                        my_new += (u32)__popcll(cmask);
-                    }
-                    if (!__ballot(st == ST_PENDING)) break;
-                    if (round >= 64u) { if (st == ST_PENDING) { bad |= ERR_INTERNAL; st = ST_NONE; } break; }
-                    if (st == ST_PENDING) {
-                        const int r = table_settle(A.table + j, cmp);
-                        if (r == ST_HIT) st = ST_HIT;
-                        else if (r == ST_STUCK) { bad |= ERR_INTERNAL; st = ST_NONE; atomicExch(&A.ctr->full, 1u); }   // (every wave stops at its next tile)
-                        else { j = (j + 1) & A.cap_mask; ++probes; st = ST_LOOK; }
-                    }
-                }
-                if (st == ST_FULL) {                                    // table too full here: defer the read, park
-                    atomicExch(&A.ctr->full, 1u);
-                    const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
-                    // (its head: the first record of the read among those of my slice up to the tile in hand -- the run counter never decreases)
-                    const u64 head = tile_head(A.rid, (u64)wid * C->chunk, min(((u64)tix << 9) + (u64)WT, A.n), rd);
-                    if (qi < C->queue_cap) C->queue[qi] = head; else atomicOr(&A.ctr->err, ERR_QUEUE);
-                } else if (st == ST_HIT) {
-                    A.read_slot[rd] = (u32)j;
-                    // First appearance of the EC (bam_utils.py:682-698: rank = first-seen order), kept current here: an old copy
-                    // of the line can only show a LATER first read, so the comparison errs on the side of one more atomic.
-                    if (~rd > fseen) atomicMax(&A.table[j].first_inv, ~rd);
-                }
-            }
-            wave_sync();
-            // the next pass: an empty table, its read 0 the read after the ones just looked up (the open one, if there is one)
-            clear_pass(ln);
-            pb += npend; npend = 0; n_ent = 0;
-            const u32 e4 = min(est * (u32)ECB_EST_MUL, 1u << ECB_LGMAX);
-            lg = e4 > 1u ? 32u - (u32)__builtin_clz(e4 - 1u) : 0u;    // room for four tiles like this one, 64 reads at most
-            if (open) {
-                if (!giant) carry_n = new_carry;
-                else {                                               // more entries than a pass carries over: one workgroup for this read (k_slow)
-                    if (ln == 0) {
-                        const u64 head = ws_get64(L, 0);
-                        const u64 qi = atomicAdd(&A.ctr->n_queue, 1ull);
-                        if (qi < C->queue_cap) C->queue[qi] = head; else atomicOr(&A.ctr->err, ERR_QUEUE);
-                    }
-                    open = false; pb += 1u;                           // (the rest of a giant read is skipped: not a head, not open, not mine)
-                }
-            }
-            ws_put64(L, 5, open ? ws_get64(L, 0) : (u64)((preflush || again) ? tix : tix + 1u) << 9, ln);
-            wave_sync();
-            TICK(6);
-        }
-        if (preflush) { revisit = true; continue; }                  // (the tile is still in its registers: nothing was prefetched over it)
-        if (!taken) {                                                // no flush behind this tile: the prefetched one is waited for here
-            parked = parked_next;
-        #pragma unroll
-            for (int k = 0; k < RPL; ++k) {
-                asm volatile("" : "+v"(R.rr[k])); asm volatile("" : "+v"(R.ll[k])); asm volatile("" : "+v"(R.hh[k]));
-                if constexpr (RANGES) asm volatile("" : "+v"(r_pos[k]));
-            }
-            asm volatile("" : "+v"(parked));
-        }
-        if (again) { revisit = true; continue; }                     // same tile, the reads after the ones just looked up (p_rel stays: the tile is loaded again)
-        revisit = false; p_rel = 0;
-        prev = last_rid;
-        slice_done = !more;
-        tix += 1u;
-    }
-    // where a relaunch takes this slice up: at the head of the first read that has not been looked up
-    u64 p_out = ws_get64(L, 5);
-    const u64 counted = max(counted0, min((u64)(revisit ? tix + 1u : tix) << 9, c1));   // (every tile before tix has been counted; tix itself once its first visit is through)
-    const bool stopped = __ballot(bad != 0u) || __builtin_amdgcn_readfirstlane((int)parked);
-    if (__ballot(bad != 0u)) { if (bad) atomicOr(&A.ctr->err, bad); p_out = ~0ull; }
-    else if (slice_done) p_out = ~0ull;
-    if (lane == 0) { u64* rs = C->resume; rs[2 * (u64)wid] = p_out; rs[2 * (u64)wid + 1] = counted; }
-    if (stopped) break;
-  }
-    // records offered / valid: one atomic pair per wave
-    const u32 wa = 0u, wv = wave_sum(my_valid);
-    // per-wave totals go to their own words: thousands of waves adding to three shared counters serialise (~50 ns each)
-    const u32 wn = VERIFY ? wave_sum(my_new) : my_new;
-#ifdef ECB_TIMING
-    if (lane == 0 && C->timing) for (int i = 0; i < 8; ++i) atomicAdd(C->timing + i, tacc[i]);
-#endif
-    if (lane == 0) { u32* wc = C->wave_counts; wc[3 * pw] = wa; wc[3 * pw + 1] = wv; wc[3 * pw + 2] = wn; }
-    if (!VERIFY && lane == 0) { u64* wav = C->wave_arena; wav[2 * pw] = ((u64)L.ws[3] << 32) | L.ws[2]; wav[2 * pw + 1] = L.ws[4]; }
+// k_stream itself, twice (see k_stream.inc): the geometry of a pass is a compile-time matter (LDS per wave, waves per SIMD, key bits)
+#define ECB_KS_SHORT 0
+namespace ks_std {
+#include "k_stream.inc"
 }
+#undef ECB_KS_SHORT
+#define ECB_KS_SHORT 1
+namespace ks_short {
+#include "k_stream.inc"
+}
+#undef ECB_KS_SHORT
 
 // resume points of a fresh batch: slice b starts (and has counted its records up to) record b * chunk
 // (ctr: the per-launch words of the batch's first launch are zeroed here too -- three memsets fewer in front of k_stream)
@@ -2855,7 +2167,8 @@ struct ecb_handle {
     bool assembled = false;                    // the result was put together from per-range results (ecb_assemble_ranges_device)
     bool list_counted = false;                 // ... and so it did for a table export (the list alone; its length at *d_list_n)
     u64* d_list_n = nullptr;
-    u64 resident_blocks = 0, resident_blocks_rg = 0, rounds = 24, min_tiles = 32;     // k_stream's launch shape (queried once)
+    u64 resident_blocks = 0, resident_blocks_rg = 0, resident_blocks_sh = 0, rounds = 24, min_tiles = 32;     // k_stream's launch shape (queried once)
+    bool short_reads = false;         // this batch goes through ks_short::k_stream (set per batch by process_batch)
     bool ctr_synced = false;          // hctr is what the device holds (no kernel that counts has been queued since the last read-back)
     bool adopted = false;             // the table holds adopted entries in consecutive slots (no hashing): finalize / export only
 
@@ -3056,19 +2369,22 @@ int excl_scan(ecb_handle* h, const u32* in, u64 n, u32* out, u64* total);
 // Launch shape of k_stream over n records: the stream is cut into ECB_ROUNDS x as many slices as waves are resident at
 // once; the launch holds the resident waves only, which claim slice after slice.
 struct StreamPlan { u64 slices, chunk, blocks, pwaves; };
-int plan_stream(ecb_handle* h, u64 n, StreamPlan* P, bool ranges = false) {
+int plan_stream(ecb_handle* h, u64 n, StreamPlan* P, bool ranges = false, bool short_reads = false) {
     if (!h->resident_blocks) {                         // (asked once per handle: two runtime queries per batch add up on a streamed BAM)
         int cus = 256, bpc = 4;
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_stream<false>, TPB, 0);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, ks_std::k_stream<false>, TPB, 0);
         h->resident_blocks = (u64)std::max(cus, 1) * std::max(bpc, 1);
         int bpr = 4;                                   // (the variant with the range update has fewer waves resident)
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpr, k_stream<false, true>, TPB, 0);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpr, ks_std::k_stream<false, true>, TPB, 0);
         h->resident_blocks_rg = (u64)std::max(cus, 1) * std::max(bpr, 1);
+        int bps = 3;                                   // (the variant for short reads: 13 KB of LDS per wave)
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&bps, ks_short::k_stream<false>, TPB, 0);
+        h->resident_blocks_sh = (u64)std::max(cus, 1) * std::max(bps, 1);
         h->rounds = getenv("ECB_ROUNDS") ? std::max(1, atoi(getenv("ECB_ROUNDS"))) : 24;   // (16 .. 32 measure alike on C3; fewer slices = fewer slice tails read twice)
         h->min_tiles = getenv("ECB_MIN_TILES") ? std::max(2, atoi(getenv("ECB_MIN_TILES"))) : 32;
     }
-    const u64 rounds = h->rounds, resident_blocks = ranges ? h->resident_blocks_rg : h->resident_blocks;
+    const u64 rounds = h->rounds, resident_blocks = short_reads ? h->resident_blocks_sh : (ranges ? h->resident_blocks_rg : h->resident_blocks);
     // slices: `rounds` per resident wave for balance, but not shorter than MIN_TILES tiles while every resident wave still gets
     // one -- a wave runs on past its slice's end to finish its open read, so every slice costs about one tile read twice
     // (at 5 tiles per slice, an eighth of config 3 on one of 8 GPUs, that was a fifth of the kernel)
@@ -3085,7 +2401,7 @@ int plan_stream(ecb_handle* h, u64 n, StreamPlan* P, bool ranges = false) {
     P->pwaves = P->blocks * NWAVE;               // waves of the launch
     // deferred reads: a parked launch defers at most the reads of the tiles in flight (one tile per resident wave); a read
     // with more than CMAX loci takes more than CMAX records
-    const u64 need_q = P->pwaves * (u64)(WT + 1) + n / CMAX + 16;
+    const u64 need_q = P->pwaves * (u64)(WT + 1) + n / 64 + 16;      // (64: the smaller of the two kernels' carry limits, k_stream.inc)
     if (h->queue_cap < need_q) {
         if (h->queue) hipFree(h->queue);
         h->queue = nullptr; h->queue_cap = 0;
@@ -3115,7 +2431,7 @@ int verify_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d
                               nullptr, nullptr, 0u, 0u};
     HIPCHK(h, hipMemcpyAsync(h->d_cold, h->pin_cold, sizeof(StreamCold), hipMemcpyHostToDevice, h->stream));
     StreamArgs a{d_rid, d_loc, d_hf, n, h->table, h->cap - 1, h->ctr, h->read_slot, h->reads_hi, h->d_cold, 0u};
-    k_stream<true><<<(unsigned)P.blocks, TPB, 0, h->stream>>>(a);
+    ks_std::k_stream<true><<<(unsigned)P.blocks, TPB, 0, h->stream>>>(a);
     k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, P.pwaves, h->ctr, 1u, 0ull);
     HIPCHK(h, hipGetLastError());
     rc = sync_counters(h);
@@ -3152,8 +2468,12 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     h->reads_hi = reads_after;
     // keep the table at most half full before a batch (it grows again, via k_slow, if a batch overfills it)
     while (h->n_ecs() * 2 > h->cap) { rc = grow_table(h, h->cap * 4); if (rc != ECB_OK) return rc; }
+    // Short reads (a 512-record tile holds more reads than a pass of 64 takes): the kernel with passes of 128 reads.  Known only when the
+    // caller has said how many reads the stream holds (ecb_hint_reads) -- the records-per-read of this batch is then n / (its share of them).
+    h->short_reads = hinted && !h->rng && h->cfg.n_loci < MAX_LOCI_SHORT && !getenv("ECB_NO_SHORT") &&
+                     (getenv("ECB_FORCE_SHORT") || n < 7 * (h->reads_hint - std::min<u64>(h->n_reads, h->reads_hint)));
     StreamPlan P;
-    rc = plan_stream(h, n, &P, h->rng != nullptr);
+    rc = plan_stream(h, n, &P, h->rng != nullptr, h->short_reads);
     if (rc != ECB_OK) return rc;
     const u64 waves = P.slices, chunk = P.chunk, blocks = P.blocks, pwaves = P.pwaves;
     u64* d_resume = nullptr;
@@ -3192,8 +2512,9 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
         }
         a.table = h->table; a.cap_mask = h->cap - 1;     // (d_wcounts: every wave of the launch stores its three words when it ends)
         if (h->prof) hipEventRecord(h->ev0, h->stream);
-        if (h->rng) k_stream<false, true><<<(unsigned)blocks, TPB, 0, h->stream>>>(a);     // ... with the range update fused in
-        else k_stream<false><<<(unsigned)blocks, TPB, 0, h->stream>>>(a);
+        if (h->rng) ks_std::k_stream<false, true><<<(unsigned)blocks, TPB, 0, h->stream>>>(a);     // ... with the range update fused in
+        else if (h->short_reads) ks_short::k_stream<false><<<(unsigned)blocks, TPB, 0, h->stream>>>(a);
+        else ks_std::k_stream<false><<<(unsigned)blocks, TPB, 0, h->stream>>>(a);
         if (h->prof) hipEventRecord(h->ev1, h->stream);
         k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, pwaves, h->ctr, 0u, offered, d_rid + (n - 1));
         offered = 0;                                    // (a relaunch after a park continues the same batch)

@@ -928,6 +928,56 @@ def test_random_streams_match_the_c_oracle(seed, n_loci, n_haps, max_len, p_inv,
         assert sizes["n_reads"] == exp["n_reads"]
 
 
+@pytest.mark.parametrize("seed,n_loci,n_haps,max_len,p_inv,mode", [
+    (11, 7, 2, 3, 0.0, "near"),                   # what the kernel is for: a few records per read, 200 reads per tile
+    (12, 40_000, 2, 6, 0.1, "near"),              # diploid, consecutive loci
+    (13, (1 << 25) - 3, 8, 9, 0.3, "wide"),       # the largest locus its keys hold
+    (14, 50, 1, 60, 0.1, "wide"),                 # forced onto it: long reads (carried over tiles), full tables
+    (15, 1 << 20, 31, 200, 0.2, "strided"),       # forced: 31 haplotypes, colliding loci, reads beyond the carry limit (k_slow)
+])
+def test_short_read_kernel_matches_the_c_oracle(seed, n_loci, n_haps, max_len, p_inv, mode, monkeypatch):
+    """``ks_short::k_stream`` (passes of up to 128 reads, looked up 64 at a time over one LDS table; chosen when the caller has bounded the
+    stream's reads and a batch brings fewer than seven records per read): the same CSR as the oracle's, in one device push and in several,
+    with a table that has to grow, and for streams it is not meant for (forced by ECB_FORCE_SHORT); ECB_NO_SHORT gives the standard
+    kernel the same input; the exactness pass agrees."""
+    import torch
+    from oracle import c_oracle
+    dev = torch.device("cuda:0")
+    t = _random_stream(seed, 20000 if max_len <= 9 else 3000, n_loci, n_haps, max_len, p_inv, mode)
+    exp = c_oracle.ec_from_tuples(t["read_id"], t["locus"], t["hapflag"], n_haps, threads=2)
+    d = [torch.from_numpy(t[k].view(np.int32)).to(dev) for k in ("read_id", "locus", "hapflag")]
+    n = len(t["read_id"])
+    cuts = [0]
+    for frac in (0.37, 0.7, 1.0):
+        c = min(int(n * frac), n)
+        while 0 < c < n and t["read_id"][c] == t["read_id"][c - 1]:
+            c += 1
+        cuts.append(c)
+    for env in ({"ECB_FORCE_SHORT": "1"}, {"ECB_NO_SHORT": "1"}):
+        for k in ("ECB_FORCE_SHORT", "ECB_NO_SHORT"):
+            monkeypatch.delenv(k, raising=False)
+        if max_len > 9 or "ECB_NO_SHORT" in env:
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+        for kw in ({}, {"ec_capacity": 256}):
+            with ecb.EcBuilder(n_loci, n_haps, **kw) as b:
+                b.hint_reads(exp["n_reads"])
+                b.push_device(*d)
+                s = b.finalize()
+                _check(b.export(), s, exp)
+                assert s["n_reads"] == exp["n_reads"]
+                b.reset()
+                for a, e in zip(cuts[:-1], cuts[1:]):
+                    if e > a:
+                        b.push_device(*(x[a:e].clone() for x in d))
+                s = b.finalize()
+                _check(b.export(), s, exp)
+                b.reset()
+                b.push_device(*d)
+                bad, _ = b.verify_device(*d)
+                assert bad == 0
+
+
 def test_multisample_triples_at_scale():
     """BASELINE config 4's shape on one GPU, scaled to 20 M paired-end reads: 5 000 cell barcodes over 3 files, per-(EC, cell,
     file) counts.  The device's triple reduce (radix sort + run lengths over 19 M reads) is checked against numpy on the
