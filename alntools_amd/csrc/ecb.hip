@@ -2470,7 +2470,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     while (h->n_ecs() * 2 > h->cap) { rc = grow_table(h, h->cap * 4); if (rc != ECB_OK) return rc; }
     // Short reads (a 512-record tile holds more reads than a pass of 64 takes): the kernel with passes of 128 reads.  Known only when the
     // caller has said how many reads the stream holds (ecb_hint_reads) -- the records-per-read of this batch is then n / (its share of them).
-    h->short_reads = hinted && !h->rng && h->cfg.n_loci < MAX_LOCI_SHORT && !getenv("ECB_NO_SHORT") &&
+    h->short_reads = hinted && !h->rng && h->cfg.n_loci < MAX_LOCI_SHORT && h->cfg.n_haplotypes <= 8 && !getenv("ECB_NO_SHORT") &&
                      (getenv("ECB_FORCE_SHORT") || n < 7 * (h->reads_hint - std::min<u64>(h->n_reads, h->reads_hint)));
     StreamPlan P;
     rc = plan_stream(h, n, &P, h->rng != nullptr, h->short_reads);

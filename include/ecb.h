@@ -112,7 +112,7 @@ int ecb_push_device(ecb_handle* h, const void* d_read_id, const void* d_locus, c
  * known, a push of device-resident tuples sizes its per-read state from it and no longer asks the device for the batch's
  * last read id before it launches anything: one host wait per push instead of two.  A stream that runs past the bound is
  * ECB_ERR_CONTRACT.  Kept across ecb_reset; 0 takes it back.  With the bound known the library also sees how many records a read
- * brings on average, and gives batches of short reads (fewer than seven records per read, n_loci < 2^25 - 2) to a stream kernel laid out for them. */
+ * brings on average, and gives batches of short reads (fewer than seven records per read, n_loci < 2^25 - 2, at most 8 haplotypes) to a stream kernel laid out for them. */
 int ecb_hint_reads(ecb_handle* h, uint64_t max_reads);
 
 /* Multisample only (ECB_F_MULTISAMPLE): per read, in read order, for reads [first_read, first_read + n):

@@ -976,6 +976,20 @@ def test_short_read_kernel_matches_the_c_oracle(seed, n_loci, n_haps, max_len, p
                 b.push_device(*d)
                 bad, _ = b.verify_device(*d)
                 assert bad == 0
+    # its haplotype masks are bytes: an index beyond 7 in a valid record must be refused before it can reach a neighbour's byte
+    if n_haps == 8:
+        for k in ("ECB_FORCE_SHORT", "ECB_NO_SHORT"):
+            monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv("ECB_FORCE_SHORT", "1")
+        hf = t["hapflag"].copy()
+        ok = np.where((hf & 0x4) == 0)[0]
+        hf[ok[len(ok) // 2]] = (hf[ok[len(ok) // 2]] & 0xFFFF) | (11 << 16)
+        with ecb.EcBuilder(n_loci, n_haps) as b:
+            b.hint_reads(exp["n_reads"])
+            with pytest.raises(ecb.EcbError) as e:
+                b.push_device(d[0], d[1], torch.from_numpy(hf.view(np.int32)).to(dev))
+                b.finalize()
+            assert e.value.code == -5
 
 
 def test_multisample_triples_at_scale():
