@@ -13,6 +13,8 @@
 //              key itself, the stand-in for the sorted string key of :307) and (c) one lane per read looks its set up in the
 //              global EC table -- hash, then an exact compare of the stored key -- or inserts it, and records the slot of the
 //              read.  Founders' (locus, mask) pairs are copied from LDS into the slot / the key arena by the whole wave.
+//              (csrc/k_stream.inc, compiled twice: passes of up to 64 reads at five waves per SIMD; passes of up to 128 reads with one-byte
+//              masks at four, for batches of short reads -- chosen per batch when ecb_hint_reads has bounded the stream's reads.)
 //   k_slow     the same for single reads that do not fit a tile or hit a full table (one workgroup per read).
 //   k_count    reads per EC and first read per EC (:309-312, 688-698) from the per-read slots, without global atomics:
 //              partition by slot range, count in LDS.
