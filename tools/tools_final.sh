@@ -19,7 +19,7 @@ stream_kib = sum(v) / max(len(v), 1)
 t = open(sys.argv[2]).read()
 fetch_kib = float(re.search(r'FETCH_SIZE\s+(\d+)', t).group(1)); write_kib = float(re.search(r'WRITE_SIZE\s+(\d+)', t).group(1))
 table_kib = max(fetch_kib - stream_kib, 0.0)
-print(json.dumps({"kernel": "k_stream<false, false>", "workload": sys.argv[3], "n_gpus": 1, "round": sys.argv[4],
+print(json.dumps({"kernel": "ks_std::k_stream<false, false>", "workload": sys.argv[3], "n_gpus": 1, "round": sys.argv[4],
                   "FETCH_SIZE_KiB": fetch_kib, "FETCH_SIZE_KiB_without_ec_table": stream_kib, "WRITE_SIZE_KiB": write_kib,
                   "hbm_bytes_per_launch": int((2 * stream_kib + table_kib + write_kib) * 1024),
                   "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/tools_final.sh); the record streams' share of FETCH_SIZE "

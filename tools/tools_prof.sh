@@ -8,11 +8,11 @@ cd $R
 f=$(find $RAW -name "*kernel_stats.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'anonymous namespace)::k_' in r['Name'] or 'fillBuffer' in r['Name']]   # (+ the runtime's fill kernels: hipMemsetAsync in reset)
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if ('anonymous namespace)::' in r['Name'] and '::k_' in r['Name']) or 'fillBuffer' in r['Name']]   # (+ the runtime's fill kernels: hipMemsetAsync in reset)
 print("%-34s %6s %10s %10s %10s %12s" % ("kernel", "calls", "avg_ms", "min_ms", "max_ms", "total_ms"))
 for r in rows:
     name = r['Name'].split('::')[1].split('(')[0] if '::' in r['Name'] else r['Name']
-    name = r['Name'][r['Name'].index('k_'):].split('(')[0] if '::k_' in r['Name'] else r['Name'].split('(')[0]
+    name = r['Name'].split('anonymous namespace)::', 1)[1].split('(')[0] if '::k_' in r['Name'] else r['Name'].split('(')[0]      # (ks_std::k_stream<...> keeps its namespace)
     print("%-34s %6s %10.3f %10.3f %10.3f %12.3f" % (name[:34], r['Calls'], float(r['AverageNs']) / 1e6, float(r.get('MinNs', 0)) / 1e6, float(r.get('MaxNs', 0)) / 1e6, float(r['TotalDurationNs']) / 1e6))
 PY
 tail -1 $OUT/run.log | cut -c1-400
