@@ -2052,12 +2052,17 @@ __global__ void k_msf2_ecs_small(const u32* meta, const u32* first, const u32* s
     const u32 a = seg[e], b = seg[e + 1];
     if (b - a > MSF_SMALL) { big[atomicAdd(n_big, 1u)] = (u32)e; return; }
     bool keep = false;
+    u32 last_f = 0xFFFFFFFFu, last_fec = 0;                                  // (the EC's first appearance in the file asked for last: cells' first files repeat)
     for (u32 t = a; t < b; ++t) {
         const u32 m = meta[t], c = m & ((1u << ECB_CELL_BITS) - 1u), f = m >> ECB_CELL_BITS;
         keep |= total[c] >= min_count;
         if (firstfile[c] != f) continue;
-        u32 fec = first[t];
-        for (u32 x = a; x < b; ++x) if ((meta[x] >> ECB_CELL_BITS) == f) fec = min(fec, first[x]);
+        if (f != last_f) {
+            u32 fec = first[t];
+            for (u32 x = a; x < b; ++x) if ((meta[x] >> ECB_CELL_BITS) == f) fec = min(fec, first[x]);
+            last_f = f; last_fec = fec;
+        }
+        const u32 fec = last_fec;
         const u64 offer = ((u64)fec << 32) | first[t];
         if (offer < cellkey[c]) atomicMin(&cellkey[c], offer);               // (the plain read may be stale: then one atomic too many)
     }
