@@ -182,7 +182,7 @@ int ecb_verify_device(ecb_handle* h, const void* d_read_id, const void* d_locus,
  * caller allocates: n_entries * 32 bytes and n_pairs * 8 bytes), the caller moves it (RCCL), and the
  * receiving rank merges it -- the reference's ordered merge, bam_utils.py:680-724.
  * read_base = number of reads on all lower ranks (makes "first appearance" global).
- * (There is no ecb_merge(handles[], n) with the collective inside the library: libecb links neither RCCL nor MPI -- it hands out and
+ * (There is no merge call that takes an array of handles and runs the collective inside the library: libecb links neither RCCL nor MPI -- it hands out and
  *  takes device buffers, and whoever owns the process group moves them.  alntools_amd/dist.py is that owner for torch.distributed (backend
  *  "nccl" = RCCL); INTEGRATION.md section 3 lists the message pattern for a host that is not Python.)
  * ecb_table_sizes: *n_pairs is an upper bound of the key pairs in use (buffer size); the export writes the keys of the
