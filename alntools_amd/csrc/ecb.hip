@@ -2176,6 +2176,7 @@ struct ecb_handle {
     u64* d_list_n = nullptr;
     u64 resident_blocks = 0, resident_blocks_rg = 0, resident_blocks_sh = 0, rounds = 24, min_tiles = 32;     // k_stream's launch shape (queried once)
     bool short_reads = false;         // this batch goes through ks_short::k_stream (set per batch by process_batch)
+    u64 records_pushed = 0;           // records of the batches so far (with n_reads: how many records a read brings)
     bool ctr_synced = false;          // hctr is what the device holds (no kernel that counts has been queued since the last read-back)
     bool adopted = false;             // the table holds adopted entries in consecutive slots (no hashing): finalize / export only
 
@@ -2477,8 +2478,11 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     while (h->n_ecs() * 2 > h->cap) { rc = grow_table(h, h->cap * 4); if (rc != ECB_OK) return rc; }
     // Short reads (a 512-record tile holds more reads than a pass of 64 takes): the kernel with passes of 128 reads.  Known only when the
     // caller has said how many reads the stream holds (ecb_hint_reads) -- the records-per-read of this batch is then n / (its share of them).
+    // (records per read: of the batches before this one where there are any; a first batch is judged as if it were the whole stream -- it must
+    //  then hold at least one record per announced read -- so that a long-read stream pushed in many batches is not taken for a short-read one)
+    const bool few = h->n_reads ? h->records_pushed < 7 * h->n_reads : (n >= h->reads_hint && n < 7 * h->reads_hint);
     h->short_reads = hinted && !h->rng && h->cfg.n_loci < MAX_LOCI_SHORT && h->cfg.n_haplotypes <= 8 && !getenv("ECB_NO_SHORT") &&
-                     (getenv("ECB_FORCE_SHORT") || n < 7 * (h->reads_hint - std::min<u64>(h->n_reads, h->reads_hint)));
+                     (getenv("ECB_FORCE_SHORT") || few);
     StreamPlan P;
     rc = plan_stream(h, n, &P, h->rng != nullptr, h->short_reads);
     if (rc != ECB_OK) return rc;
@@ -2568,6 +2572,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     }
     h->prev_rid = last_rid;
     h->n_reads = reads_after;
+    h->records_pushed += n;
     return ECB_OK;
 }
 
@@ -2996,7 +3001,7 @@ int ecb_reset(ecb_handle* h) {
         k_fill_minmax<<<nblk(ns, TPB), TPB, 0, h->stream>>>(h->rng, ns);
     }
     // (no wait: everything above is ordered on the handle's stream, where all later work goes too)
-    h->prev_rid = 0xFFFFFFFFu; h->n_reads = 0; h->reads_hi = 0; h->meta_hi = 0; h->n_triples = 0; h->ms_ocount = nullptr; h->ms_adopted = false;
+    h->prev_rid = 0xFFFFFFFFu; h->n_reads = 0; h->records_pushed = 0; h->reads_hi = 0; h->meta_hi = 0; h->n_triples = 0; h->ms_ocount = nullptr; h->ms_adopted = false;
     h->extra_all = h->extra_valid = h->extra_reads = 0;
     h->c_rid.clear(); h->c_loc.clear(); h->c_hf.clear(); h->c_pos.clear();
     h->finalized = false; h->counted = false; h->adopted = false; h->sizes = ecb_sizes{}; h->n_list = 0;
