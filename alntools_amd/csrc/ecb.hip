@@ -2045,11 +2045,13 @@ __global__ void k_msf2_seg(const u32* ec, u64 n, u32 n_ecs, u32* seg, u32* err) 
 // sweeps was latency: 14 us per EC.)
 constexpr u32 MSF_SMALL = 256;
 constexpr u32 MSF_FILES = 1u << MS_FILE_BITS;
+constexpr u32 MSF_GIANT = 1u << 15;           // triples above which an EC is shared out over the whole grid (k_msf2_giant_*), not given to one workgroup
 __global__ void k_msf2_ecs_small(const u32* meta, const u32* first, const u32* seg, u32 n_ecs, const u64* total, const u32* firstfile,
-                                 u64 min_count, u64* cellkey, u32* keep_ec, u32* big, u32* n_big) {
+                                 u64 min_count, u64* cellkey, u32* keep_ec, u32* big, u32* n_big, u32* giant, u32* n_giant) {
     const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (e >= n_ecs) return;
     const u32 a = seg[e], b = seg[e + 1];
+    if (b - a > MSF_GIANT) { giant[atomicAdd(n_giant, 1u)] = (u32)e; return; }
     if (b - a > MSF_SMALL) { big[atomicAdd(n_big, 1u)] = (u32)e; return; }
     bool keep = false;
     u32 last_f = 0xFFFFFFFFu, last_fec = 0;                                  // (the EC's first appearance in the file asked for last: cells' first files repeat)
@@ -2094,6 +2096,44 @@ __global__ __launch_bounds__(TPB) void k_msf2_ecs_big(const u32* meta, const u32
         }
         if (threadIdx.x == 0 && s_keep) keep_ec[e] = 1u;
         __syncthreads();
+    }
+}
+// The few ECs with tens of thousands of triples and more (config 4's most popular EC has millions): one workgroup each was the tail of the
+// whole filter.  Every workgroup of the grid takes a strided share of each such EC: first the EC's first appearance per file (LDS, then one
+// global atomic per file and workgroup), then -- a launch later -- the offers.
+__global__ __launch_bounds__(TPB) void k_msf2_giant_fec(const u32* meta, const u32* first, const u32* seg, const u32* giant, const u32* n_giant,
+                                                        const u64* total, u64 min_count, u32* gfec, u32* keep_ec) {
+    __shared__ u32 fec[MSF_FILES];
+    __shared__ u32 s_keep;
+    for (u32 g = 0; g < *n_giant; ++g) {
+        const u32 e = giant[g], a = seg[e], b = seg[e + 1];
+        for (u32 f = threadIdx.x; f < MSF_FILES; f += TPB) fec[f] = 0xFFFFFFFFu;
+        if (threadIdx.x == 0) s_keep = 0;
+        __syncthreads();
+        bool keep = false;
+        for (u64 t = (u64)a + (u64)blockIdx.x * TPB + threadIdx.x; t < b; t += (u64)gridDim.x * TPB) {
+            const u32 m = meta[t];
+            atomicMin(&fec[m >> ECB_CELL_BITS], first[t]);
+            keep |= total[m & ((1u << ECB_CELL_BITS) - 1u)] >= min_count;
+        }
+        if (keep) s_keep = 1u;
+        __syncthreads();
+        for (u32 f = threadIdx.x; f < MSF_FILES; f += TPB) if (fec[f] != 0xFFFFFFFFu) atomicMin(&gfec[(u64)g * MSF_FILES + f], fec[f]);
+        if (threadIdx.x == 0 && s_keep) keep_ec[e] = 1u;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(TPB) void k_msf2_giant_offer(const u32* meta, const u32* first, const u32* seg, const u32* giant, const u32* n_giant,
+                                                          const u32* firstfile, const u32* gfec, u64* cellkey) {
+    for (u32 g = 0; g < *n_giant; ++g) {
+        const u32 e = giant[g], a = seg[e], b = seg[e + 1];
+        for (u64 t = (u64)a + (u64)blockIdx.x * TPB + threadIdx.x; t < b; t += (u64)gridDim.x * TPB) {
+            const u32 m = meta[t], c = m & ((1u << ECB_CELL_BITS) - 1u), f = m >> ECB_CELL_BITS;
+            if (firstfile[c] == f) {
+                const u64 offer = ((u64)gfec[(u64)g * MSF_FILES + f] << 32) | first[t];
+                if (offer < cellkey[c]) atomicMin(&cellkey[c], offer);
+            }
+        }
     }
 }
 // cells that have reads, as the lists the ordering below works on
@@ -3700,10 +3740,16 @@ int ecb_ms_filter(ecb_handle* h, uint32_t n_cells, int64_t minimum_count, ecb_ms
     k_msf2_seg<<<nblk(T, TPB), TPB, 0, st>>>(ec, T, (u32)E, seg, d_err);
     {
         u32* big = sc.get<u32>(E + 1);                       // ECs of more than MSF_SMALL triples, their number behind the list
-        if (!big) return fail(h, ECB_ERR_HIP, "out of device memory");
+        const u64 max_giant = T / MSF_GIANT + 1;             // ... and of more than MSF_GIANT, with their per-file first appearances
+        u32 *giant = sc.get<u32>(max_giant + 1), *gfec = sc.get<u32>(max_giant * MSF_FILES);
+        if (!big || !giant || !gfec) return fail(h, ECB_ERR_HIP, "out of device memory");
         HIPCHK(h, hipMemsetAsync(big + E, 0, 4, st));
-        k_msf2_ecs_small<<<nblk(E, TPB), TPB, 0, st>>>(meta, first, seg, (u32)E, total, firstfile, min_count, cellkey, keep_ec, big, big + E);
+        HIPCHK(h, hipMemsetAsync(giant + max_giant, 0, 4, st));
+        HIPCHK(h, hipMemsetAsync(gfec, 0xFF, max_giant * MSF_FILES * 4, st));
+        k_msf2_ecs_small<<<nblk(E, TPB), TPB, 0, st>>>(meta, first, seg, (u32)E, total, firstfile, min_count, cellkey, keep_ec, big, big + E, giant, giant + max_giant);
         k_msf2_ecs_big<<<(unsigned)std::min<u64>(std::max<u64>(E / MSF_SMALL, 1), 4096), TPB, 0, st>>>(meta, first, seg, big, big + E, total, firstfile, min_count, cellkey, keep_ec);
+        k_msf2_giant_fec<<<1024, TPB, 0, st>>>(meta, first, seg, giant, giant + max_giant, total, min_count, gfec, keep_ec);
+        k_msf2_giant_offer<<<1024, TPB, 0, st>>>(meta, first, seg, giant, giant + max_giant, firstfile, gfec, cellkey);
     }
     // 3. cell order: by (first appearance of the EC in the cell's first file, first read), then -- stable -- by that file
     int rc, where = 0;
