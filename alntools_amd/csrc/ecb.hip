@@ -2593,6 +2593,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
         u64 tot = 0; for (int i = 0; i < 7; ++i) tot += t[i];
         fprintf(stderr, "[ecb timing] %llu waves, clocks per wave:", (unsigned long long)waves);
         for (int i = 0; i < 7; ++i) fprintf(stderr, "  %s %.0f (%.1f%%)", nm[i], (double)t[i] / waves, 100.0 * t[i] / std::max<u64>(tot, 1));
+        fprintf(stderr, "  tile visits on the probe-on path %llu of %llu tiles", (unsigned long long)t[7], (unsigned long long)((n + WT - 1) / WT));
         fprintf(stderr, "\n");
     }
 #endif

@@ -181,12 +181,13 @@ class SynthSpec(object):
     """Parameters of one synthetic workload."""
 
     def __init__(self, n_reads, n_loci, n_haps, paired=False, seed=SEED, n_variants=4,
-                 unmapped_read_pct=4, dup_pct=2):
+                 unmapped_read_pct=4, dup_pct=2, locus_stride=1):
         if not 1 <= n_haps <= 8:
             raise ValueError("synthetic generator supports 1..8 haplotypes")
         self.n_reads, self.n_loci, self.n_haps = int(n_reads), int(n_loci), int(n_haps)
         self.paired, self.seed, self.n_variants = bool(paired), int(seed), int(n_variants)
         self.unmapped_read_pct, self.dup_pct = int(unmapped_read_pct), int(dup_pct)
+        self.locus_stride = int(locus_stride)       # a read's loci are base, base + stride, ... (1: consecutive target ids, the default and what the fixtures hold)
 
     # header --------------------------------------------------------------
     def hap_names(self):
@@ -218,7 +219,7 @@ def _per_read(spec, be, r):
     pc = be.lut(_popcount8_lut())
     masks, cnts = [], []
     for j in range(_MAXL):
-        loc = (base + j) % T
+        loc = (base + j * spec.locus_stride) % T
         m = loc * 0
         for h in range(H):
             hv = _pos(_rnd(seed ^ 0x5EED, loc * 64 + v * 8 + h, 7)) % 100
@@ -312,7 +313,7 @@ def generate(spec, r0, r1, device=None, want_raw=False, read_id_base=0):
         rem = be.where(done | hit, rem, rem - c)
         done = done | hit
     hap = be.take(kth, mask_sel * 8 + rem)
-    locus = (g(pr["base"]) + j) % T
+    locus = (g(pr["base"]) + j * spec.locus_stride) % T
     tid = locus * H + hap
     length = 500 + (locus * 7919) % 4500
     pos = _pos(_rnd(seed, rr * 64 + a, 11)) % length
