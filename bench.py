@@ -38,6 +38,7 @@ WORKLOADS = {
     "c4": (200_000_000, 80_000, 8, True, "BASELINE config 4: multisample, 200M paired-end reads, 5k cell barcodes (log-normal sizes) over 64 files, minimum count 1000"),
     "c4h": (100_000_000, 80_000, 8, True, "half of config 4 (debug)"),
     "c3s": (100_000_000, 80_000, 8, True, "config 3 with every read's loci 64 target ids apart (their low bits equal: the worst case for the stream kernel's LDS table)"),
+    "c3q": (100_000_000, 80_000, 8, True, "config 3 with every read's loci 4 target ids apart: the third locus of a read collides with its first in the LDS table (reads of three loci and more: two in five)"),
     "dip": (200_000_000, 40_000, 2, False, "diploid single-end reads: 2 hap x 40k transcripts, ~4 records per read (short reads: several passes per tile)"),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
@@ -315,7 +316,7 @@ def main():
     red_dev = torch.device("cpu") if rehearsal else device          # where the small reductions of the timing live
 
     R, T, H, paired, desc = WORKLOADS[args.workload]
-    spec = synth.SynthSpec(R, T, H, paired=paired, locus_stride=64 if args.workload == "c3s" else 1)
+    spec = synth.SynthSpec(R, T, H, paired=paired, locus_stride={"c3s": 64, "c3q": 4}.get(args.workload, 1))
     r0, r1 = rank * R // world, (rank + 1) * R // world
     t_gen = time.perf_counter()
     rid, loc, hf, st = generate_shard(spec, r0, r1, device)
@@ -324,7 +325,7 @@ def main():
 
     # EC-table slots: sized for the workload's EC count (c3: 3.7 M ECs) so that the timed steps do not grow it
     # (a shard of 1/4 or 1/8 of config 3 still founds 2.3 - 3 M of its 3.7 M ECs: 2^23 slots keep it under half full)
-    ec_cap = 1 << int(os.environ.get("ECB_EC_CAP_LOG2", ("23" if world >= 4 else "24") if args.workload in ("c3", "c3h", "c3s", "c4", "c4h") else "22"))
+    ec_cap = 1 << int(os.environ.get("ECB_EC_CAP_LOG2", ("23" if world >= 4 else "24") if args.workload in ("c3", "c3h", "c3s", "c3q", "c4", "c4h") else "22"))
     b = ecb.EcBuilder(T, H, device=local, ec_capacity=ec_cap, arena_capacity=1 << 26)
     hint = 0 if os.environ.get("ECB_NO_HINT") else st["reads"]      # (a caller that knows how many reads its stream holds says so: one host wait per push)
     b.hint_reads(hint)
