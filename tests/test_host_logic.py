@@ -91,6 +91,23 @@ def test_synthetic_read_ids_follow_the_contract():
         assert rid[-1] + 1 == t["n_reads"]
 
 
+def test_synthetic_loci_of_a_read_keep_the_stride_they_were_given():
+    """``SynthSpec(locus_stride=...)``: the loci of a read are its base locus plus multiples of the stride (``bench.py --workload c3s / c3q``:
+    the LDS table's bad cases); the default, 1 -- what every fixture holds -- gives runs of consecutive loci."""
+    T = 5000
+    for stride in (1, 4, 64):
+        t = synth.generate(synth.SynthSpec(2000, T, 8, locus_stride=stride), 0, 2000)
+        ok = orc.tuples_valid(t["hapflag"])
+        seen = 0
+        for r in np.unique(t["read_id"][ok])[:300]:
+            loci = np.unique(t["locus"][ok & (t["read_id"] == r)]).astype(np.int64)
+            if loci.max() - loci.min() > T // 2:                 # (a read that wraps around the last locus)
+                continue
+            assert set((loci - loci.min()) % stride) == {0} and loci.max() - loci.min() <= 4 * stride
+            seen += len(loci) > 1
+        assert seen > 50
+
+
 def test_c_abi_library_loads_and_exports_every_declared_symbol():
     import re
     from alntools_amd import ecb
