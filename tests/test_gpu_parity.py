@@ -285,6 +285,29 @@ def test_mid_size_device_vs_c_oracle_properties(paired):
         assert np.array_equal(out[k], out2[k]), k
 
 
+@pytest.mark.parametrize("stride,paired", [(4, True), (64, False), (8, True)])
+def test_reads_whose_loci_collide_in_the_lds_table_match_the_c_oracle(stride, paired):
+    """The stream kernel's LDS table gives a read a home region and places a locus by its low bits: consecutive target ids never meet there.
+    Loci a stride apart do -- every tile then goes through the probe-on path (only the record positions that collided, since round 3) and
+    the lookups through the full key walk.  600 k reads at three strides against the C oracle, bit for bit; the exactness pass agrees."""
+    import torch
+    from oracle import c_oracle
+    spec = synth.SynthSpec(600_000, 20_000, 8, paired=paired, locus_stride=stride)
+    dev = torch.device("cuda:0")
+    t = synth.generate(spec, 0, spec.n_reads)
+    exp = c_oracle.ec_from_tuples(t["read_id"], t["locus"], t["hapflag"], spec.n_haps, threads=4)
+    d = [torch.from_numpy(t[k].view(np.int32)).to(dev) for k in ("read_id", "locus", "hapflag")]
+    for hint in (0, exp["n_reads"]):
+        with ecb.EcBuilder(spec.n_loci, spec.n_haps) as b:
+            b.hint_reads(hint)
+            b.push_device(*d)
+            s = b.finalize()
+            _check(b.export(), s, exp)
+            b.reset()
+            b.push_device(*d)
+            assert b.verify_device(*d) == (0, 0)
+
+
 def test_many_small_batches_do_not_leak_the_key_arena():
     """A stream pushed in hundreds of small host batches into a handle whose key arena is only ~2.5 x the keys it has to
     hold: a wave keeps the rest of its 512-pair reservation from launch to launch (leaving it behind per launch would
