@@ -3,9 +3,16 @@
 ``bam2ec``, ``bam2emase``, ``ec2emase``, ``emase2ec``.  ``python -m alntools_amd.cli bam2ec in.bam out.bin``."""
 from __future__ import annotations
 
+import os
+
 import click
 
-from . import methods, utils
+# The one-GPU commands move everything through libecb's host-pointer entry points: no tensors, so PyTorch is not imported and libecb
+# runs on the system's HIP runtime (alntools_amd/ecb.py: load).  ALNTOOLS_GPUS=N (> 1) runs ranks over torch.distributed and wants it.
+if int(os.environ.get("ALNTOOLS_GPUS", "1") or 1) <= 1:
+    os.environ.setdefault("ALNTOOLS_TORCH", "0")
+
+from . import methods, utils  # noqa: E402
 
 
 @click.group()

@@ -2263,6 +2263,7 @@ struct ecb_handle {
 
     // profiling
     bool prof = false; double prof_ms = 0; u64 prof_launches = 0, prof_records = 0;
+    const char* last_kernel = "";     // which compilation of the stream kernel the last batch launched (ecb_profile_kernel)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -2563,9 +2564,9 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
         }
         a.table = h->table; a.cap_mask = h->cap - 1;     // (d_wcounts: every wave of the launch stores its three words when it ends)
         if (h->prof) hipEventRecord(h->ev0, h->stream);
-        if (h->rng) ks_std::k_stream<false, true><<<(unsigned)blocks, TPB, 0, h->stream>>>(a);     // ... with the range update fused in
-        else if (h->short_reads) ks_short::k_stream<false><<<(unsigned)blocks, TPB, 0, h->stream>>>(a);
-        else ks_std::k_stream<false><<<(unsigned)blocks, TPB, 0, h->stream>>>(a);
+        if (h->rng) { ks_std::k_stream<false, true><<<(unsigned)blocks, TPB, 0, h->stream>>>(a); h->last_kernel = "ks_std::k_stream<false, true>"; }     // ... with the range update fused in
+        else if (h->short_reads) { ks_short::k_stream<false><<<(unsigned)blocks, TPB, 0, h->stream>>>(a); h->last_kernel = "ks_short::k_stream<false, false>"; }
+        else { ks_std::k_stream<false><<<(unsigned)blocks, TPB, 0, h->stream>>>(a); h->last_kernel = "ks_std::k_stream<false, false>"; }
         if (h->prof) hipEventRecord(h->ev1, h->stream);
         k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, pwaves, h->ctr, 0u, offered, d_rid + (n - 1));
         offered = 0;                                    // (a relaunch after a park continues the same batch)
@@ -3877,6 +3878,10 @@ int ecb_profile_read(ecb_handle* h, double* ms, uint64_t* launches, uint64_t* re
     return ECB_OK;
 }
 
+// the stream kernel the last batch launched, as rocprofv3 names it (k_stream.inc is compiled more than once: which compilation a
+// batch takes is decided per batch, in process_batch)
+const char* ecb_profile_kernel(const ecb_handle* h) { return h ? h->last_kernel : ""; }
+
 }  // extern "C"
 
 // ---- f-2 conversions (stateless; scratch is allocated per call: this is not the hot path) ------------------------
@@ -4085,5 +4090,71 @@ extern "C" int ecb_hapcsc_to_csr_device(int device, uint32_t n_ecs, uint32_t n_l
     k_cvb_rowptr<<<nblk((u64)n_ecs + 1, TPB), TPB, 0, st>>>(kk[where], nnz, n_ecs, (int*)d_indptr);
     if (hipStreamSynchronize(st) != hipSuccess) return fail(nullptr, ECB_ERR_HIP, "csc -> csr");
     *nnz_out = nnz;
+    return ECB_OK;
+}
+
+// ---- the same two conversions from and to HOST arrays: the library allocates, fills and frees its own device buffers, so a host
+// that only converts files (alntools ec2emase / emase2ec, the .h5 writer of bam2emase: bin_utils.py:979-1028) needs no device
+// allocator of its own -- and the Python drop-in no PyTorch on that path.
+namespace {
+struct DevBuf {                        // a device buffer that goes away with its scope
+    void* p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    int take(u64 bytes) { return hipMalloc(&p, std::max<u64>(bytes, 4)) == hipSuccess ? ECB_OK : ECB_ERR_HIP; }
+};
+}  // namespace
+
+extern "C" int ecb_csr_to_hapcsc(int device, uint32_t n_ecs, uint32_t n_loci, uint32_t n_haps, const int32_t* indptr, const int32_t* indices,
+                                 const int32_t* data, int32_t* csc_indptr, int32_t* csc_indices, uint64_t capacity, uint64_t* total) {
+    if (!indptr || !total || !n_ecs || !n_loci || !n_haps || n_haps > 31) return fail(nullptr, ECB_ERR_ARG, "bad argument");
+    if (device < 0 || device >= CV_MAX_DEV || hipSetDevice(device) != hipSuccess) return fail(nullptr, ECB_ERR_NO_DEVICE, "no such device");
+    if (indptr[n_ecs] < 0) return fail(nullptr, ECB_ERR_CONTRACT, "malformed CSR: negative row pointer");
+    const u64 nnz = (u64)indptr[n_ecs];
+    if (nnz && (!indices || !data)) return fail(nullptr, ECB_ERR_ARG, "bad argument");
+    if (!csc_indices || !csc_indptr) {                 // the count alone: the set bits of the masks, on the host (one pass over nnz words)
+        u64 tot = 0;
+        for (u64 i = 0; i < nnz; ++i) tot += (u64)__builtin_popcount((unsigned)data[i]);
+        if (tot >= (1ull << 32)) return fail(nullptr, ECB_ERR_LIMIT, "more than 2^32-1 set haplotype bits");
+        *total = tot;
+        return ECB_OK;
+    }
+    DevBuf ip, ix, da, cp, ci;
+    const u64 nc = (u64)n_haps * (n_loci + 1);
+    if (ip.take(((u64)n_ecs + 1) * 4) || ix.take(nnz * 4) || da.take(nnz * 4) || cp.take(nc * 4) || ci.take(capacity * 4))
+        return fail(nullptr, ECB_ERR_HIP, "out of device memory");
+    if (hipMemcpy(ip.p, indptr, ((u64)n_ecs + 1) * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        (nnz && (hipMemcpy(ix.p, indices, nnz * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(da.p, data, nnz * 4, hipMemcpyHostToDevice) != hipSuccess)))
+        return fail(nullptr, ECB_ERR_HIP, "copy to the device");
+    // (the device entry point writes at most one row index per set bit: ask it for the count first when the caller's buffer might be short)
+    uint64_t need = 0;
+    int rc = ecb_csr_to_hapcsc_device(device, n_ecs, n_loci, n_haps, ip.p, ix.p, da.p, nullptr, nullptr, &need);
+    if (rc != ECB_OK) return rc;
+    *total = need;
+    if (need > capacity) return fail(nullptr, ECB_ERR_ARG, "csc_indices holds %llu entries, the matrix has %llu set bits", (unsigned long long)capacity, (unsigned long long)need);
+    rc = ecb_csr_to_hapcsc_device(device, n_ecs, n_loci, n_haps, ip.p, ix.p, da.p, cp.p, ci.p, total);
+    if (rc != ECB_OK) return rc;
+    if (hipMemcpy(csc_indptr, cp.p, nc * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        (*total && hipMemcpy(csc_indices, ci.p, *total * 4, hipMemcpyDeviceToHost) != hipSuccess))
+        return fail(nullptr, ECB_ERR_HIP, "copy from the device");
+    return ECB_OK;
+}
+
+extern "C" int ecb_hapcsc_to_csr(int device, uint32_t n_ecs, uint32_t n_loci, uint32_t n_haps, const int32_t* csc_indptr, const int32_t* csc_indices,
+                                 uint64_t total, int32_t* indptr, int32_t* indices, int32_t* data, uint64_t* nnz) {
+    if (!csc_indptr || !csc_indices || !indptr || !indices || !data || !nnz || !n_ecs || !n_loci || !n_haps || n_haps > 31 || !total)
+        return fail(nullptr, ECB_ERR_ARG, "bad argument");
+    if (total >= (1ull << 32)) return fail(nullptr, ECB_ERR_LIMIT, "more than 2^32-1 row indices");
+    if (device < 0 || device >= CV_MAX_DEV || hipSetDevice(device) != hipSuccess) return fail(nullptr, ECB_ERR_NO_DEVICE, "no such device");
+    DevBuf cp, ci, ip, ix, da;
+    const u64 nc = (u64)n_haps * (n_loci + 1);
+    if (cp.take(nc * 4) || ci.take(total * 4) || ip.take(((u64)n_ecs + 1) * 4) || ix.take(total * 4) || da.take(total * 4))
+        return fail(nullptr, ECB_ERR_HIP, "out of device memory");
+    if (hipMemcpy(cp.p, csc_indptr, nc * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(ci.p, csc_indices, total * 4, hipMemcpyHostToDevice) != hipSuccess)
+        return fail(nullptr, ECB_ERR_HIP, "copy to the device");
+    const int rc = ecb_hapcsc_to_csr_device(device, n_ecs, n_loci, n_haps, cp.p, ci.p, total, ip.p, ix.p, da.p, nnz);
+    if (rc != ECB_OK) return rc;
+    if (hipMemcpy(indptr, ip.p, ((u64)n_ecs + 1) * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        (*nnz && (hipMemcpy(indices, ix.p, *nnz * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(data, da.p, *nnz * 4, hipMemcpyDeviceToHost) != hipSuccess)))
+        return fail(nullptr, ECB_ERR_HIP, "copy from the device");
     return ECB_OK;
 }

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -32,7 +33,9 @@ SYMBOLS = ("ecb_abi_version", "ecb_device_count", "ecb_create", "ecb_destroy", "
            "ecb_table_adopt_device", "ecb_table_merge_batch_device", "ecb_table_adopt_batch_device",
            "ecb_export_firsts_device", "ecb_assemble_ranges_device", "ecb_table_rebase_device",
            "ecb_export_ec_keys_device", "ecb_ms_local_triples_device", "ecb_ms_adopt_triples_device", "ecb_counters", "ecb_add_counters", "ecb_profile",
-           "ecb_profile_read", "ecb_csr_to_hapcsc_device", "ecb_hapcsc_to_csr_device", "ecb_release_scratch")
+           "ecb_profile_read", "ecb_profile_kernel", "ecb_csr_to_hapcsc_device", "ecb_hapcsc_to_csr_device", "ecb_release_scratch",
+           "ecb_csr_to_hapcsc", "ecb_hapcsc_to_csr")
+ABI_VERSION = 4            # include/ecb.h: ECB_ABI_VERSION
 
 
 class EcbError(RuntimeError):
@@ -70,14 +73,22 @@ def load():
     # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as
     # /opt/rocm's).  Importing torch first makes the loader bind libecb's libamdhip64.so.7 to the copy
     # torch already mapped, so tensors and libecb share one runtime (two copies cannot both open the GPU).
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    # A process that will never hold a tensor says so (ALNTOOLS_TORCH=0: the command line does, for its one-GPU commands --
+    # everything it needs goes through host pointers) and libecb then runs on the system's HIP runtime, PyTorch not imported.
+    if os.environ.get("ALNTOOLS_TORCH", "1") != "0" or "torch" in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s not found: build it with `python -m alntools_amd.build` "
                           "(the HIP path has no fallback)" % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
+    lib.ecb_abi_version.restype = C.c_int
+    ab = "ECB_LIB" in os.environ        # (an A/B build named by hand, tools/: may be an older ABI; what it lacks is simply not bound)
+    if lib.ecb_abi_version() != ABI_VERSION and not ab:
+        raise ImportError("%s has ABI %d, this binding is for ABI %d: rebuild it (python -m alntools_amd.build)"
+                          % (LIB_PATH, lib.ecb_abi_version(), ABI_VERSION))
     vp, u64, sz = C.c_void_p, C.c_uint64, C.c_size_t
     lib.ecb_abi_version.restype = C.c_int
     lib.ecb_device_count.restype = C.c_int
@@ -119,6 +130,11 @@ def load():
     lib.ecb_add_counters.argtypes = [vp, u64, u64, u64]
     lib.ecb_profile.argtypes = [vp, C.c_int]
     lib.ecb_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]
+    if not ab or hasattr(lib, "ecb_profile_kernel"):
+        lib.ecb_profile_kernel.argtypes = [vp]
+        lib.ecb_profile_kernel.restype = C.c_char_p
+        lib.ecb_csr_to_hapcsc.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, u64, C.POINTER(u64)]
+        lib.ecb_hapcsc_to_csr.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, u64, vp, vp, vp, C.POINTER(u64)]
     lib.ecb_csr_to_hapcsc_device.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, C.POINTER(u64)]
     lib.ecb_hapcsc_to_csr_device.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, u64, vp, vp, vp, C.POINTER(u64)]
     _lib = lib
@@ -158,6 +174,41 @@ def csr_to_hapcsc(indptr, indices, data, n_loci, n_haps, nnz=None):
     if rc != 0:
         raise EcbError(rc, (lib.ecb_last_error(None) or b"").decode())
     return cptr, cidx[:tot.value]
+
+
+def csr_to_hapcsc_host(indptr, indices, data, n_loci, n_haps, device=0):
+    """f-2 on HOST arrays (``ecb_csr_to_hapcsc``: the library holds the device buffers itself; no PyTorch involved):
+    CSR(bitmask) -> (csc_indptr int32 [H, T+1], csc_indices int32 [total])."""
+    lib = load()
+    ip, ix, da = (np.ascontiguousarray(a, dtype=np.int32) for a in (indptr, indices, data))
+    E = len(ip) - 1
+    tot = C.c_uint64()
+    rc = lib.ecb_csr_to_hapcsc(device, E, n_loci, n_haps, _ptr(ip), _ptr(ix), _ptr(da), None, None, 0, C.byref(tot))
+    if rc != 0:
+        raise EcbError(rc, (lib.ecb_last_error(None) or b"").decode())
+    cptr = np.empty((n_haps, n_loci + 1), dtype=np.int32)
+    cidx = np.empty(max(tot.value, 1), dtype=np.int32)
+    rc = lib.ecb_csr_to_hapcsc(device, E, n_loci, n_haps, _ptr(ip), _ptr(ix), _ptr(da), _ptr(cptr), _ptr(cidx), len(cidx), C.byref(tot))
+    if rc != 0:
+        raise EcbError(rc, (lib.ecb_last_error(None) or b"").decode())
+    return cptr, cidx[:tot.value]
+
+
+def hapcsc_to_csr_host(csc_indptr, csc_indices, n_ecs, device=0):
+    """f-2 inverse on HOST arrays (``ecb_hapcsc_to_csr``): per-haplotype CSC -> CSR(bitmask) (indptr, indices, data), int32."""
+    lib = load()
+    cptr = np.ascontiguousarray(csc_indptr, dtype=np.int32)
+    cidx = np.ascontiguousarray(csc_indices, dtype=np.int32)
+    H, T1 = cptr.shape
+    total = len(cidx)
+    ip = np.empty(n_ecs + 1, dtype=np.int32)
+    ix = np.empty(max(total, 1), dtype=np.int32)
+    da = np.empty(max(total, 1), dtype=np.int32)
+    nnz = C.c_uint64()
+    rc = lib.ecb_hapcsc_to_csr(device, n_ecs, T1 - 1, H, _ptr(cptr), _ptr(cidx), total, _ptr(ip), _ptr(ix), _ptr(da), C.byref(nnz))
+    if rc != 0:
+        raise EcbError(rc, (lib.ecb_last_error(None) or b"").decode())
+    return ip, ix[:nnz.value], da[:nnz.value]
 
 
 def hapcsc_to_csr(csc_indptr, csc_indices, n_ecs):
@@ -431,3 +482,7 @@ class EcBuilder(object):
         ms, n, r = C.c_double(), C.c_uint64(), C.c_uint64()
         self._chk(self._lib.ecb_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(r)))
         return ms.value, n.value, r.value
+
+    def profile_kernel(self):
+        """Name of the stream kernel the last batch launched (as rocprofv3 prints it)."""
+        return (self._lib.ecb_profile_kernel(self._h) or b"").decode() if hasattr(self._lib, "ecb_profile_kernel") else ""

@@ -42,24 +42,18 @@ class _Csc(object):
 
 
 def _device(device=None):
-    """The GPU the conversions run on: the one named, else ``ALNTOOLS_GPU`` (default 0)."""
+    """Index of the GPU the conversions run on: the one named, else ``ALNTOOLS_GPU`` (default 0)."""
     import os
-    import torch
-    return torch.device("cuda", int(os.environ.get("ALNTOOLS_GPU", "0")) if device is None else int(device))
+    return int(os.environ.get("ALNTOOLS_GPU", "0")) if device is None else int(device)
 
 
 def device_hapcsc(m, device=None):
-    """CSR(bitmask) A -> one CSC matrix per haplotype, on the GPU (``ecb_csr_to_hapcsc_device``: the sparse-format half of
+    """CSR(bitmask) A -> one CSC matrix per haplotype, on the GPU (``ecb_csr_to_hapcsc``: the sparse-format half of
     ``bin_utils.ec2emase`` / ``Sparse3DMatrix.finalize``, ``bin_utils.py:979-995``, ``Sparse3DMatrix.py:189-193``).
+    Host arrays in, host arrays out -- libecb holds the device buffers itself, PyTorch is not involved.
     No CPU path: without a GPU this raises, like the rest of the hot path."""
-    import torch
     from . import ecb
-    if not torch.cuda.is_available():
-        raise RuntimeError("the CSR -> per-haplotype CSC conversion runs on the GPU (libecb); no HIP device is visible")
-    dev = _device(device)
-    ip, ix, da = (torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev) for a in (m.indptrA, m.indicesA, m.dataA))
-    cptr, cidx = ecb.csr_to_hapcsc(ip, ix, da, m.num_loci, m.num_haplotypes)
-    cptr, cidx = cptr.cpu().numpy(), cidx.cpu().numpy()
+    cptr, cidx = ecb.csr_to_hapcsc_host(m.indptrA, m.indicesA, m.dataA, m.num_loci, m.num_haplotypes, _device(device))
     out, start = [], 0
     for h in range(m.num_haplotypes):
         n = int(cptr[h, -1])
@@ -69,17 +63,12 @@ def device_hapcsc(m, device=None):
 
 
 def device_csr(parts, n_ecs, n_loci, device=None):
-    """Per-haplotype CSC (indptr, indices) -> CSR(bitmask) A = sum_h 2^h M_h, on the GPU (``ecb_hapcsc_to_csr_device``:
+    """Per-haplotype CSC (indptr, indices) -> CSR(bitmask) A = sum_h 2^h M_h, on the GPU (``ecb_hapcsc_to_csr``:
     ``bin_utils.emase2ec``, ``bin_utils.py:998-1028``)."""
-    import torch
     from . import ecb
-    if not torch.cuda.is_available():
-        raise RuntimeError("the per-haplotype CSC -> CSR conversion runs on the GPU (libecb); no HIP device is visible")
-    dev = _device(device)
-    cptr = torch.from_numpy(np.stack([np.asarray(ip, dtype=np.int32) for ip, _ in parts])).to(dev)
-    cidx = torch.from_numpy(np.concatenate([np.asarray(ix, dtype=np.int32) for _, ix in parts])).to(dev)
-    ip, ix, da = ecb.hapcsc_to_csr(cptr, cidx, n_ecs)
-    return ip.cpu().numpy(), ix.cpu().numpy(), da.cpu().numpy()
+    cptr = np.stack([np.asarray(ip, dtype=np.int32) for ip, _ in parts])
+    cidx = np.concatenate([np.asarray(ix, dtype=np.int32) for _, ix in parts])
+    return ecb.hapcsc_to_csr_host(cptr, cidx, n_ecs, _device(device))
 
 
 def save(h5file, m, title=None, incidence_only=True, count_2d=None, hapcsc=device_hapcsc, device=None):

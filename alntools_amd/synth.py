@@ -39,6 +39,7 @@ GEN_VERSION = 2  # bump when the stream changes: committed fixtures depend on it
 
 _NLOCI_CHOICES = (1, 1, 2, 3, 5)
 _MAXL = 5
+_MAXP = 3   # further loci a read may hit anywhere among the targets ("paralogs", SynthSpec.paralog_pct)
 _M64 = (1 << 64) - 1
 
 
@@ -181,13 +182,17 @@ class SynthSpec(object):
     """Parameters of one synthetic workload."""
 
     def __init__(self, n_reads, n_loci, n_haps, paired=False, seed=SEED, n_variants=4,
-                 unmapped_read_pct=4, dup_pct=2, locus_stride=1):
+                 unmapped_read_pct=4, dup_pct=2, locus_stride=1, paralog_pct=0):
         if not 1 <= n_haps <= 8:
             raise ValueError("synthetic generator supports 1..8 haplotypes")
         self.n_reads, self.n_loci, self.n_haps = int(n_reads), int(n_loci), int(n_haps)
         self.paired, self.seed, self.n_variants = bool(paired), int(seed), int(n_variants)
         self.unmapped_read_pct, self.dup_pct = int(unmapped_read_pct), int(dup_pct)
         self.locus_stride = int(locus_stride)       # a read's loci are base, base + stride, ... (1: consecutive target ids, the default and what the fixtures hold)
+        # this percentage of the reads hit 1 - 3 further loci besides their cluster: the cluster's "paralogs", three loci drawn uniformly
+        # over all targets per base locus (multi-mappers at unrelated target ids; 0: none, the default and what the fixtures hold --
+        # the stream is then unchanged)
+        self.paralog_pct = int(paralog_pct)
 
     # header --------------------------------------------------------------
     def hap_names(self):
@@ -217,19 +222,30 @@ def _per_read(spec, be, r):
         nl = be.where(nl > T, T, nl)
     v = _pos(_rnd(seed, r, 3)) % spec.n_variants
     pc = be.lut(_popcount8_lut())
-    masks, cnts = [], []
-    for j in range(_MAXL):
-        loc = (base + j * spec.locus_stride) % T
+    masks, cnts, locs = [], [], []
+    nslots = _MAXL + (_MAXP if spec.paralog_pct else 0)
+    if spec.paralog_pct:
+        n_par = be.where(_pos(_rnd(seed, r, 20)) % 100 < spec.paralog_pct, 1 + _pos(_rnd(seed, r, 21)) % _MAXP, 0)
+    for j in range(nslots):
+        if j < _MAXL:
+            loc = (base + j * spec.locus_stride) % T
+            here = nl > j
+        else:
+            loc = _pos(_rnd(seed ^ 0x9A7A, base * 8 + j, 22)) % T     # (a property of the cluster, not of the read: paralogs are fixed relations, and the ECs stay few)
+            here = n_par > (j - _MAXL)
         m = loc * 0
         for h in range(H):
             hv = _pos(_rnd(seed ^ 0x5EED, loc * 64 + v * 8 + h, 7)) % 100
             m = m | be.where(hv < 85, 1 << h, 0)
         forced = (m * 0 + 1) << (_pos(_rnd(seed ^ 0x5EED, loc * 64 + v * 8, 9)) % H)
         m = be.where(m == 0, forced, m)
-        m = be.where(nl > j, m, 0)
+        m = be.where(here, m, 0)
         masks.append(m)
         cnts.append(be.take(pc, m))
+        locs.append(loc)
     n_al = cnts[0] + cnts[1] + cnts[2] + cnts[3] + cnts[4]
+    for j in range(_MAXL, nslots):
+        n_al = n_al + cnts[j]
     dup = (_pos(_rnd(seed, r, 4)) % 100 < spec.dup_pct)
     n_al_d = n_al + be.where(dup, 1, 0)           # alignments incl. the duplicate
     rot = _pos(_rnd(seed, r, 5)) % n_al
@@ -243,7 +259,7 @@ def _per_read(spec, be, r):
         n_unm = be.where(e < 15, 2, be.where(e < 50, 1, 0))
         n_rec = be.where(unm_read, 1, n_al_d + n_unm)
     upos = _pos(_rnd(seed, r, 10)) % n_al_d        # unmapped records sit before alignment `upos`
-    return dict(base=base, nl=nl, masks=masks, cnts=cnts, n_al=n_al, n_al_d=n_al_d, dup=dup,
+    return dict(base=base, nl=nl, masks=masks, cnts=cnts, locs=locs, n_al=n_al, n_al_d=n_al_d, dup=dup,
                 rot=rot, unm_read=unm_read, n_unm=n_unm, n_rec=n_rec, upos=upos)
 
 
@@ -305,15 +321,18 @@ def generate(spec, r0, r1, device=None, want_raw=False, read_id_base=0):
     rem = a
     done = a < 0
     mask_sel = a * 0
-    for jj in range(_MAXL):
+    loc_sel = a * 0
+    for jj in range(len(pr["cnts"])):
         c = g(pr["cnts"][jj])
         hit = (~done) & (rem < c)
         j = be.where(hit, jj, j)
         mask_sel = be.where(hit, g(pr["masks"][jj]), mask_sel)
+        if spec.paralog_pct:
+            loc_sel = be.where(hit, g(pr["locs"][jj]), loc_sel)
         rem = be.where(done | hit, rem, rem - c)
         done = done | hit
     hap = be.take(kth, mask_sel * 8 + rem)
-    locus = (g(pr["base"]) + j * spec.locus_stride) % T
+    locus = loc_sel if spec.paralog_pct else (g(pr["base"]) + j * spec.locus_stride) % T
     tid = locus * H + hap
     length = 500 + (locus * 7919) % 4500
     pos = _pos(_rnd(seed, rr * 64 + a, 11)) % length

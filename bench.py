@@ -39,9 +39,17 @@ WORKLOADS = {
     "c4h": (100_000_000, 80_000, 8, True, "half of config 4 (debug)"),
     "c3s": (100_000_000, 80_000, 8, True, "config 3 with every read's loci 64 target ids apart (their low bits equal: the worst case for the stream kernel's LDS table)"),
     "c3q": (100_000_000, 80_000, 8, True, "config 3 with every read's loci 4 target ids apart: the third locus of a read collides with its first in the LDS table (reads of three loci and more: two in five)"),
+    "c3r": (100_000_000, 80_000, 8, True, "config 3 with paralogs: 30 % of the reads hit 1 - 3 further loci drawn uniformly over all targets besides their cluster of consecutive ids (multi-mappers at unrelated target ids: first-probe collisions in the LDS table at the birthday rate)"),
     "dip": (200_000_000, 40_000, 2, False, "diploid single-end reads: 2 hap x 40k transcripts, ~4 records per read (short reads: several passes per tile)"),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+
+def workload_spec(name):
+    """The synthetic stream a workload name stands for."""
+    from alntools_amd import synth
+    R, T, H, paired, _ = WORKLOADS[name]
+    return synth.SynthSpec(R, T, H, paired=paired, locus_stride={"c3s": 64, "c3q": 4}.get(name, 1), paralog_pct=30 if name == "c3r" else 0)
 
 
 def generate_shard(spec, r0, r1, device, chunk_reads=1 << 20):
@@ -316,7 +324,7 @@ def main():
     red_dev = torch.device("cpu") if rehearsal else device          # where the small reductions of the timing live
 
     R, T, H, paired, desc = WORKLOADS[args.workload]
-    spec = synth.SynthSpec(R, T, H, paired=paired, locus_stride={"c3s": 64, "c3q": 4}.get(args.workload, 1))
+    spec = workload_spec(args.workload)
     r0, r1 = rank * R // world, (rank + 1) * R // world
     t_gen = time.perf_counter()
     rid, loc, hf, st = generate_shard(spec, r0, r1, device)
@@ -325,7 +333,7 @@ def main():
 
     # EC-table slots: sized for the workload's EC count (c3: 3.7 M ECs) so that the timed steps do not grow it
     # (a shard of 1/4 or 1/8 of config 3 still founds 2.3 - 3 M of its 3.7 M ECs: 2^23 slots keep it under half full)
-    ec_cap = 1 << int(os.environ.get("ECB_EC_CAP_LOG2", ("23" if world >= 4 else "24") if args.workload in ("c3", "c3h", "c3s", "c3q", "c4", "c4h") else "22"))
+    ec_cap = 1 << int(os.environ.get("ECB_EC_CAP_LOG2", ("23" if world >= 4 else "24") if args.workload in ("c3", "c3h", "c3s", "c3q", "c3r", "c4", "c4h") else "22"))
     b = ecb.EcBuilder(T, H, device=local, ec_capacity=ec_cap, arena_capacity=1 << 26)
     hint = 0 if os.environ.get("ECB_NO_HINT") else st["reads"]      # (a caller that knows how many reads its stream holds says so: one host wait per push)
     b.hint_reads(hint)

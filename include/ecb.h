@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define ECB_ABI_VERSION 3
+#define ECB_ABI_VERSION 4
 
 #define ECB_OK               0
 #define ECB_ERR_ARG         -1   /* bad argument / configuration */
@@ -260,9 +260,22 @@ int ecb_hapcsc_to_csr_device(int device, uint32_t n_ecs, uint32_t n_loci, uint32
                              const void* d_csc_indices, uint64_t total, void* d_indptr_a, void* d_indices_a,
                              void* d_data_a, uint64_t* nnz);
 
-/* Measurement: HIP-event time of the record-stream kernel on the handle's own stream. */
+/* The same two conversions from and to HOST arrays (ABI 4): the library allocates, fills and frees its own device buffers, so a
+ * host that only converts files needs no device allocator -- what the reference's ec2emase / emase2ec and the .h5 writer of
+ * bam2emase do on the CPU (bin_utils.py:979-1028, Sparse3DMatrix.py:189-193).
+ * ecb_csr_to_hapcsc: csc_indices == NULL -> *total = number of row indices (set bits of the masks) and nothing else; otherwise
+ *   csc_indptr holds H x (T+1) int32 and csc_indices `capacity` int32 (ECB_ERR_ARG when that is too few; *total says how many).
+ * ecb_hapcsc_to_csr: indices / data hold `total` int32 each (an upper bound of the non-zeros), indptr n_ecs + 1; *nnz = non-zeros. */
+int ecb_csr_to_hapcsc(int device, uint32_t n_ecs, uint32_t n_loci, uint32_t n_haps, const int32_t* indptr_a, const int32_t* indices_a,
+                      const int32_t* data_a, int32_t* csc_indptr, int32_t* csc_indices, uint64_t capacity, uint64_t* total);
+int ecb_hapcsc_to_csr(int device, uint32_t n_ecs, uint32_t n_loci, uint32_t n_haps, const int32_t* csc_indptr, const int32_t* csc_indices,
+                      uint64_t total, int32_t* indptr_a, int32_t* indices_a, int32_t* data_a, uint64_t* nnz);
+
+/* Measurement: HIP-event time of the record-stream kernel on the handle's own stream; ecb_profile_kernel (ABI 4): the name of the
+ * kernel the last batch launched, as rocprofv3 prints it (the stream kernel is compiled more than once; the library picks per batch). */
 int ecb_profile(ecb_handle* h, int enable);
 int ecb_profile_read(ecb_handle* h, double* kernel_ms, uint64_t* launches, uint64_t* records);
+const char* ecb_profile_kernel(const ecb_handle* h);
 
 #ifdef __cplusplus
 }

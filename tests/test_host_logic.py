@@ -117,7 +117,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     assert declared == set(ecb.SYMBOLS), declared ^ set(ecb.SYMBOLS)
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.ecb_abi_version() == 3
+    assert lib.ecb_abi_version() == ecb.ABI_VERSION == 4
     # the host-side decoder library and its header
     from alntools_amd import bamdec
     bamdec.build()
