@@ -10,6 +10,7 @@ Not reproduced: the chunk-file plumbing that only exists to feed one pysam reade
 from __future__ import annotations
 
 import os
+import subprocess
 import time
 
 import numpy as np
@@ -36,6 +37,8 @@ def open_bam(filename, names=True, ms=False):
                 return bamdec.NativeBamReader(filename)
             except ValueError:                       # not BGZF / not BAM (SAM, CRAM ...): what pysam, the reference's reader, may still open
                 pass
+            except (ImportError, OSError, subprocess.CalledProcessError) as e:      # a stale library that cannot be rebuilt here (no compiler, read-only tree)
+                LOG.warning("libbamdec.so is not usable ({}): the file is decoded by the Python-level reader instead".format(e))
     try:
         import pysam
     except ImportError:
@@ -148,23 +151,53 @@ def _log_summary(maps, sizes):
 
 def _deal_out(reader, enc, world, builder, track, group_send):
     """Rank 0 of a multi-GPU run: decode the file ONCE and deal its records out in contiguous read ranges -- the reference plans its
-    chunks once and gives every process its own (``bam_utils.py:1174-1304, 646-680``).  The owner of the records being decoded
-    moves on from rank r to r + 1 when the decoder is (r + 1) / world of the way through the file, at the next read boundary;
-    rank 0 pushes its own share as it goes.  ``group_send(dst, arrays or None)`` ships one batch (``None``: nothing more)."""
+    chunks once and gives every process its own (``bam_utils.py:1174-1304, 646-680``).  Rank r is to have the reads between
+    r / world and (r + 1) / world of the way through the file (by the decoder's ``progress()``: compressed bytes of the records
+    parsed so far, no read-ahead counted); a batch that covers the stretch [p0, p1] of the file is cut where those marks fall
+    within it, in proportion, at the next read that starts -- so a file of a single batch is shared out like a long one.
+    Rank 0 pushes its own share as it goes.  ``group_send(dst, arrays or None)`` ships one batch (``None``: nothing more); what is
+    shipped is always WHOLE reads -- the records of the read that is still open at the end of a batch wait for the next one -- so
+    that a receiver may push a message from where it lands (``ecb_push_device`` takes whole reads).
+    A reader that cannot say how far it is (the pysam fall-back) leaves everything with rank 0: said in the log.
+    -> records dealt to each rank."""
     owner, base, dealt = 0, 0, 0                      # the rank being fed, the run counter of its first read, records it has had
     prev = 0xFFFFFFFF                                 # run counter of the record before the batch
     prog = getattr(reader, "progress", None)
+    per_rank = [0] * world
+    p0 = 0.0
+    held = None                                       # the open read of the rank being fed (its columns), not shipped yet
+
+    def ship(dst, part, last):
+        """``part``: the next records of rank ``dst`` (columns, read ids local); ``last``: nothing of this rank's follows."""
+        nonlocal held
+        if held is not None:
+            part = [np.concatenate([h, c]) for h, c in zip(held, part)]
+            held = None
+        if not last and len(part[0]):
+            rid_ = part[0]
+            k = len(rid_) - 1                         # first record of the trailing run of equal read ids (invalid records carry the id before them)
+            tail = rid_[k]
+            while k > 0 and rid_[k - 1] == tail:
+                k -= 1
+            held = [c[k:] for c in part]
+            part = [c[:k] for c in part]
+        if len(part[0]):
+            group_send(dst, part)
+
     for t in iter_tuple_batches(reader, enc):
         rid = t["read_id"]
+        n = len(rid)
+        p1 = max(p0, min(1.0, float(prog()))) if prog else 0.0
         cols = [rid, t["locus"], t["hapflag"]] + ([t["pos"]] if track else [])
         before = np.concatenate([np.asarray([prev], dtype=rid.dtype), rid[:-1]])
         starts = np.flatnonzero((rid != before) & (rid != 0xFFFFFFFF))      # records that start a read
         lo = 0
         while True:
-            target = min(world - 1, int(world * prog())) if prog else 0
-            cut = len(rid)
-            if target > owner:                       # hand over at the next read that starts (a rank that has had nothing keeps what starts here)
-                cand = starts[starts >= lo] if dealt else starts[starts > lo]
+            cut = n
+            mark = (owner + 1) / float(world)
+            if owner < world - 1 and mark <= p1:     # the owner's stretch ends within this batch (or did before it, with no read starting since)
+                at = lo if mark <= p0 else max(lo, int(n * (mark - p0) / max(p1 - p0, 1e-12)))
+                cand = starts[starts >= at] if (dealt or at > lo) else starts[starts > lo]      # (a rank that has had nothing keeps what starts here)
                 if len(cand):
                     cut = int(cand[0])
             if cut > lo:
@@ -173,16 +206,28 @@ def _deal_out(reader, enc, world, builder, track, group_send):
                 if owner == 0:
                     builder.push(local, part[1], part[2], part[3] if track else None)
                 else:
-                    group_send(owner, [local] + part[1:])
+                    ship(owner, [local] + part[1:], cut < n)      # (cut < n: the next read belongs to the next rank)
                 dealt += cut - lo
-            if cut == len(rid):
+                per_rank[owner] += cut - lo
+            if cut == n:
                 break
+            if held is not None:                     # (nothing of this rank's in the batch, but its open read ends here)
+                group_send(owner, held)
+                held = None
             owner += 1                               # (the read at `cut` is the new owner's read 0)
             base = int(rid[cut])
             lo, dealt = cut, 0
         prev = int(rid[-1])
+        p0 = p1
+    if held is not None:                              # the stream ended: the open read is complete
+        group_send(owner, held)
+        held = None
     for r in range(1, world):
         group_send(r, None)
+    if world > 1 and min(per_rank) * 4 * world < sum(per_rank):
+        LOG.warning("uneven deal-out over {} ranks (records per rank: {}){}".format(
+            world, per_rank, "" if prog else ": this reader does not report its progress, every record stayed with rank 0"))
+    return per_rank
 
 
 def _rank_convert(rank, world, port, backend, devices, bam_filename, ec_filename, emase_filename, range_filename, sample,
@@ -202,10 +247,14 @@ def _rank_convert(rank, world, port, backend, devices, bam_filename, ec_filename
     dev_index = devices[rank]
     device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
+    # (a rank waits in its first receive until the decoder has reached its share of the file: minutes on a large BAM -- the
+    #  process group's default timeout, ten minutes under nccl, would abort the job)
+    import datetime
+    patience = datetime.timedelta(seconds=int(os.environ.get("ALNTOOLS_DIST_TIMEOUT_S", str(24 * 3600))))
     if backend == "nccl":
-        tdist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        tdist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=patience)
     else:
-        tdist.init_process_group(backend, rank=rank, world_size=world)
+        tdist.init_process_group(backend, rank=rank, world_size=world, timeout=patience)
     wire = device if backend == "nccl" else torch.device("cpu")        # where a message lives while it travels
     targets = list(utils.parse_targets(target_filename).keys()) if target_filename else None
     track = range_filename is not None
@@ -218,9 +267,12 @@ def _rank_convert(rank, world, port, backend, devices, bam_filename, ec_filename
         def send(dst, arrays):
             n = 0 if arrays is None else len(arrays[0])
             tdist.send(torch.tensor([n, 0 if arrays is None else 1], dtype=torch.int64, device=wire), dst)
-            if n:
-                msg = torch.from_numpy(np.concatenate([np.ascontiguousarray(a).view(np.int32) for a in arrays])).to(wire)
-                tdist.send(msg, dst)
+            if n:       # one message: the columns back to back, each padded to whole 16 bytes (what ecb_push_device asks of a stream)
+                ns = (n + 3) & ~3
+                host = np.zeros(ns * len(arrays), dtype=np.int32)
+                for i, a in enumerate(arrays):
+                    host[i * ns:i * ns + n] = np.ascontiguousarray(a).view(np.int32)
+                tdist.send(torch.from_numpy(host).to(wire), dst)
         _deal_out(reader, TupleEncoder(maps), world, b, track, send)
         reader.close()
     else:
@@ -231,11 +283,17 @@ def _rank_convert(rank, world, port, backend, devices, bam_filename, ec_filename
             n, more = (int(x) for x in head.cpu().tolist())
             if not more:
                 break
-            msg = torch.empty(n * n_cols, dtype=torch.int32, device=wire)
+            ns = (n + 3) & ~3
+            msg = torch.empty(ns * n_cols, dtype=torch.int32, device=wire)
             tdist.recv(msg, 0)
-            a = msg.cpu().numpy()
-            cols = [a[i * n:(i + 1) * n] for i in range(n_cols)]
-            b.push(cols[0].view(np.uint32), cols[1].view(np.uint32), cols[2].view(np.uint32), cols[3] if track else None)
+            if wire.type == "cuda":                   # over RCCL the tuples arrive in HBM: pushed from where they are
+                torch.cuda.current_stream(device).synchronize()      # (libecb works on its own stream)
+                cols = [msg[i * ns:i * ns + n] for i in range(n_cols)]
+                b.push_device(cols[0], cols[1], cols[2], cols[3] if track else None)
+            else:
+                a = msg.numpy()
+                cols = [a[i * ns:i * ns + n] for i in range(n_cols)]
+                b.push(cols[0].view(np.uint32), cols[1].view(np.uint32), cols[2].view(np.uint32), cols[3] if track else None)
     wrap = lambda e: e if backend == "nccl" else ecdist.HostStagedEngine(e)
     eng = wrap(ecdist.GpuEngine(b, device))
     fresh = lambda: wrap(ecdist.GpuEngine(EcBuilder(maps.n_loci, maps.n_haplotypes, device=dev_index, track_ranges=False), device))

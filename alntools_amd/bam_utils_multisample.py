@@ -221,8 +221,9 @@ def _rank_convert(rank, world, port, backend, devices, bam_files, ec_filename, e
     """One process per GPU.  Rank r takes the files ``[r F / world, (r + 1) F / world)`` -- contiguous, so the run's read order is
     the reference's file order -- and builds the EC table of their reads on its GPU; cell ids are agreed on first (names in the
     order the files bring them up: rank 0's cells first, then what rank 1 adds ...: the single process's ids); the tables are
-    merged by key range over the process group (``dist.exchange_and_merge``) and adopted by rank 0, every rank reduces its reads
-    to (EC, cell, file) triples against the merged ECs (``dist.exchange_multisample``), and rank 0 filters and writes."""
+    merged by key range over the process group (``dist.exchange_and_merge``), every rank finalizes the range it merged and rank 0
+    places the rows, every rank reduces its reads to (EC, cell, file) triples against the merged ECs
+    (``dist.exchange_multisample``), and rank 0 filters and writes."""
     import json
     import pickle
     import torch
@@ -235,10 +236,12 @@ def _rank_convert(rank, world, port, backend, devices, bam_files, ec_filename, e
     dev_index = devices[rank]
     device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
+    import datetime
+    patience = datetime.timedelta(seconds=int(os.environ.get("ALNTOOLS_DIST_TIMEOUT_S", str(24 * 3600))))      # (ranks scan files of very different sizes)
     if backend == "nccl":
-        tdist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        tdist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=patience)
     else:
-        tdist.init_process_group(backend, rank=rank, world_size=world)
+        tdist.init_process_group(backend, rank=rank, world_size=world, timeout=patience)
     red = device if backend == "nccl" else torch.device("cpu")
     maps = _header_maps(bam_files, target_filename)
     F = len(bam_files)
@@ -291,7 +294,11 @@ def _rank_convert(rank, world, port, backend, devices, bam_files, ec_filename, e
     eng = wrap(ecdist.GpuEngine(b, device))
     plain = lambda: wrap(ecdist.GpuEngine(EcBuilder(maps.n_loci, maps.n_haplotypes, device=dev_index), device))
     root = lambda: wrap(ecdist.GpuEngine(EcBuilder(maps.n_loci, maps.n_haplotypes, device=dev_index, multisample=True), device))
-    merged = ecdist.exchange_and_merge(eng, plain, root, root=0, finalize_ranges=False)      # (the second exchange looks ECs up in the root's table)
+    # Every rank ranks and emits the key range it merged; the root only places the rows (``ecb_assemble_ranges_device``) and takes the
+    # ECs' hashes off the finished rows for the second exchange -- it no longer adopts every merged table and finalizes alone.
+    # (ALNTOOLS_DIST_FINALIZE=root: the earlier ending, the merged tables adopted by the root.)
+    per_range = os.environ.get("ALNTOOLS_DIST_FINALIZE", "ranges") != "root"
+    merged = ecdist.exchange_and_merge(eng, plain, root, root=0, finalize_ranges=per_range)
     sizes, n_ecs = None, 0
     if rank == 0:
         sizes = merged.b.finalize()

@@ -20,16 +20,27 @@ LIB_PATH = os.path.join(_HERE, "libbamdec.so")
 SRC = os.path.join(_HERE, "csrc", "bamdec.c")
 SYMBOLS = ("bd_abi_version", "bd_open", "bd_close", "bd_last_error", "bd_n_references", "bd_reference_name",
            "bd_reference_length", "bd_header_text", "bd_references", "bd_read", "bd_read_tuples", "bd_read_ms", "bd_ms_cells", "bd_progress")
-ABI_VERSION = 3            # include/bamdec.h: bd_abi_version()
+ABI_VERSION = 4            # include/bamdec.h: bd_abi_version()
 _lib = None
 
 
 def build(force=False):
     """gcc + zlib, in-tree (``python -m alntools_amd.build`` calls this too)."""
     import subprocess
+    import tempfile
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= os.path.getmtime(SRC):
         return LIB_PATH
-    subprocess.check_call([os.environ.get("CC", "gcc"), "-O2", "-Wall", "-shared", "-fPIC", "-o", LIB_PATH, SRC, "-lz", "-lpthread"])
+    # into a file of its own, then moved into place in one step: several ranks of one run may get here at the same moment, and a
+    # sibling may be mapping the library while another writes it
+    fd, tmp = tempfile.mkstemp(prefix=".libbamdec.", suffix=".so", dir=_HERE)
+    os.close(fd)
+    try:
+        subprocess.check_call([os.environ.get("CC", "gcc"), "-O2", "-Wall", "-shared", "-fPIC", "-o", tmp, SRC, "-lz", "-lpthread"])
+        os.chmod(tmp, 0o755)
+        os.replace(tmp, LIB_PATH)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB_PATH
 
 
@@ -40,7 +51,7 @@ def available():
 def lib():
     global _lib
     if _lib is None:
-        if os.path.exists(SRC) and os.path.getmtime(LIB_PATH) < os.path.getmtime(SRC):
+        if os.path.exists(SRC) and (not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(SRC)):
             build()                                  # (a library older than its source: the argument lists below may not be its own)
         l = C.CDLL(LIB_PATH)
         l.bd_abi_version.restype = C.c_int
@@ -164,7 +175,8 @@ class NativeBamReader(object):
                     next_pos=self._i32[3][:k], valid=self._u8[0][:k], newrun=self._u8[1][:k]), cells
 
     def progress(self):
-        """Fraction of the file taken in so far (compressed bytes, read-ahead included): monotone, 1.0 at the end."""
+        """Fraction of the file the records handed out so far reach (compressed bytes; what is read ahead but not parsed yet is not
+        counted): monotone, 1.0 at the end."""
         a, b = C.c_uint64(0), C.c_uint64(0)
         if self._l.bd_progress(self._h, C.byref(a), C.byref(b)) != 0 or not b.value:
             return 0.0

@@ -28,13 +28,15 @@ def build(force=False, verbose=False):
         bamdec.build(force=force)                # the host side's BAM decoder (plain C + zlib): a library of its own, and optional --
     except (OSError, subprocess.CalledProcessError) as e:             # without it the pure-Python reader (or pysam) decodes
         print("warning: libbamdec.so not built (%s): BAM files will be decoded by the Python reader" % e, file=sys.stderr)
-    build_tools(force=force)
-    if not force and not needs_build():
-        return OUT
-    cmd = [HIPCC] + FLAGS + ["-o", OUT, SRC]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    if force or needs_build():
+        cmd = [HIPCC] + FLAGS + ["-o", OUT, SRC]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    try:
+        build_tools(force=force)                 # (a measurement helper: never the reason the product library is missing)
+    except (OSError, subprocess.CalledProcessError) as e:
+        print("warning: tools/micro/copy_peak.hip not built (%s): bench.py falls back to torch's copy for its measured peak" % e, file=sys.stderr)
     return OUT
 
 

@@ -37,6 +37,7 @@ typedef struct bd_handle {
     bd_block blocks[BLOCKS_PER_FILL];
     int n_threads;
     int eof;
+    uint64_t fill_cstart, fill_clen, fill_ulen; /* the last refill: where its compressed bytes start in the file, how many, and what they inflated to */
     /* header */
     char* text; int32_t l_text; int32_t n_ref; char** names; int32_t* lens;
     char* ref_blob; size_t ref_blob_len;
@@ -81,6 +82,7 @@ static int refill(bd_handle* h) {
     if (h->pos) { memmove(h->buf, h->buf + h->pos, h->len - h->pos); h->len -= h->pos; h->pos = 0; }
     size_t raw_used = 0, out_total = 0;
     int nb = 0;
+    const long c_at = ftell(h->f);
     while (nb < BLOCKS_PER_FILL) {
         uint8_t hd[18];
         const size_t got = fread(hd, 1, 18, h->f);
@@ -143,6 +145,7 @@ static int refill(bd_handle* h) {
         for (int t = 0; t < nt; ++t) if (jobs[t].rc != BD_OK) return fail(h, jobs[t].rc, "corrupt BGZF block");
     }
     h->len += out_total;
+    { const long c_end = ftell(h->f); h->fill_cstart = c_at < 0 ? 0 : (uint64_t)c_at; h->fill_clen = c_end > c_at ? (uint64_t)(c_end - c_at) : 0; h->fill_ulen = out_total; }
     return BD_OK;
 }
 
@@ -159,14 +162,20 @@ static int need(bd_handle* h, size_t n) {
 static inline int32_t rd_i32(const uint8_t* p) { int32_t v; memcpy(&v, p, 4); return v; }   /* (little-endian hosts only, like the rest of the repo) */
 
 /* ---- API ------------------------------------------------------------------------------------------------------- */
-int bd_abi_version(void) { return 3; }
+int bd_abi_version(void) { return 4; }
 
-/* how far the file has been read (compressed bytes, read-ahead included) and how long it is: a monotone measure of progress */
+/* How far the records handed out so far reach into the file, in compressed bytes, and how long the file is: a monotone measure of
+ * progress.  What has been read ahead and inflated but not parsed yet is NOT counted (up to 512 blocks -- a whole small file --
+ * sit in the buffer at a time): the unread part of the last refill is taken off in proportion to its inflated size.  (ABI 3 counted
+ * the read-ahead, which made a multi-GPU deal-out of a small file hand nearly everything to the last rank.) */
 int bd_progress(bd_handle* h, uint64_t* consumed, uint64_t* total) {
     if (!h || !h->f || !consumed || !total) return BD_ERR_ARG;
-    const long at = ftell(h->f);
-    if (at < 0) return fail(h, BD_ERR_IO, "ftell");
-    *consumed = (uint64_t)at; *total = h->file_size;
+    uint64_t unread = (uint64_t)(h->len - h->pos);
+    if (unread > h->fill_ulen) unread = h->fill_ulen;
+    const uint64_t back = h->fill_ulen ? (uint64_t)((double)h->fill_clen * (double)unread / (double)h->fill_ulen) : 0;
+    uint64_t at = h->fill_cstart + h->fill_clen - back;
+    if (h->eof && unread == 0) at = h->file_size;
+    *consumed = at > h->file_size ? h->file_size : at; *total = h->file_size;
     return BD_OK;
 }
 

@@ -1449,6 +1449,16 @@ __global__ void k_export_keys(const Slot* table, const u32* order, u64 n, u64* o
     const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (e < n) out[e] = table[order[e]].lo;
 }
+// ... and where no table stands behind the result (it was assembled from per-range pieces): the hash of an EC is a function of its
+// key alone -- the sum of its pairs' hashes, as the stream kernel forms it -- so it is taken from the finished CSR row
+__global__ void k_row_keys(const u32* indptr, const int* indices, const int* data, u64 n, u64* out) {
+    const u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const u32 a = indptr[e], z = indptr[e + 1];
+    u64 acc = 0;
+    for (u32 i = a; i < z; ++i) acc += pair_hash64((u32)indices[i], (u32)data[i]);
+    out[e] = finish_hash(acc, z - a);
+}
 // EC e of the merged result = (hash keys[e], CSR row e with ascending loci).  Find it in this shard's table, by its hash and
 // then by its key, pair for pair: grank[slot] = e.
 __global__ void k_set_global_rank(const u64* keys, const int* indptr, const int* indices, const int* data, u64 n,
@@ -2348,6 +2358,9 @@ int grow_table(ecb_handle* h, u64 new_cap) {
     POOL(h, P_REMAP, remap, h->cap);
     HIPCHK(h, hipMalloc(&nt, new_cap * sizeof(Slot)));
     hipError_t e = hipMemsetAsync(nt, 0, new_cap * sizeof(Slot), h->stream);
+    // (slots the old table did not hold map to PENDING: read_slot may hold slot ids of an EARLIER stream beyond the reads processed so far --
+    //  ecb_reset leaves them, ecb_hint_reads makes reads_hi run ahead of the stream -- and what such an entry maps to must not be pool garbage)
+    if (e == hipSuccess) e = hipMemsetAsync(remap, 0xFF, h->cap * sizeof(u32), h->stream);
     if (e == hipSuccess) {
         k_rehash<<<2048, TPB, 0, h->stream>>>(h->table, h->cap, nt, new_cap - 1, remap);
         if (h->reads_hi)
@@ -2427,7 +2440,7 @@ int plan_stream(ecb_handle* h, u64 n, StreamPlan* P, bool ranges = false, bool s
         int bpr = 4;                                   // (the variant with the range update has fewer waves resident)
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpr, ks_std::k_stream<false, true>, TPB, 0);
         h->resident_blocks_rg = (u64)std::max(cus, 1) * std::max(bpr, 1);
-        int bps = 3;                                   // (the variant for short reads: 13 KB of LDS per wave)
+        int bps = 4;                                   // (the variant for short reads: 9.9 KB of LDS per wave, four workgroups per CU)
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&bps, ks_short::k_stream<false>, TPB, 0);
         h->resident_blocks_sh = (u64)std::max(cus, 1) * std::max(bps, 1);
         h->rounds = getenv("ECB_ROUNDS") ? std::max(1, atoi(getenv("ECB_ROUNDS"))) : 24;   // (16 .. 32 measure alike on C3; fewer slices = fewer slice tails read twice)
@@ -3037,7 +3050,10 @@ int ecb_reset(ecb_handle* h) {
     if (h->wave_arena) HIPCHK(h, hipMemsetAsync(h->wave_arena, 0, 2 * h->wave_arena_n * sizeof(u64), h->stream));
     // (read_slot keeps the last run's slot ids: every read of the next stream has its entry written by k_stream or k_slow
     //  before anything reads it -- k_count, the exports and the exactness pass look at reads [0, n_reads) of a stream that was
-    //  looked up without an error -- and entries of a fresh allocation are PENDING.  384 MB of stores per run at config 3.)
+    //  looked up without an error -- and entries of a fresh allocation are PENDING.  384 MB of stores per run at config 3.
+    //  A handle that checks itself (ECB_F_VERIFY) pays for the fill: a read the stream kernel skipped then shows as PENDING, which the
+    //  exactness pass counts as a read in a wrong EC.)
+    if ((h->cfg.flags & ECB_F_VERIFY) && h->read_slot) HIPCHK(h, hipMemsetAsync(h->read_slot, 0xFF, h->read_slot_cap * sizeof(u32), h->stream));
     if (h->rng) {
         const u64 ns = (u64)h->cfg.n_loci * h->cfg.n_haplotypes;
         k_fill_minmax<<<nblk(ns, TPB), TPB, 0, h->stream>>>(h->rng, ns);
@@ -3138,6 +3154,7 @@ int ecb_push_cells_device(ecb_handle* h, const void* d_meta, uint64_t first_read
     if (!n) return ECB_OK;
     if (!d_meta) return fail(h, ECB_ERR_ARG, "null meta");
     HIPCHK(h, hipSetDevice(h->device));
+    if (first_read >= (1ull << 32) - 1 || (u64)n >= (1ull << 32) - 1 - first_read) return fail(h, ECB_ERR_LIMIT, "more than 2^32-2 reads");
     const u64 need = first_read + n;
     if (need > h->meta_cap) {
         const u64 nc = std::max<u64>(need, h->meta_cap * 2);
@@ -3150,7 +3167,8 @@ int ecb_push_cells_device(ecb_handle* h, const void* d_meta, uint64_t first_read
         }
         h->meta = p; h->meta_cap = nc;
     }
-    HIPCHK(h, hipMemcpyAsync(h->meta + first_read, d_meta, n * sizeof(u32), hipMemcpyDeviceToDevice, h->stream));   // (ordered on the handle's stream: no wait)
+    // (the copy is ordered on the handle's own stream, behind nothing of the caller's: d_meta must be COMPLETE when this is called -- see ecb.h)
+    HIPCHK(h, hipMemcpyAsync(h->meta + first_read, d_meta, n * sizeof(u32), hipMemcpyDeviceToDevice, h->stream));
     h->meta_hi = std::max<u64>(h->meta_hi, need);
     return ECB_OK;
 }
@@ -3271,7 +3289,6 @@ int ecb_assemble_ranges_device(ecb_handle* h, uint32_t n_pieces, const void* con
                                uint64_t valid_alignments, ecb_sizes* out) {
     if (!h || !out) return ECB_ERR_ARG;
     if (h->finalized || h->adopted || h->n_reads || !h->c_rid.empty() || h->n_ecs()) return fail(h, ECB_ERR_STATE, "assembling needs an empty handle");
-    if (h->cfg.flags & ECB_F_MULTISAMPLE) return fail(h, ECB_ERR_STATE, "multisample results are assembled from adopted tables (ecb_table_adopt_device)");
     if (n_pieces && (!d_indptr || !d_indices || !d_data || !d_counts || !d_firsts || !n_ecs || !nnz)) return fail(h, ECB_ERR_ARG, "null piece lists");
     if (n_pieces > 65535u) return fail(h, ECB_ERR_LIMIT, "at most 65535 pieces");
     u64 E = 0, NNZ = 0;
@@ -3332,6 +3349,7 @@ int ecb_assemble_ranges_device(ecb_handle* h, uint32_t n_pieces, const void* con
     if (tot[2] != NNZ) return fail(h, ECB_ERR_HIP, "internal: %llu non-zeros placed, %llu received", (unsigned long long)tot[2], (unsigned long long)NNZ);
     h->sizes = ecb_sizes{};
     h->sizes.n_ecs = E; h->sizes.nnz_a = NNZ; h->sizes.n_samples = 1; h->sizes.nnz_n = E;
+    if (h->cfg.flags & ECB_F_MULTISAMPLE) { h->sizes.n_samples = 0; h->sizes.nnz_n = 0; h->n_triples = 0; h->ms_adopted = false; }   // (N comes with the shards' triples: ecb_ms_adopt_triples_device)
     h->sizes.all_alignments = all_alignments; h->sizes.valid_alignments = valid_alignments; h->sizes.n_reads = total_reads;
     h->finalized = true; h->assembled = true; h->counted = true;
     *out = h->sizes;
@@ -3404,7 +3422,7 @@ int ecb_export_pairs(ecb_handle* h, uint32_t* ec, uint32_t* meta, uint32_t* coun
     const u64 nt = h->n_triples;
     u32* x = nullptr;
     POOL(h, P_MS_X, x, 3 * nt);
-    if (h->adopted && !h->ms_adopted) return fail(h, ECB_ERR_STATE, "multisample across GPUs: no triples adopted yet (ecb_ms_adopt_triples_device)");
+    if ((h->adopted || h->assembled) && !h->ms_adopted) return fail(h, ECB_ERR_STATE, "multisample across GPUs: no triples adopted yet (ecb_ms_adopt_triples_device)");
     k_ms_split<<<nblk(nt, TPB), TPB, 0, h->stream>>>(h->ms_okey, h->ms_ostart, h->ms_ocount, nt, x, x + nt, x + 2 * nt);
     HIPCHK(h, hipMemcpyAsync(ec, x, nt * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(meta, x + nt, nt * 4, hipMemcpyDeviceToHost, h->stream));
@@ -3608,10 +3626,10 @@ int ecb_table_adopt_device(ecb_handle* h, const void* d_entries, uint64_t n_entr
 int ecb_export_ec_keys_device(ecb_handle* h, void* d_keys) {
     if (!h || !d_keys) return ECB_ERR_ARG;
     if (!h->finalized) return fail(h, ECB_ERR_STATE, "export before finalize");
-    if (h->assembled) return fail(h, ECB_ERR_STATE, "an assembled result holds no table to take hashes from");
     HIPCHK(h, hipSetDevice(h->device));
     const u64 E = h->sizes.n_ecs;
-    k_export_keys<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->table, h->order, E, (u64*)d_keys);
+    if (h->assembled) k_row_keys<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->indptr, h->indices, h->data, E, (u64*)d_keys);     // (no table behind an assembled result)
+    else k_export_keys<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->table, h->order, E, (u64*)d_keys);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return ECB_OK;
 }
@@ -3655,7 +3673,7 @@ int ecb_ms_adopt_triples_device(ecb_handle* h, uint32_t n_tables, const void* co
                                 const void* const* d_first, const uint64_t* n, uint64_t* n_triples) {
     if (!h) return ECB_ERR_ARG;
     if (!(h->cfg.flags & ECB_F_MULTISAMPLE)) return fail(h, ECB_ERR_STATE, "handle was created without ECB_F_MULTISAMPLE");
-    if (!h->finalized || !h->adopted) return fail(h, ECB_ERR_STATE, "triples are adopted by the finalized handle that adopted the merged ECs");
+    if (!h->finalized || !(h->adopted || h->assembled)) return fail(h, ECB_ERR_STATE, "triples are adopted by the finalized handle that adopted the merged ECs (or assembled their ranges)");
     if (n_tables && (!d_key || !d_count || !d_first || !n)) return fail(h, ECB_ERR_ARG, "null lists");
     HIPCHK(h, hipSetDevice(h->device));
     u64 tot = 0;
@@ -3704,7 +3722,7 @@ int ecb_ms_adopt_triples_device(ecb_handle* h, uint32_t n_tables, const void* co
 int ecb_ms_filter(ecb_handle* h, uint32_t n_cells, int64_t minimum_count, ecb_ms_sizes* out) {
     if (!h || !out) return ECB_ERR_ARG;
     if (!h->finalized || !(h->cfg.flags & ECB_F_MULTISAMPLE)) return fail(h, ECB_ERR_STATE, "no multisample result");
-    if (h->adopted && !h->ms_adopted) return fail(h, ECB_ERR_STATE, "multisample across GPUs: no triples adopted yet (ecb_ms_adopt_triples_device)");
+    if ((h->adopted || h->assembled) && !h->ms_adopted) return fail(h, ECB_ERR_STATE, "multisample across GPUs: no triples adopted yet (ecb_ms_adopt_triples_device)");
     if (!n_cells || n_cells > (1u << ECB_CELL_BITS)) return fail(h, ECB_ERR_ARG, "n_cells out of range");
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = h->stream;
@@ -4157,4 +4175,127 @@ extern "C" int ecb_hapcsc_to_csr(int device, uint32_t n_ecs, uint32_t n_loci, ui
         (*nnz && (hipMemcpy(indices, ix.p, *nnz * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(data, da.p, *nnz * 4, hipMemcpyDeviceToHost) != hipSuccess)))
         return fail(nullptr, ECB_ERR_HIP, "copy from the device");
     return ECB_OK;
+}
+
+// ---- ecb_merge: the multi-GPU merge for ONE process that drives several GPUs ----------------------------------------------
+// shards[r] holds the reads of contiguous read shard r on its own device; `root` is an empty handle (any device).  The same protocol as
+// alntools_amd/dist.py runs over RCCL with one process per GPU, here with peer copies (hipMemcpyPeerAsync: xGMI between the GPUs of a
+// node) -- cut every shard's table into n key ranges, range q of every shard to device q, merged there in shard order on a handle of its own,
+// finalized there (ranked against the whole run's read numbering, rows emitted), the finished pieces placed by first read on the root.
+// (bam_utils.py:646-724: contiguous chunks per worker, the workers' dicts merged in order.)  Everything is built from the entry points above;
+// the devices work one after the other here -- a host that wants them side by side runs one thread or one process per GPU over the same calls.
+namespace {
+struct PeerBuf {                       // device memory on a given device, freed with its scope
+    void* p = nullptr; int dev = 0;
+    PeerBuf() {}
+    PeerBuf(const PeerBuf&) = delete; PeerBuf& operator=(const PeerBuf&) = delete;
+    PeerBuf(PeerBuf&& o) noexcept : p(o.p), dev(o.dev) { o.p = nullptr; }
+    ~PeerBuf() { if (p) { hipSetDevice(dev); hipFree(p); } }
+    int take(int device, u64 bytes) {
+        dev = device;
+        if (hipSetDevice(device) != hipSuccess) return ECB_ERR_NO_DEVICE;
+        return hipMalloc(&p, std::max<u64>(bytes, 16)) == hipSuccess ? ECB_OK : ECB_ERR_HIP;
+    }
+};
+struct HandleGuard { std::vector<ecb_handle*> h; ~HandleGuard() { for (ecb_handle* x : h) ecb_destroy(x); } };
+}  // namespace
+
+extern "C" int ecb_merge(ecb_handle* const* shards, uint32_t n, ecb_handle* root, ecb_sizes* out) {
+    if (!shards || !n || !root || !out) return fail(root, ECB_ERR_ARG, "ecb_merge: null argument");
+    if (n > MAX_PARTS) return fail(root, ECB_ERR_LIMIT, "ecb_merge: at most %u shards", MAX_PARTS);
+    for (u32 r = 0; r < n; ++r) {
+        if (!shards[r] || shards[r] == root) return fail(root, ECB_ERR_ARG, "ecb_merge: shard %u is null or the root itself", r);
+        if (shards[r]->cfg.n_loci != root->cfg.n_loci || shards[r]->cfg.n_haplotypes != root->cfg.n_haplotypes)
+            return fail(root, ECB_ERR_ARG, "ecb_merge: shard %u was created for other targets than the root", r);
+        if ((shards[r]->cfg.flags | root->cfg.flags) & ECB_F_MULTISAMPLE) return fail(root, ECB_ERR_STATE, "ecb_merge: single-sample handles (the multisample merge has a second exchange: alntools_amd/dist.py)");
+    }
+    // 1. every shard: sizes, counters, its table cut into n key ranges (first reads counted from the shard's own 0)
+    std::vector<u64> ne(n), np(n), nr(n), all(n), valid(n), base(n + 1, 0);
+    std::vector<PeerBuf> ent(n), prs(n);
+    std::vector<std::vector<uint64_t>> eoff(n, std::vector<uint64_t>(n + 1, 0)), poff(n, std::vector<uint64_t>(n + 1, 0));
+    for (u32 r = 0; r < n; ++r) {
+        uint64_t a = 0, b = 0, c = 0;
+        int rc = ecb_table_sizes(shards[r], &a, &b, &c);
+        if (rc != ECB_OK) return fail(root, rc, "ecb_merge: shard %u: %s", r, ecb_last_error(shards[r]));
+        ne[r] = a; np[r] = b; nr[r] = c;
+        uint64_t ca = 0, cv = 0, cr = 0;
+        rc = ecb_counters(shards[r], &ca, &cv, &cr);
+        if (rc != ECB_OK) return fail(root, rc, "ecb_merge: shard %u: %s", r, ecb_last_error(shards[r]));
+        all[r] = ca; valid[r] = cv;
+        base[r + 1] = base[r] + nr[r];
+        if (ent[r].take(shards[r]->device, std::max<u64>(ne[r], 1) * sizeof(Entry)) || prs[r].take(shards[r]->device, std::max<u64>(np[r], 1) * sizeof(uint2)))
+            return fail(root, ECB_ERR_HIP, "ecb_merge: out of device memory on device %d", shards[r]->device);
+        if (ne[r]) {
+            rc = ecb_table_export_parts_device(shards[r], ent[r].p, prs[r].p, 0, n, eoff[r].data(), poff[r].data());
+            if (rc != ECB_OK) return fail(root, rc, "ecb_merge: shard %u: %s", r, ecb_last_error(shards[r]));
+        }
+    }
+    u64 t_all = 0, t_valid = 0;
+    for (u32 r = 0; r < n; ++r) { t_all += all[r]; t_valid += valid[r]; }
+    const u64 t_reads = base[n];
+    // 2. range q: its pieces to device q (the device of shard q), merged in shard order on a handle of its own, finalized there
+    HandleGuard parts;
+    struct Piece { PeerBuf ip, ix, da, cn, fi; u64 n_ecs = 0, nnz = 0; };
+    std::vector<Piece> piece(n);
+    for (u32 q = 0; q < n; ++q) {
+        const int dq = shards[q]->device;
+        ecb_config cfg = shards[q]->cfg;
+        cfg.flags = 0; cfg.device = dq;
+        u64 arriving = 0;
+        for (u32 r = 0; r < n; ++r) arriving += eoff[r][q + 1] - eoff[r][q];
+        if (!arriving) continue;
+        cfg.ec_capacity = std::max<u64>(next_pow2(arriving * 2 + 1024), 1 << 12);
+        ecb_handle* part = nullptr;
+        int rc = ecb_create(&cfg, &part);
+        if (rc != ECB_OK) return fail(root, rc, "ecb_merge: range %u: %s", q, ecb_last_error(nullptr));
+        parts.h.push_back(part);
+        std::vector<PeerBuf> pe(n), pp(n);
+        std::vector<const void*> le, lp; std::vector<uint64_t> lne, lnp;
+        for (u32 r = 0; r < n; ++r) {
+            const u64 e_n = eoff[r][q + 1] - eoff[r][q], p_n = poff[r][q + 1] - poff[r][q];
+            if (!e_n) continue;
+            if (pe[r].take(dq, e_n * sizeof(Entry)) || pp[r].take(dq, std::max<u64>(p_n, 1) * sizeof(uint2))) return fail(root, ECB_ERR_HIP, "ecb_merge: out of device memory on device %d", dq);
+            if (hipMemcpyPeer(pe[r].p, dq, (const char*)ent[r].p + eoff[r][q] * sizeof(Entry), shards[r]->device, e_n * sizeof(Entry)) != hipSuccess ||
+                (p_n && hipMemcpyPeer(pp[r].p, dq, (const char*)prs[r].p + poff[r][q] * sizeof(uint2), shards[r]->device, p_n * sizeof(uint2)) != hipSuccess))
+                return fail(root, ECB_ERR_HIP, "ecb_merge: peer copy from device %d to device %d failed", shards[r]->device, dq);
+            if (base[r]) { rc = ecb_table_rebase_device(part, pe[r].p, e_n, base[r]); if (rc != ECB_OK) return fail(root, rc, "ecb_merge: %s", ecb_last_error(part)); }
+            le.push_back(pe[r].p); lp.push_back(pp[r].p); lne.push_back(e_n); lnp.push_back(p_n);
+        }
+        rc = ecb_table_merge_batch_device(part, (uint32_t)le.size(), le.data(), lne.data(), lp.data(), lnp.data());
+        if (rc == ECB_OK) rc = ecb_add_counters(part, t_all, t_valid, t_reads);
+        ecb_sizes s{};
+        if (rc == ECB_OK) rc = ecb_finalize(part, &s);
+        if (rc != ECB_OK) return fail(root, rc, "ecb_merge: range %u: %s", q, ecb_last_error(part));
+        Piece& P = piece[q];
+        P.n_ecs = s.n_ecs; P.nnz = s.nnz_a;
+        if (P.ip.take(dq, (s.n_ecs + 1) * 4) || P.ix.take(dq, s.nnz_a * 4) || P.da.take(dq, s.nnz_a * 4) || P.cn.take(dq, s.n_ecs * 4) || P.fi.take(dq, s.n_ecs * 4))
+            return fail(root, ECB_ERR_HIP, "ecb_merge: out of device memory on device %d", dq);
+        rc = ecb_export_device(part, P.ip.p, P.ix.p, P.da.p, nullptr, nullptr, P.cn.p);
+        if (rc == ECB_OK) rc = ecb_export_firsts_device(part, P.fi.p);
+        if (rc != ECB_OK) return fail(root, rc, "ecb_merge: range %u: %s", q, ecb_last_error(part));
+    }
+    // 3. the finished pieces to the root's device, placed by first read
+    const int d0 = root->device;
+    std::vector<Piece> at_root(n);
+    std::vector<const void*> lip, lix, lda, lcn, lfi; std::vector<uint64_t> lne2, lnz;
+    for (u32 q = 0; q < n; ++q) {
+        Piece& S = piece[q];
+        if (!S.n_ecs) continue;
+        Piece* use = &S;
+        if (S.ip.dev != d0) {
+            Piece& D = at_root[q];
+            if (D.ip.take(d0, (S.n_ecs + 1) * 4) || D.ix.take(d0, S.nnz * 4) || D.da.take(d0, S.nnz * 4) || D.cn.take(d0, S.n_ecs * 4) || D.fi.take(d0, S.n_ecs * 4))
+                return fail(root, ECB_ERR_HIP, "ecb_merge: out of device memory on device %d", d0);
+            if (hipMemcpyPeer(D.ip.p, d0, S.ip.p, S.ip.dev, (S.n_ecs + 1) * 4) != hipSuccess || hipMemcpyPeer(D.ix.p, d0, S.ix.p, S.ip.dev, S.nnz * 4) != hipSuccess ||
+                hipMemcpyPeer(D.da.p, d0, S.da.p, S.ip.dev, S.nnz * 4) != hipSuccess || hipMemcpyPeer(D.cn.p, d0, S.cn.p, S.ip.dev, S.n_ecs * 4) != hipSuccess ||
+                hipMemcpyPeer(D.fi.p, d0, S.fi.p, S.ip.dev, S.n_ecs * 4) != hipSuccess)
+                return fail(root, ECB_ERR_HIP, "ecb_merge: peer copy from device %d to device %d failed", S.ip.dev, d0);
+            D.n_ecs = S.n_ecs; D.nnz = S.nnz;
+            use = &D;
+        }
+        lip.push_back(use->ip.p); lix.push_back(use->ix.p); lda.push_back(use->da.p); lcn.push_back(use->cn.p); lfi.push_back(use->fi.p);
+        lne2.push_back(use->n_ecs); lnz.push_back(use->nnz);
+    }
+    return ecb_assemble_ranges_device(root, (uint32_t)lip.size(), lip.data(), lix.data(), lda.data(), lcn.data(), lfi.data(), lne2.data(), lnz.data(),
+                                      t_reads, t_all, t_valid, out);
 }

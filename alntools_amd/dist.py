@@ -11,11 +11,12 @@ export), then
    ``1/world`` of a table each;
 2. rank q merges the ``world`` pieces of range q in rank order (``ecb_table_merge_device``): the hashing and key
    comparison of the merge is spread over the GPUs instead of queueing on the root;
-3. the merged ranges hold disjoint ECs.  Single-sample runs (``finalize_ranges=True``): rank q finalizes its own range --
-   ranks its ECs by first read and emits their CSR rows and counts, 1/world of the work -- and sends the rows to the root,
-   which only places the pieces in the global order of first reads (``ecb_assemble_ranges_device``).  Multisample runs
-   (the shards need the root's table for the second exchange): the merged tables are sent to the root, which loads them
-   without hashing (``ecb_table_adopt_device``) and finalizes.
+3. the merged ranges hold disjoint ECs.  ``finalize_ranges=True`` (single-sample and, since round 4, multisample runs): rank q
+   finalizes its own range -- ranks its ECs by first read and emits their CSR rows and counts, 1/world of the work -- and sends
+   the rows to the root, which only places the pieces in the global order of first reads (``ecb_assemble_ranges_device``);
+   a multisample root takes the ECs' hashes for the second exchange off the finished rows (an EC's hash is a function of its
+   key).  ``finalize_ranges=False`` (kept): the merged tables are sent to the root, which loads them without hashing
+   (``ecb_table_adopt_device``) and finalizes alone.
 
 The functions only need an *engine* with ``table_sizes/counters/table_export/table_export_parts/table_merge(_many)/
 table_adopt(_many)/table_rebase/add_counters/finalize_range/assemble_ranges`` -- :class:`GpuEngine` wraps an :class:`alntools_amd.ecb.EcBuilder`; the CPU ``gloo`` tests

@@ -34,7 +34,7 @@ SYMBOLS = ("ecb_abi_version", "ecb_device_count", "ecb_create", "ecb_destroy", "
            "ecb_export_firsts_device", "ecb_assemble_ranges_device", "ecb_table_rebase_device",
            "ecb_export_ec_keys_device", "ecb_ms_local_triples_device", "ecb_ms_adopt_triples_device", "ecb_counters", "ecb_add_counters", "ecb_profile",
            "ecb_profile_read", "ecb_profile_kernel", "ecb_csr_to_hapcsc_device", "ecb_hapcsc_to_csr_device", "ecb_release_scratch",
-           "ecb_csr_to_hapcsc", "ecb_hapcsc_to_csr")
+           "ecb_csr_to_hapcsc", "ecb_hapcsc_to_csr", "ecb_merge")
 ABI_VERSION = 4            # include/ecb.h: ECB_ABI_VERSION
 
 
@@ -130,9 +130,12 @@ def load():
     lib.ecb_add_counters.argtypes = [vp, u64, u64, u64]
     lib.ecb_profile.argtypes = [vp, C.c_int]
     lib.ecb_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]
+    if not ab or hasattr(lib, "ecb_merge"):
+        lib.ecb_merge.argtypes = [C.POINTER(vp), C.c_uint32, vp, C.POINTER(Sizes)]
     if not ab or hasattr(lib, "ecb_profile_kernel"):
         lib.ecb_profile_kernel.argtypes = [vp]
         lib.ecb_profile_kernel.restype = C.c_char_p
+    if not ab or hasattr(lib, "ecb_csr_to_hapcsc"):
         lib.ecb_csr_to_hapcsc.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, u64, C.POINTER(u64)]
         lib.ecb_hapcsc_to_csr.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, u64, vp, vp, vp, C.POINTER(u64)]
     lib.ecb_csr_to_hapcsc_device.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, C.POINTER(u64)]
@@ -152,8 +155,8 @@ def _dev_ptr(t):
 def csr_to_hapcsc(indptr, indices, data, n_loci, n_haps, nnz=None):
     """f-2 on device tensors (int32, CUDA): CSR(bitmask) -> (csc_indptr [H, T+1], csc_indices [total], nnz per haplotype).
     Haplotype h's row indices are ``csc_indices[starts[h]:starts[h+1]]`` (``bin_utils.ec2emase``'s per-haplotype CSC).
-    One call: the row-index buffer is sized for every non-zero carrying every haplotype (``nnz`` x H, when that is below 2^30
-    elements) instead of asking the library for the count of set bits first."""
+    One call when the row-index buffer sized for every non-zero carrying every haplotype (``nnz`` x H) stays below 1 GiB; beyond
+    that (many haplotypes, sparse masks: up to 31 x what is needed) the library is asked for the count of set bits first."""
     import torch
     lib = load()
     dev = indptr.device
@@ -161,7 +164,7 @@ def csr_to_hapcsc(indptr, indices, data, n_loci, n_haps, nnz=None):
     tot = C.c_uint64()
     nnz = indices.numel() if nnz is None else int(nnz)
     cap = nnz * n_haps
-    if cap >= (1 << 30):                             # (a count first: the exact size)
+    if cap >= (1 << 28):                             # (a count first: the exact size)
         rc = lib.ecb_csr_to_hapcsc_device(dev.index or 0, E, n_loci, n_haps, _dev_ptr(indptr), _dev_ptr(indices), _dev_ptr(data),
                                           None, None, C.byref(tot))
         if rc != 0:
@@ -482,6 +485,16 @@ class EcBuilder(object):
         ms, n, r = C.c_double(), C.c_uint64(), C.c_uint64()
         self._chk(self._lib.ecb_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(r)))
         return ms.value, n.value, r.value
+
+    def merge_from(self, shards):
+        """``ecb_merge``: this (empty) handle becomes the finalized result of the contiguous read shards held by the builders in
+        ``shards`` (each on its own GPU, pushed but not finalized): the multi-GPU merge inside libecb, one process, peer copies."""
+        k = len(shards)
+        hs = (C.c_void_p * k)(*[b._h for b in shards])
+        s = Sizes()
+        self._chk(self._lib.ecb_merge(hs, k, self._h, C.byref(s)))
+        self.sizes = {k_: int(getattr(s, k_)) for k_, _ in Sizes._fields_}
+        return self.sizes
 
     def profile_kernel(self):
         """Name of the stream kernel the last batch launched (as rocprofv3 prints it)."""

@@ -37,6 +37,7 @@ WORKLOADS = {
     "c2x": (150_000_000, 40_000, 8, False, "3x config 2 (debug: > 2^31 records)"),
     "c4": (200_000_000, 80_000, 8, True, "BASELINE config 4: multisample, 200M paired-end reads, 5k cell barcodes (log-normal sizes) over 64 files, minimum count 1000"),
     "c4h": (100_000_000, 80_000, 8, True, "half of config 4 (debug)"),
+    "c4t": (2_000_000, 8_000, 8, True, "config 4's shape at 2 M reads (debug: rehearsals of the sharded multisample step)"),
     "c3s": (100_000_000, 80_000, 8, True, "config 3 with every read's loci 64 target ids apart (their low bits equal: the worst case for the stream kernel's LDS table)"),
     "c3q": (100_000_000, 80_000, 8, True, "config 3 with every read's loci 4 target ids apart: the third locus of a read collides with its first in the LDS table (reads of three loci and more: two in five)"),
     "c3r": (100_000_000, 80_000, 8, True, "config 3 with paralogs: 30 % of the reads hit 1 - 3 further loci drawn uniformly over all targets besides their cluster of consecutive ids (multi-mappers at unrelated target ids: first-probe collisions in the LDS table at the birthday rate)"),
@@ -185,6 +186,61 @@ def e2e_from_bam(spec_args, reads, tmpdir):
                      "all @SQ names included (host_header_seconds: a fixed cost per file, most of a slice this small)" % decoder)
 
 
+def secondary(name, device, local, steps, with_oracle):
+    """A further workload behind the headline's timed steps, on the same box in the same run: ``steps`` whole steps (reset -> push ->
+    finalize) after one warm-up, the stream kernel's own HIP-event time, and the result held to the C oracle's on the whole workload
+    (workloads above a billion records: the device's own exactness pass instead -- every read's target set against its EC's key)."""
+    import torch
+    from alntools_amd import ecb
+    R, T, H, paired, desc = WORKLOADS[name]
+    spec = workload_spec(name)
+    rid, loc, hf, st = generate_shard(spec, 0, R, device)
+    cap = 1 << (25 if name == "c3r" else 24 if name.startswith("c3") else 22)
+    out = {"workload": desc, "records": st["records"], "reads_with_alignments": st["reads"]}
+    with ecb.EcBuilder(T, H, device=local, ec_capacity=cap, arena_capacity=1 << 26) as b:
+        b.hint_reads(st["reads"])
+        sizes = {}
+
+        def step():
+            b.reset()
+            b.push_device(rid, loc, hf)
+            sizes.update(b.finalize())
+
+        step()
+        b.profile(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        k_ms, k_launches, _ = b.profile_read()
+        kernel = b.profile_kernel()
+        b.profile(False)
+        alg = 12.0 * st["records"] + 4.0 * st["reads"]
+        k_per = k_ms / max(steps, 1)
+        out.update(ms_per_step=dt * 1e3 / steps, k_stream_ms=k_per, launches_per_step=k_launches / float(max(steps, 1)), kernel=kernel,
+                   achieved=alg / (k_per * 1e-3) / 1e9, frac=alg / (k_per * 1e-3) / 1e9 / HBM_PEAK_GBS, algorithmic_bytes_per_launch=alg,
+                   value=st["records"] / (dt / steps), ecs=sizes.get("n_ecs"), nnz_a=sizes.get("nnz_a"))
+        if with_oracle and st["records"] <= 1_000_000_000:
+            base, oracle_result = cpu_baseline(rid, loc, hf, H, 0)
+            ok, diff = parity_vs_oracle(b, rid, loc, hf, oracle_result)
+            out["parity_vs_oracle"] = ok
+            out["cpu_baseline"] = {"value": base["value"], "cores": base["cores"], "kind": base["kind"]}
+            if not ok:
+                out["differs"] = diff
+            del oracle_result
+        else:
+            b.reset()
+            b.push_device(rid, loc, hf)
+            bad, skipped = b.verify_device(rid, loc, hf)
+            out["parity_vs_oracle"] = None
+            out["exactness_pass"] = {"reads_differing_from_their_ec_key": bad, "reads_on_the_long_read_path": skipped}
+    del rid, loc, hf
+    torch.cuda.empty_cache()
+    return out
+
+
 def copy_peak(device, nbytes=4 << 30, reps=5):
     """Device-to-device copy rate (read + written bytes per second) measured in this run with the access shape of the stream
     kernel -- 16 bytes per lane, non-temporal (tools/micro/copy_peak.hip) -- and the rate of reading alone: what a kernel can
@@ -284,6 +340,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the C baseline (0 = every hardware thread of the host)")
     ap.add_argument("--py-sample-reads", type=int, default=1_000_000, help="reads of the Python restatement's slice")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip every host-side measurement (C / Python baselines, H2D, BAM)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (c2, c3r, dip) behind a default config-3 run")
+    ap.add_argument("--secondary-steps", type=int, default=5)
     ap.add_argument("--e2e-slice-reads", type=int, default=100_000, help="reads of the config-2 slice converted from a real BAM file")
     args = ap.parse_args()
 
@@ -333,8 +391,9 @@ def main():
 
     # EC-table slots: sized for the workload's EC count (c3: 3.7 M ECs) so that the timed steps do not grow it
     # (a shard of 1/4 or 1/8 of config 3 still founds 2.3 - 3 M of its 3.7 M ECs: 2^23 slots keep it under half full)
-    ec_cap = 1 << int(os.environ.get("ECB_EC_CAP_LOG2", ("23" if world >= 4 else "24") if args.workload in ("c3", "c3h", "c3s", "c3q", "c3r", "c4", "c4h") else "22"))
-    b = ecb.EcBuilder(T, H, device=local, ec_capacity=ec_cap, arena_capacity=1 << 26)
+    multisample = args.workload.startswith("c4")
+    ec_cap = 1 << int(os.environ.get("ECB_EC_CAP_LOG2", "25" if args.workload == "c3r" else ("23" if world >= 4 else "24") if args.workload in ("c3", "c3h", "c3s", "c3q", "c4", "c4h") else "22"))
+    b = ecb.EcBuilder(T, H, device=local, ec_capacity=ec_cap, arena_capacity=1 << 26, multisample=multisample)
     hint = 0 if os.environ.get("ECB_NO_HINT") else st["reads"]      # (a caller that knows how many reads its stream holds says so: one host wait per push)
     b.hint_reads(hint)
     eng = ecdist.GpuEngine(b, device)
@@ -348,8 +407,8 @@ def main():
         part_cap = ec_cap
         part_eng = ecdist.GpuEngine(ecb.EcBuilder(T, H, device=local, ec_capacity=part_cap, arena_capacity=1 << 26), device)
         if rank == 0:
-            root_eng = ecdist.GpuEngine(ecb.EcBuilder(T, H, device=local, ec_capacity=(1 << 22) if args.workload in ("c3", "c3h") else 1 << 20,
-                                                           arena_capacity=1 << 26), device)
+            root_eng = ecdist.GpuEngine(ecb.EcBuilder(T, H, device=local, ec_capacity=(1 << 22) if args.workload in ("c3", "c3h", "c4", "c4h") else 1 << 20,
+                                                           arena_capacity=1 << 26, multisample=multisample), device)
         if rehearsal:
             part_eng = ecdist.HostStagedEngine(part_eng)
             root_eng = ecdist.HostStagedEngine(root_eng) if root_eng is not None else None
@@ -365,30 +424,48 @@ def main():
     sizes = {}
     ms_sizes = {}
     parity_failed = False
-    multisample = args.workload in ("c4", "c4h")
-    n_cells, min_count, meta = 5000, 1000, None
+    n_cells, min_count, meta = 5000, (100 if args.workload == "c4t" else 1000), None
     if multisample:
+        # cell of every read: 5 000 barcodes with log-normal sizes (sigma = 1), drawn by a hash of the read's index in the RUN; file = the
+        # read's 64th of the run (a directory of 64 BAM files read in order, dealt out to the ranks in contiguous runs as
+        # bam_utils_multisample.convert does); cell ids compacted over the cells the run uses (the host names cells as they turn up)
+        first_read, run_reads = 0, st["reads"]
         if use_dist:
-            raise SystemExit("bench.py --workload c4 measures one GPU (the multi-GPU multisample path is behind bam_utils_multisample.convert)")
-        # cell of every read: 5 000 barcodes with log-normal sizes (sigma = 1), drawn by a hash of the read index; file = the read's
-        # 64th of the run (a directory of 64 BAM files read in order); ids in order of first appearance, as the host hands them out
-        g = torch.arange(st["reads"], dtype=torch.int64, device=device)
+            mine_n = torch.tensor([st["reads"]], dtype=torch.int64, device=red_dev)
+            all_n = torch.empty(world, dtype=torch.int64, device=red_dev)
+            dist.all_gather_into_tensor(all_n, mine_n)
+            all_n = [int(x) for x in all_n.cpu().tolist()]
+            first_read, run_reads = sum(all_n[:rank]), sum(all_n)
+        g = torch.arange(first_read, first_read + st["reads"], dtype=torch.int64, device=device)
         u = (((g * 0x9E3779B97F4A7C15) >> 11) & ((1 << 40) - 1)).to(torch.float64) / float(1 << 40)
         w = torch.exp(torch.randn(n_cells, generator=torch.Generator().manual_seed(20260101), dtype=torch.float64)).to(device)
         cdf = torch.cumsum(w / w.sum(), 0)
         cell = torch.searchsorted(cdf, u).clamp_(max=n_cells - 1)
-        _, inv = torch.unique(cell, return_inverse=True)
-        meta = (inv | (((g * 64) // st["reads"]) << 22)).to(torch.int32)
-        del g, u, cell, inv
-        b.close()
-        b = ecb.EcBuilder(T, H, device=local, ec_capacity=ec_cap, arena_capacity=1 << 26, multisample=True)
-        b.hint_reads(hint)
+        used = torch.zeros(n_cells, dtype=torch.int64, device=device)
+        used[cell] = 1
+        if use_dist:
+            used_r = used.to(red_dev)
+            dist.all_reduce(used_r, op=dist.ReduceOp.MAX)
+            used = used_r.to(device)
+        compact = torch.cumsum(used, 0) - 1
+        meta = (compact[cell] | (((g * 64) // run_reads) << 22)).to(torch.int32)
+        del g, u, cell, used, compact
     per_range = os.environ.get("ECB_DIST_FINALIZE", "ranges") != "root"      # ("root": the merged tables go to rank 0, which finalizes alone)
 
     def step():
         b.reset()
         b.push_device(rid, loc, hf)
-        if multisample:      # + the cell of every read (4 B per read), the (EC, cell, file) triples, cell order / filter / N on the device
+        if multisample and use_dist:      # config 4 as BASELINE names it: per-barcode EC build over the GPUs
+            b.push_cells_device(meta, 0)
+            m = ecdist.exchange_and_merge(eng, make_part, make_root, root=0, finalize_ranges=per_range)
+            n_ecs = None
+            if m is not None:
+                sizes.update(m.b.finalize())
+                n_ecs = sizes["n_ecs"]
+            ecdist.exchange_multisample(eng, m, n_ecs, root=0)      # every rank's reads -> (EC, cell, file) triples against the merged ECs
+            if m is not None:
+                ms_sizes.update(m.b.ms_filter_sizes(n_cells, min_count))
+        elif multisample:      # + the cell of every read (4 B per read), the (EC, cell, file) triples, cell order / filter / N on the device
             b.push_cells_device(meta, 0)
             sizes.update(b.finalize())
             ms_sizes.update(b.ms_filter_sizes(n_cells, min_count))
@@ -433,6 +510,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     k_ms, k_launches, _ = b.profile_read()
+    kernel_name = b.profile_kernel()              # (what libecb launched: k_stream.inc is compiled more than once, the library picks per batch)
     b.profile(False)
     # config 3 names bam2emase: the .h5 holds one CSC matrix per haplotype, so its device work is the step plus the transposition
     # of the finished CSR (ecb_csr_to_hapcsc_device).  Timed on its own, outside the K steps the headline is measured on.
@@ -496,12 +574,19 @@ def main():
                 sensors = sensors_under_load(step, fence, local)
             except Exception as e:      # (never the reason a bench line is missing)
                 sensors = {"error": repr(e)}
-        traffic, traffic_src = None, None
+        # HBM traffic: PMC counters need rocprofv3 around the process, so the figure comes from the committed pass of tools/tools_final.sh
+        # (profiles/traffic_<workload>_n<N>.json) -- taken only when that pass profiled the kernel that ran here, and said with the build
+        # it was measured on
+        traffic, traffic_src, traffic_build = None, None, None
         tfile = os.path.join(ROOT, "profiles", "traffic_%s_n%d.json" % (args.workload, world))
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "from_profiles: " + tj.get("source", "profiles/ (rocprofv3 --pmc, separate passes)")
+                traffic_build = "%s, commit %s" % (tj.get("round", "?"), tj.get("commit", "not recorded"))
+                if tj.get("kernel") != kernel_name:
+                    traffic_src = "refused: profiles/%s was measured on %r, this run launched %r" % (os.path.basename(tfile), tj.get("kernel"), kernel_name)
+                else:
+                    traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "from_profiles: " + tj.get("source", "profiles/ (rocprofv3 --pmc, separate passes)")
             except Exception:
                 traffic = None
         out = {
@@ -521,12 +606,13 @@ def main():
                        "ecs": sizes.get("n_ecs"), "nnz_a": sizes.get("nnz_a"),
                        "multisample": None if not multisample else dict(cells=n_cells, files=64, minimum_count=min_count, triples=sizes.get("nnz_n"),
                                                                         cells_kept=ms_sizes.get("n_cells_kept"), ecs_kept=ms_sizes.get("n_ecs_kept"), nnz_n=ms_sizes.get("nnz_n")),
-                       "sharding": "contiguous reads over %d GPU(s)%s" % (world, ", per-rank EC tables cut into key ranges, exchanged point-to-point over RCCL, merged and finalized per range, rows assembled on rank 0" if world > 1 else ""),
+                       "sharding": "contiguous reads over %d GPU(s)%s%s" % (world, ", per-rank EC tables cut into key ranges, exchanged point-to-point over RCCL, merged and finalized per range, rows assembled on rank 0" if world > 1 else "",
+                                                                              "; the merged ECs broadcast, every rank's reads reduced to (EC, cell, file) triples against them, rank 0 filters" if (world > 1 and multisample) else ""),
                        "generate_s": round(t_gen, 2), "exactness_pass": exact,
                        "step_emase": None if emase_ms is None else "step + CSR -> per-haplotype CSC (%d row indices) on the device, what bam2emase's .h5 holds: %.2f ms" % (emase_bits, emase_ms)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": ("ks_short" if (hint and H <= 8 and T < (1 << 25) - 2 and st["records"] < 7 * st["reads"] and not os.environ.get("ECB_NO_SHORT")) else "ks_std") + "::k_stream<false, false>",      # (csrc/k_stream.inc: which of its two compilations this stream takes)
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_on": traffic_build,
+                         "kernel": kernel_name,      # (ecb_profile_kernel: the compilation of csrc/k_stream.inc the library launched)
                          "kernel_ms_per_launch": k_ms_per_launch,
                          "launches_per_step": launches_per_step,
                          "algorithmic_bytes_per_launch": alg_bytes,
@@ -544,6 +630,16 @@ def main():
                 out["config"]["parity_vs_oracle"] = "CSR A, counts and counters of the whole workload equal oracle/ec_oracle.c's" if ok else "DIFFERS: " + ", ".join(diff)
                 parity_failed = not ok
                 del oracle_result
+            if args.workload == "c3" and not args.no_secondary:
+                # the other BASELINE config of one GPU, the paralog stream and the short-read stream, on this box in this run
+                out["secondary"] = {}
+                for name in ("c2", "c3r", "dip"):
+                    try:
+                        out["secondary"][name] = secondary(name, device, local, args.secondary_steps, True)
+                        if out["secondary"][name].get("parity_vs_oracle") is False:
+                            parity_failed = True
+                    except Exception as e:      # (a secondary line never costs the headline)
+                        out["secondary"][name] = {"error": repr(e)}
             out["cpu_baseline_py"] = cpu_baseline_py(rid, loc, hf, H, min(args.py_sample_reads, st["reads"]))
             out["h2d_inclusive"] = h2d_inclusive(b, rid, loc, hf, 400_000_000)
             import tempfile

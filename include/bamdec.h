@@ -56,8 +56,9 @@ int bd_read_tuples(bd_handle* h, size_t max_records, int trim, const uint32_t* t
 int bd_read_ms(bd_handle* h, size_t max_records, uint16_t* flag, int32_t* tid, int32_t* pos, int32_t* next_tid, int32_t* next_pos,
                uint8_t* valid, uint8_t* newrun, size_t* n_out);
 int bd_ms_cells(const bd_handle* h, const uint8_t** bytes, const uint32_t** off, size_t* n);
-/* How far the file has been read: compressed bytes taken in so far (read-ahead included) and the file's size -- a monotone
- * measure of progress, for a reader that deals a file's records out to several consumers in order (ABI 3). */
+/* How far the records handed out so far reach into the file (compressed bytes; what has been read ahead and inflated but not
+ * parsed yet is not counted) and the file's size -- a monotone measure of progress, for a reader that deals a file's records out
+ * to several consumers in order (ABI 4; ABI 3 counted the read-ahead). */
 int bd_progress(bd_handle* h, uint64_t* consumed, uint64_t* total);
 
 #ifdef __cplusplus

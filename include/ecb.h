@@ -120,8 +120,10 @@ int ecb_hint_reads(ecb_handle* h, uint64_t max_reads);
  *        | input file index << 22 (bits 22-31; the reference scans one file per worker, :473-480).
  * The host leaves out the last read of every file (the reference never counts it, :306-321). */
 int ecb_push_cells(ecb_handle* h, const uint32_t* meta, uint64_t first_read, size_t n);
-/* The same from device memory (the cell stream of a resident workload: +4 bytes per read); the caller keeps d_meta
- * alive and unchanged until the next call that waits for the handle (ecb_finalize). */
+/* The same from device memory (the cell stream of a resident workload: +4 bytes per read).  The copy is queued on the
+ * handle's own stream and waits for nothing of the caller's: whatever produced d_meta must have COMPLETED before the call (as for
+ * the streams of ecb_push_device), and the caller keeps d_meta alive and unchanged until the next call that waits for the handle
+ * (ecb_finalize).  first_read + n beyond 2^32 - 2 reads: ECB_ERR_LIMIT. */
 int ecb_push_cells_device(ecb_handle* h, const void* d_meta, uint64_t first_read, size_t n);
 #define ECB_CELL_BITS 22
 
@@ -226,6 +228,13 @@ int ecb_assemble_ranges_device(ecb_handle* h, uint32_t n_pieces, const void* con
                                const void* const* d_data, const void* const* d_counts, const void* const* d_firsts,
                                const uint64_t* n_ecs, const uint64_t* nnz, uint64_t total_reads, uint64_t all_alignments,
                                uint64_t valid_alignments, ecb_sizes* out);
+/* The whole multi-GPU merge in one call, for ONE process that drives several GPUs (ABI 4; SURVEY.md 8b's ecb_merge): shards[r] holds
+ * contiguous read shard r of the run on its own device (pushed, not finalized), root is an empty handle on any device.  Runs the steps
+ * above -- key ranges cut, range q of every shard copied to shard q's device (hipMemcpyPeer: xGMI between the GPUs of a node), merged
+ * there in shard order, finalized there, the pieces assembled on the root -- and leaves root finalized (ecb_export / ecb_export_device);
+ * the shards are spent (counted: they take no further pushes).  Single-sample handles only.  The devices work one after the other;
+ * one process per GPU over RCCL (alntools_amd/dist.py) runs the same steps side by side.  (bam_utils.py:646-724.) */
+int ecb_merge(ecb_handle* const* shards, uint32_t n_shards, ecb_handle* root, ecb_sizes* out);
 /* Multisample across GPUs (the shards' handles and the root's adopting handle all carry ECB_F_MULTISAMPLE).  After the ECs
  * were merged and the root finalized: ecb_export_ec_keys_device writes the 8-byte set hash of every EC in rank order
  * (n_ecs * 8 bytes; broadcast it together with the root's CSR A from ecb_export_device).  A shard finds its own ECs in

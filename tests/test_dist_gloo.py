@@ -105,9 +105,13 @@ class OracleEngine(object):
 
     # multisample across ranks
     def ec_keys(self, n_ecs):
-        rows = sorted(self.table.items(), key=lambda kv: kv[1][1])
-        assert len(rows) == n_ecs
         c = self.csr()
+        if getattr(self, "assembled", None) is not None:      # no table behind an assembled result: an EC's identity is a function of its key
+            ip, ix, da = c["indptr"], c["indices"], c["data"]
+            rows = [(self._ident(tuple((int(ix[i]), int(da[i])) for i in range(ip[e], ip[e + 1]))), None) for e in range(len(ip) - 1)]
+        else:
+            rows = sorted(self.table.items(), key=lambda kv: kv[1][1])
+        assert len(rows) == n_ecs
         packed = ecdist.pack_ec_keys(torch.tensor([lo for (lo, hi), _ in rows], dtype=torch.int64),
                                      torch.tensor(c["indptr"], dtype=torch.int32), torch.tensor(c["indices"], dtype=torch.int32),
                                      torch.tensor(c["data"], dtype=torch.int32))
@@ -304,7 +308,7 @@ def _meta_of(g):
     return ((g * 2654435761) % 37) | ((g % 3) << 22)
 
 
-def _ms_worker(rank, world, port, spec_args, out_path):
+def _ms_worker(rank, world, port, spec_args, out_path, per_range=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -317,8 +321,8 @@ def _ms_worker(rank, world, port, spec_args, out_path):
     eng.build(t)
     eng.meta = [_meta_of(base + i) for i in range(eng.n_reads)]
     fresh = lambda: OracleEngine(spec.n_haps)
-    merged = ecdist.exchange_and_merge(eng, fresh, fresh, root=0)
-    n_ecs = len(merged.table) if rank == 0 else None
+    merged = ecdist.exchange_and_merge(eng, fresh, fresh, root=0, finalize_ranges=per_range)
+    n_ecs = (len(merged.csr()["indptr"]) - 1) if rank == 0 else None
     n = ecdist.exchange_multisample(eng, merged, n_ecs, root=0)
     if rank == 0:
         assert n == len(merged.triples)
@@ -329,12 +333,14 @@ def _ms_worker(rank, world, port, spec_args, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3, 4])
-def test_multisample_triples_over_ranks(tmp_path, world):
-    """(EC, cell, file) read counts with the reads sharded over ranks == one process over the whole stream."""
+@pytest.mark.parametrize("world,per_range", [(2, False), (3, False), (4, False), (2, True), (3, True)])
+def test_multisample_triples_over_ranks(tmp_path, world, per_range):
+    """(EC, cell, file) read counts with the reads sharded over ranks == one process over the whole stream; with the merged tables
+    adopted by the root, and (``per_range``) with every rank finalizing its own key range and the root taking the ECs' identities
+    off the assembled rows."""
     spec_args = dict(n_reads=3000, n_loci=300, n_haps=4, paired=True)
     out = str(tmp_path / "triples.npy")
-    mp.spawn(_ms_worker, args=(world, _free_port(), spec_args, out), nprocs=world, join=True)
+    mp.spawn(_ms_worker, args=(world, _free_port(), spec_args, out, per_range), nprocs=world, join=True)
     got = np.load(out)
     spec = synth.SynthSpec(**spec_args)
     one = OracleEngine(spec.n_haps)

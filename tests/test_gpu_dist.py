@@ -18,7 +18,7 @@ def _meta(g):
     return (((g * np.uint64(2654435761)) % np.uint64(101)) | ((g % np.uint64(3)) << np.uint64(22))).astype(np.uint32)
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, per_range=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -35,7 +35,7 @@ def _worker(rank, world, port, out_path):
     b.push_cells(_meta(np.arange(base, base + t["n_reads"])), 0)
     eng = ecdist.HostStagedEngine(ecdist.GpuEngine(b, dev))
     fresh = lambda ms: (lambda: ecdist.HostStagedEngine(ecdist.GpuEngine(ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=1 << 12, multisample=ms), dev)))
-    merged = ecdist.exchange_and_merge(eng, fresh(False), fresh(True), root=0)
+    merged = ecdist.exchange_and_merge(eng, fresh(False), fresh(True), root=0, finalize_ranges=per_range)
     n_ecs = None
     if rank == 0:
         s = merged.e.b.finalize()
@@ -56,10 +56,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_two_processes_one_gpu_equal_one_handle(tmp_path):
+@pytest.mark.parametrize("per_range", [False, True])
+def test_two_processes_one_gpu_equal_one_handle(tmp_path, per_range):
+    """Multisample over two ranks: the merged tables adopted by the root, or (``per_range``) every rank finalizing the key range it
+    merged, the root assembling the rows and taking the ECs' hashes off them for the second exchange."""
     from alntools_amd import ecb, synth
     out = str(tmp_path / "merged.npz")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, per_range), nprocs=2, join=True)
     got = np.load(out)
     spec = synth.SynthSpec(60000, 3000, 8, paired=True)
     whole = synth.generate(spec, 0, spec.n_reads, device=torch.device("cuda:0"))
@@ -191,8 +194,6 @@ def test_ranges_finalized_apart_assemble_to_the_result_of_one_handle(world):
         assert np.array_equal(got[k], exp[k]), k
     with pytest.raises(ecb.EcbError):                   # no table behind an assembled result
         root.b.export_read_ec()
-    with pytest.raises(ecb.EcbError):
-        root.b.export_ec_keys_device(torch.empty(s["n_ecs"], dtype=torch.int64, device=dev))
     root.b.reset()                                      # and the handle is as good as new
     root.b.push_device(whole["read_id"], whole["locus"], whole["hapflag"])
     assert root.b.finalize() == exp_s
@@ -254,10 +255,21 @@ def test_assembling_refuses_overlapping_or_malformed_pieces():
         e.assemble_ranges(pieces, *totals)
     assert ei.value.code == -6
     e.b.close()
-    e = ecdist.GpuEngine(ecb.EcBuilder(spec.n_loci, spec.n_haps, multisample=True), dev)
-    with pytest.raises(ecb.EcbError) as ei:
-        e.assemble_ranges(pieces, *totals)
+    e = ecdist.GpuEngine(ecb.EcBuilder(spec.n_loci, spec.n_haps, multisample=True), dev)      # a multisample root assembles too ...
+    s_ms = e.assemble_ranges(pieces, *totals)
+    assert s_ms["nnz_n"] == 0 and s_ms["n_samples"] == 0
+    with pytest.raises(ecb.EcbError) as ei:             # ... and has no N until the shards' triples are adopted
+        e.b.ms_filter(10, 1)
     assert ei.value.code == -6
+    keys = torch.empty(s_ms["n_ecs"], dtype=torch.int64, device=dev)
+    e.b.export_ec_keys_device(keys)                     # the ECs' hashes, off the assembled rows: the ones a table holds
+    whole = synth.generate(spec, 0, spec.n_reads, device=dev)
+    with ecb.EcBuilder(spec.n_loci, spec.n_haps) as one:
+        one.push_device(whole["read_id"], whole["locus"], whole["hapflag"])
+        one.finalize()
+        exp_keys = torch.empty_like(keys)
+        one.export_ec_keys_device(exp_keys)
+    assert torch.equal(keys, exp_keys)
     e.b.close()
     # moving first reads on: not past 2^32 - 2 reads
     src = ecdist.GpuEngine(ecb.EcBuilder(spec.n_loci, spec.n_haps), dev)
@@ -273,3 +285,36 @@ def test_assembling_refuses_overlapping_or_malformed_pieces():
         e.table_merge(ent, ne, prs, npairs)
     assert ei.value.code == -5
     e.b.close(); src.b.close()
+
+
+@pytest.mark.parametrize("world", [1, 2, 5])
+def test_merge_inside_the_library_equals_one_handle(world):
+    """``ecb_merge``: the multi-GPU merge for one process that drives several GPUs, inside libecb (peer copies instead of RCCL) --
+    here with every shard on the one GPU of the box.  Contiguous read shards, one handle each -> the root == one handle over the
+    whole stream, bit for bit; the spent shards and a root that is not empty are refused."""
+    from alntools_amd import ecb, synth
+    dev = torch.device("cuda:0")
+    spec = synth.SynthSpec(90000, 3000, 8, paired=True)
+    R = spec.n_reads
+    shards = []
+    for r in range(world):
+        t = synth.generate(spec, r * R // world, (r + 1) * R // world, device=dev)
+        b = ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=1 << 12)
+        b.push_device(t["read_id"], t["locus"], t["hapflag"])
+        shards.append(b)
+    root = ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=1 << 10)
+    s = root.merge_from(shards)
+    got = root.export()
+    whole = synth.generate(spec, 0, R, device=dev)
+    with ecb.EcBuilder(spec.n_loci, spec.n_haps) as one:
+        one.push_device(whole["read_id"], whole["locus"], whole["hapflag"])
+        exp_s = one.finalize()
+        exp = one.export()
+    assert s == exp_s and root.finalize() == exp_s
+    for k in exp:
+        assert np.array_equal(got[k], exp[k]), k
+    with pytest.raises(ecb.EcbError):                   # the root holds a result now
+        root.merge_from(shards)
+    for b in shards:
+        b.close()
+    root.close()

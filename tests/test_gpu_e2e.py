@@ -125,3 +125,32 @@ def test_bam2emase_then_emase2ec_gives_the_reference_bin(golden_dir, tmp_path):
     methods.bam2emase(bam, h5)
     methods.emase2ec(h5, back)
     assert _bytes(back) == _bytes(os.path.join(golden_dir, "g1_edge.bin"))
+
+
+def test_command_line_file_conversions_import_no_pytorch(golden_dir, tmp_path):
+    """``alntools bam2ec`` / ``bam2emase`` / ``ec2emase`` / ``emase2ec`` on one GPU, each in a fresh interpreter with ``-X importtime``:
+    the reference's bytes come out and ``torch`` is never imported -- everything goes through libecb's host-pointer entry points
+    (``ecb_push``, ``ecb_csr_to_hapcsc``, ``ecb_hapcsc_to_csr``); the reference has no such dependency either (``setup.py:21-30``)."""
+    import subprocess
+    import sys
+    from alntools_amd import emase_h5
+    try:
+        emase_h5._backend()
+    except RuntimeError:
+        pytest.skip("no HDF5 library on this box")
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    g = json.load(open(os.path.join(golden_dir, "g1_edge.json")))
+    bam = str(tmp_path / g["sample"])
+    bamio.write_bam(bam, [tuple(r) for r in g["references"]], [tuple(r) for r in g["records"]])
+    b1, h5a, h5b, b2 = (str(tmp_path / n) for n in ("a.bin", "a.h5", "b.h5", "b.bin"))
+    env = dict(os.environ)
+    env.pop("ALNTOOLS_TORCH", None)
+    env.pop("ALNTOOLS_GPUS", None)
+    for args in (["bam2ec", bam, b1], ["bam2emase", bam, h5a], ["ec2emase", b1, h5b], ["emase2ec", h5b, b2]):
+        r = subprocess.run([sys.executable, "-X", "importtime", "-m", "alntools_amd.cli"] + args, cwd=root, env=env, capture_output=True, text=True)
+        assert r.returncode == 0, (args, r.stderr[-2000:])
+        imported = [l.split("|")[-1].strip() for l in r.stderr.splitlines() if l.startswith("import time:")]
+        assert "alntools_amd.ecb" in imported, args
+        assert not any(m == "torch" or m.startswith("torch.") for m in imported), (args, [m for m in imported if m.startswith("torch")][:5])
+    assert _bytes(b1) == _bytes(os.path.join(golden_dir, "g1_edge.bin"))
+    assert _bytes(b2) == _bytes(b1)

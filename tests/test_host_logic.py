@@ -126,7 +126,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     assert declared == set(bamdec.SYMBOLS), declared ^ set(bamdec.SYMBOLS)
     for s in declared:
         assert hasattr(bamdec.lib(), s), s
-    assert bamdec.lib().bd_abi_version() == bamdec.ABI_VERSION == 3
+    assert bamdec.lib().bd_abi_version() == bamdec.ABI_VERSION == 4
 
 
 def test_plain_c_program_links_against_the_abi(tmp_path):
@@ -398,6 +398,31 @@ def test_native_multisample_scan_matches_the_python_scan(golden_dir, tmp_path):
     bamio.write_bam(str(tmp_path / "nocell.bam"), refs, [("plain_name", 0, 0, 1, -1, -1)])
     with pytest.raises(ValueError):
         bum.scan_file(bamdec.NativeBamReader(str(tmp_path / "nocell.bam")), None)
+
+
+def test_decoder_progress_follows_the_records_handed_out_not_the_read_ahead(tmp_path):
+    """``bd_progress`` (what a multi-GPU deal-out cuts a file by): a file small enough to be read ahead whole must still report about
+    half-way when half of its records have been handed out, and 1.0 at the end -- ABI 3 reported 1.0 from the first batch on, which dealt
+    one read to every rank but the last."""
+    from alntools_amd import bamdec, bamio
+    bamdec.build()
+    spec = synth.SynthSpec(6000, 300, 4, paired=True)
+    recs = list(synth.raw_records(spec, 0, spec.n_reads))
+    bam = str(tmp_path / "small.bam")
+    bamio.write_bam(bam, spec.references(), recs, level=1)
+    nat = bamdec.NativeBamReader(bam, threads=2)
+    enc = TupleEncoder(HeaderMaps(nat.references, nat.lengths))
+    seen, marks = 0, []
+    while True:
+        t = nat.read_tuples(len(recs) // 8 + 1, enc)
+        if t is None:
+            break
+        seen += len(t["read_id"])
+        marks.append((seen / float(len(recs)), nat.progress()))
+    nat.close()
+    assert len(marks) >= 8 and marks[-1][1] == 1.0
+    assert all(b >= a for (_, a), (_, b) in zip(marks, marks[1:]))           # monotone
+    assert all(abs(frac - prog) < 0.15 for frac, prog in marks), marks        # tracks the records handed out (by bytes: within a few blocks)
 
 
 def test_rank_zero_deals_a_decoded_file_out_in_contiguous_read_ranges():

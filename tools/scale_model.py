@@ -81,6 +81,13 @@ for N in NS:
         sz_a = aeng.assemble_ranges(done, *tot)
         asm_ms = (sync() - t0) * 1e3
         del done
+        # the multisample ending since round 4: the same per-range finalize and assembly; what the root adds for the second exchange is the
+        # ECs' hashes, taken off the assembled rows (ecb_export_ec_keys_device on a handle without a table)
+        keys = torch.empty(sz_a["n_ecs"], dtype=torch.int64, device=dev)
+        t0 = sync()
+        asm.export_ec_keys_device(keys)
+        keys_ms = (sync() - t0) * 1e3
+        del keys
         t1 = sync()
         reng.table_adopt_many(merged)
         adopt_ms = (sync() - t1) * 1e3
@@ -100,7 +107,9 @@ for N in NS:
               N, rk, max(x[0] for x in rank_ms), max(x[1] for x in rank_ms), max(x[2] for x in rank_ms), mg, max(fin_ms), asm_ms,
               max(sent), sum(moved_fin[1:]), (max(sent) / max(N - 1, 1)) / 153.0, (max(moved_fin[1:]) if N > 1 else 0.0) / 153.0,
               rk + mg + max(fin_ms) + asm_ms, sz["n_ecs"]), flush=True)
-    print("   (multisample ending) N=%d: my range: merge %.2f + export %.2f ms | root: adopt %.2f + finalize %.2f ms | to root %.0f MB (%.2f ms) | model step %.2f ms" % (
+    print("   (multisample ending, round 4: finalize per range + assembly + the ECs' hashes off the assembled rows) N=%d: hashes %.2f ms | model step up to the second exchange %.2f ms" % (
+        N, keys_ms, rk + mg + max(fin_ms) + asm_ms + keys_ms), flush=True)
+    print("   (multisample ending until round 3, kept as finalize_ranges=False) N=%d: my range: merge %.2f + export %.2f ms | root: adopt %.2f + finalize %.2f ms | to root %.0f MB (%.2f ms) | model step %.2f ms" % (
         N, mg, max(x[1] for x in part_ms), adopt_ms, (t6 - t5) * 1e3, sum(moved[1:]), (max(moved[1:]) if N > 1 else 0.0) / 153.0,
         rk + max(sum(x) for x in part_ms) + adopt_ms + (t6 - t5) * 1e3), flush=True)
     part.close()
