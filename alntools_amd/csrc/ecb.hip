@@ -106,6 +106,7 @@ struct Counters {
     u64 next_slice;                  // k_stream: next unclaimed slice of the batch (zeroed per launch)
     u64 n_mismatch;                  // exactness pass (ecb_verify_device): reads whose set differs from their EC's key
     u32 last_rid, pad_;              // read_id of the last record of the batch k_sum_counts closed (ecb_hint_reads: the host learns it here)
+    u64 n_probe_tiles;               // tile visits on k_stream's probe-on path (records that found their first LDS slot taken), over the batches so far
 };
 
 // The key arena is cut into equal regions with a cursor each; a wave allocates from the region its index picks and moves
@@ -390,6 +391,7 @@ __device__ __forceinline__ void load_pos(const int* pos, u64 tb, u64 te, u32 lan
 
 // k_stream itself, twice (see k_stream.inc): the geometry of a pass is a compile-time matter (LDS per wave, waves per SIMD, key bits)
 #define ECB_KS_SHORT 0
+#define ECB_KS_PAR 0
 namespace ks_std {
 #include "k_stream.inc"
 }
@@ -398,6 +400,14 @@ namespace ks_std {
 namespace ks_short {
 #include "k_stream.inc"
 }
+#undef ECB_KS_SHORT
+#undef ECB_KS_PAR
+#define ECB_KS_SHORT 0
+#define ECB_KS_PAR 1
+namespace ks_par {
+#include "k_stream.inc"
+}
+#undef ECB_KS_PAR
 #undef ECB_KS_SHORT
 
 // resume points of a fresh batch: slice b starts (and has counted its records up to) record b * chunk
@@ -420,7 +430,7 @@ __global__ __launch_bounds__(1024) void k_sum_counts(const u32* wave_counts, u64
         a = v = e = 0;
         for (int k = 0; k < 16; ++k) { a += s[0][k]; v += s[1][k]; e += s[2][k]; }
         if (verify) ctr->n_mismatch += e;                  // the exactness pass counts differing reads, and recounts nothing
-        else { ctr->all += a + offered; ctr->valid += v; ctr->n_ecs += e; }
+        else { ctr->all += offered; ctr->valid += v; ctr->n_ecs += e; ctr->n_probe_tiles += a; }
         if (d_last) ctr->last_rid = *d_last;
     }
 }
@@ -2226,6 +2236,8 @@ struct ecb_handle {
     u64* d_list_n = nullptr;
     u64 resident_blocks = 0, resident_blocks_rg = 0, resident_blocks_sh = 0, rounds = 24, min_tiles = 32;     // k_stream's launch shape (queried once)
     bool short_reads = false;         // this batch goes through ks_short::k_stream (set per batch by process_batch)
+    bool par_stream = false;          // ... through ks_par::k_stream: the batch before met loci that displace each other in the LDS table (sticky per handle)
+    u64 resident_blocks_par = 0;
     u64 records_pushed = 0;           // records of the batches so far (with n_reads: how many records a read brings)
     bool ctr_synced = false;          // hctr is what the device holds (no kernel that counts has been queued since the last read-back)
     bool adopted = false;             // the table holds adopted entries in consecutive slots (no hashing): finalize / export only
@@ -2431,7 +2443,7 @@ int excl_scan(ecb_handle* h, const u32* in, u64 n, u32* out, u64* total);
 // Launch shape of k_stream over n records: the stream is cut into ECB_ROUNDS x as many slices as waves are resident at
 // once; the launch holds the resident waves only, which claim slice after slice.
 struct StreamPlan { u64 slices, chunk, blocks, pwaves; };
-int plan_stream(ecb_handle* h, u64 n, StreamPlan* P, bool ranges = false, bool short_reads = false) {
+int plan_stream(ecb_handle* h, u64 n, StreamPlan* P, bool ranges = false, bool short_reads = false, bool par = false) {
     if (!h->resident_blocks) {                         // (asked once per handle: two runtime queries per batch add up on a streamed BAM)
         int cus = 256, bpc = 4;
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
@@ -2443,10 +2455,13 @@ int plan_stream(ecb_handle* h, u64 n, StreamPlan* P, bool ranges = false, bool s
         int bps = 4;                                   // (the variant for short reads: 9.9 KB of LDS per wave, four workgroups per CU)
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&bps, ks_short::k_stream<false>, TPB, 0);
         h->resident_blocks_sh = (u64)std::max(cus, 1) * std::max(bps, 1);
+        int bpp = 5;
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpp, ks_par::k_stream<false>, TPB, 0);
+        h->resident_blocks_par = (u64)std::max(cus, 1) * std::max(bpp, 1);
         h->rounds = getenv("ECB_ROUNDS") ? std::max(1, atoi(getenv("ECB_ROUNDS"))) : 24;   // (16 .. 32 measure alike on C3; fewer slices = fewer slice tails read twice)
         h->min_tiles = getenv("ECB_MIN_TILES") ? std::max(2, atoi(getenv("ECB_MIN_TILES"))) : 32;
     }
-    const u64 rounds = h->rounds, resident_blocks = short_reads ? h->resident_blocks_sh : (ranges ? h->resident_blocks_rg : h->resident_blocks);
+    const u64 rounds = h->rounds, resident_blocks = short_reads ? h->resident_blocks_sh : (ranges ? h->resident_blocks_rg : (par ? h->resident_blocks_par : h->resident_blocks));
     // slices: `rounds` per resident wave for balance, but not shorter than MIN_TILES tiles while every resident wave still gets
     // one -- a wave runs on past its slice's end to finish its open read, so every slice costs about one tile read twice
     // (at 5 tiles per slice, an eighth of config 3 on one of 8 GPUs, that was a fifth of the kernel)
@@ -2537,8 +2552,11 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     const bool few = h->n_reads ? h->records_pushed < 7 * h->n_reads : (n >= h->reads_hint && n < 7 * h->reads_hint);
     h->short_reads = hinted && !h->rng && h->cfg.n_loci < MAX_LOCI_SHORT && h->cfg.n_haplotypes <= 8 && !getenv("ECB_NO_SHORT") &&
                      (getenv("ECB_FORCE_SHORT") || few);
+    // Loci that displace each other in the LDS table (paralogs: target ids anywhere): the compilation whose key compare settles displaced pairs
+    // in registers, once a batch has shown that more than a quarter of its tiles took the probe-on path (and back below a sixteenth).
+    const bool par = !h->short_reads && !h->rng && !getenv("ECB_NO_PAR") && (getenv("ECB_FORCE_PAR") || h->par_stream);
     StreamPlan P;
-    rc = plan_stream(h, n, &P, h->rng != nullptr, h->short_reads);
+    rc = plan_stream(h, n, &P, h->rng != nullptr, h->short_reads, par);
     if (rc != ECB_OK) return rc;
     const u64 waves = P.slices, chunk = P.chunk, blocks = P.blocks, pwaves = P.pwaves;
     u64* d_resume = nullptr;
@@ -2568,6 +2586,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     StreamArgs a{d_rid, d_loc, d_hf, n, h->table, h->cap - 1, h->ctr, h->read_slot, h->reads_hi, h->d_cold,
                  getenv("ECB_ABLATE") ? (u32)atoi(getenv("ECB_ABLATE")) : 0u};
     h->ctr_synced = false;
+    const u64 probe_before = h->hctr.n_probe_tiles;
     u64 offered = n;                                    // records offered to the filter (bam_utils.py:261): all of the batch
     for (u32 launch = 0;; ++launch) {
         if (launch) {                                   // per launch (the first one's: k_init_resume)
@@ -2579,6 +2598,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
         if (h->prof) hipEventRecord(h->ev0, h->stream);
         if (h->rng) { ks_std::k_stream<false, true><<<(unsigned)blocks, TPB, 0, h->stream>>>(a); h->last_kernel = "ks_std::k_stream<false, true>"; }     // ... with the range update fused in
         else if (h->short_reads) { ks_short::k_stream<false><<<(unsigned)blocks, TPB, 0, h->stream>>>(a); h->last_kernel = "ks_short::k_stream<false, false>"; }
+        else if (par) { ks_par::k_stream<false><<<(unsigned)blocks, TPB, 0, h->stream>>>(a); h->last_kernel = "ks_par::k_stream<false, false>"; }
         else { ks_std::k_stream<false><<<(unsigned)blocks, TPB, 0, h->stream>>>(a); h->last_kernel = "ks_std::k_stream<false, false>"; }
         if (h->prof) hipEventRecord(h->ev1, h->stream);
         k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, pwaves, h->ctr, 0u, offered, d_rid + (n - 1));
@@ -2612,6 +2632,10 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     }
 #endif
     if (rc != ECB_OK) return rc;
+    {
+        const u64 tiles = (n + WT - 1) / WT, on_path = h->hctr.n_probe_tiles - probe_before;
+        if (on_path * 4 > tiles) h->par_stream = true; else if (on_path * 16 < tiles) h->par_stream = false;
+    }
     if (h->prof) h->prof_records += n;
     if (h->cfg.flags & ECB_F_VERIFY) {                  // belt and braces: the grouping is exact by construction (Slot), this re-derives it
         u64 bad = 0, nl = 0;
@@ -2633,12 +2657,16 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
 
 int ensure_staging(ecb_handle* h, u64 need) {
     if (need <= h->st_cap) return ECB_OK;
-    if (h->st_rid) { hipFree(h->st_rid); hipFree(h->st_loc); hipFree(h->st_hf); if (h->st_pos) hipFree(h->st_pos); }
+    // one allocation for the three (four) staging streams, each on a 2 MiB boundary within it (see bench.py: generate_shard -- where separate
+    // allocations land moves the stream kernel by several per cent)
+    if (h->st_rid) hipFree(h->st_rid);
+    h->st_rid = h->st_loc = h->st_hf = nullptr; h->st_pos = nullptr;
     h->st_cap = std::max<u64>(need, h->cfg.max_batch_records);
-    HIPCHK(h, hipMalloc(&h->st_rid, h->st_cap * sizeof(u32)));
-    HIPCHK(h, hipMalloc(&h->st_loc, h->st_cap * sizeof(u32)));
-    HIPCHK(h, hipMalloc(&h->st_hf, h->st_cap * sizeof(u32)));
-    if (h->cfg.flags & ECB_F_RANGES) HIPCHK(h, hipMalloc(&h->st_pos, h->st_cap * sizeof(int)));
+    const u64 stride = (h->st_cap * sizeof(u32) + (2ull << 20) - 1) / (2ull << 20) * (2ull << 20) / sizeof(u32);
+    const bool rg = (h->cfg.flags & ECB_F_RANGES) != 0;
+    HIPCHK(h, hipMalloc(&h->st_rid, (rg ? 4 : 3) * stride * sizeof(u32)));
+    h->st_loc = h->st_rid + stride; h->st_hf = h->st_rid + 2 * stride;
+    if (rg) h->st_pos = reinterpret_cast<int*>(h->st_rid + 3 * stride);
     return ECB_OK;
 }
 
@@ -2997,7 +3025,7 @@ void ecb_destroy(ecb_handle* h) {
     if (h->pin_cold) hipHostFree(h->pin_cold);
     hipFree(h->d_cold);
     for (int i = 0; i < ecb_handle::P_N; ++i) hipFree(h->pool[i]);
-    hipFree(h->st_rid); hipFree(h->st_loc); hipFree(h->st_hf); hipFree(h->st_pos);
+    hipFree(h->st_rid);                                  // (one allocation holds all staging streams: ensure_staging)
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);

@@ -58,9 +58,13 @@ def generate_shard(spec, r0, r1, device, chunk_reads=1 << 20):
     import torch
     from alntools_amd import synth
     n = synth.count_records(spec, r0, r1, device=device)
-    rid = torch.empty(n, dtype=torch.int32, device=device)
-    loc = torch.empty(n, dtype=torch.int32, device=device)
-    hf = torch.empty(n, dtype=torch.int32, device=device)
+    # ONE allocation for the three streams (each starting on a 2 MiB boundary within it).  Three allocations of 13 GB each land wherever the
+    # driver has room, and where they land moves a pure read sweep over them by 4.5 % and k_stream by 8 - 10 % (profiles/r04_stream_placement*.txt:
+    # the pool's "slow" and "fast" boxes of round 3 were slow and fast RUNS); one allocation of all three measured at the fast end in every
+    # arrangement tried.  What a caller of ecb_push_device should do, too (include/ecb.h).
+    stride = (n * 4 + (2 << 20) - 1) // (2 << 20) * (2 << 20) // 4
+    arena = torch.empty(3 * stride, dtype=torch.int32, device=device)
+    rid, loc, hf = arena[:n], arena[stride:stride + n], arena[2 * stride:2 * stride + n]
     at, reads, valid = 0, 0, 0
     for a in range(r0, r1, chunk_reads):
         g = synth.generate(spec, a, min(a + chunk_reads, r1), device=device, read_id_base=reads)
@@ -237,6 +241,43 @@ def secondary(name, device, local, steps, with_oracle):
             out["parity_vs_oracle"] = None
             out["exactness_pass"] = {"reads_differing_from_their_ec_key": bad, "reads_on_the_long_read_path": skipped}
     del rid, loc, hf
+    torch.cuda.empty_cache()
+    return out
+
+
+def placement_spread(b, rid, loc, hf, step_from, n_arenas=3, steps=3):
+    """k_stream's time with the SAME tuples at other places in HBM: ``n_arenas`` further allocations of the streams' size, the tuples copied
+    into each, ``steps`` steps from each (untimed for the headline, which was measured where generate_shard put the tuples).  On one box the time
+    moves by up to 14 % with where the 40 GB sit, reproducibly per allocation and for no reason this repository could pin down (not the stagger
+    between the streams, not the region's plain read rate: profiles/r04_stream_regions*.txt); this says where in that spread the run's own
+    allocation lies.  -> ms per launch, the run's own allocation first."""
+    import torch
+    n = rid.numel()
+    stride = (n * 4 + (2 << 20) - 1) // (2 << 20) * (2 << 20) // 4
+    out = []
+    arenas = []
+    try:
+        for i in range(n_arenas + 1):
+            if i == 0:
+                views = (rid, loc, hf)
+            else:
+                a = torch.empty(3 * stride, dtype=torch.int32, device=rid.device)
+                arenas.append(a)              # (all kept until the end: allocations that exist at the same time are different memory)
+                views = (a[:n], a[stride:stride + n], a[2 * stride:2 * stride + n])
+                for v, src in zip(views, (rid, loc, hf)):
+                    v.copy_(src)
+            torch.cuda.synchronize()
+            step_from(*views)
+            b.profile(True)
+            for _ in range(steps):
+                step_from(*views)
+            torch.cuda.synchronize()
+            ms, launches, _ = b.profile_read()
+            b.profile(False)
+            out.append(round(ms / max(launches, 1), 3))
+    except RuntimeError:                      # (out of memory for another copy: report what there is)
+        pass
+    del arenas
     torch.cuda.empty_cache()
     return out
 
@@ -622,6 +663,19 @@ def main():
                          "frac_of_measured_copy": (achieved / peak_copy) if peak_copy else None},
         }
         out["config"]["sensors_under_load"] = sensors
+        if world == 1 and not multisample and not os.environ.get("ECB_ABLATE") and not args.no_cpu_baseline and args.workload in ("c3", "c2"):
+            def step_from(r_, l_, h_):
+                b.reset()
+                b.push_device(r_, l_, h_)
+                b.finalize()
+            try:
+                spread = placement_spread(b, rid, loc, hf, step_from)
+                out["roofline"]["kernel_ms_by_placement"] = spread
+                out["roofline"]["kernel_ms_by_placement_note"] = ("k_stream ms per launch with the same tuples in this run's own allocation (first) and in %d further allocations made "
+                                                                  "side by side: where the tuples sit in HBM moves the kernel by up to 14 %% on one box, reproducibly per allocation "
+                                                                  "(profiles/r04_stream_regions*.txt); the headline is the first one's, whatever it is" % (len(spread) - 1))
+            except Exception as e:
+                out["roofline"]["kernel_ms_by_placement"] = {"error": repr(e)}
         if not use_dist and not args.no_cpu_baseline and not multisample:
             out["cpu_baseline"], oracle_result = cpu_baseline(rid, loc, hf, H, args.cpu_sample_reads, args.cpu_threads)
             if oracle_result is not None:      # the whole workload went through the oracle: hold the GPU's result to it, bit for bit

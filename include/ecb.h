@@ -102,7 +102,10 @@ const char* ecb_last_error(const ecb_handle* h);   /* h may be NULL: error of th
 
 /* Streaming input -- replaces the per-alignment loop of process_convert_bam (bam_utils.py:258-344).
  * ecb_push: host pointers; batches may cut a read anywhere (the library carries the open read over).
- * ecb_push_device: device pointers (HBM-resident tuples); every call must hold whole reads.
+ * ecb_push_device: device pointers (HBM-resident tuples); every call must hold whole reads.  The streams must be 16-byte aligned and
+ *   complete when the call is made (the library works on a stream of its own).  Advice, measured: keep the three (four) streams in ONE
+ *   device allocation -- where separate multi-GB allocations land moves the stream kernel by 8 - 10 % on MI355X
+ *   (profiles/r04_stream_placement*.txt); the library's own staging for ecb_push is laid out that way.
  * pos may be NULL unless ECB_F_RANGES. */
 int ecb_push(ecb_handle* h, const uint32_t* read_id, const uint32_t* locus, const uint32_t* hapflag,
              const int32_t* pos, size_t n);

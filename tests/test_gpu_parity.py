@@ -287,7 +287,7 @@ def test_mid_size_device_vs_c_oracle_properties(paired):
 
 @pytest.mark.parametrize("stride,paired,paralogs", [(4, True, 0), (64, False, 0), (8, True, 0), (7, True, 0), (128, False, 30), (1, True, 30), (1, False, 60),
                                                     (1024, True, 100)])
-def test_reads_whose_loci_collide_in_the_lds_table_match_the_c_oracle(stride, paired, paralogs):
+def test_reads_whose_loci_collide_in_the_lds_table_match_the_c_oracle(stride, paired, paralogs, monkeypatch):
     """The stream kernel's LDS table gives a read a home region and places a locus in it by a fold of its bits (k_stream.inc: home_off): runs of
     consecutive target ids and loci a power of two apart do not meet there; loci seven apart do, and so do loci anywhere among the targets
     (`paralogs`: that percentage of the reads hit 1 - 3 further loci drawn uniformly, bench.py's c3r) at the birthday rate -- those records go
@@ -300,15 +300,36 @@ def test_reads_whose_loci_collide_in_the_lds_table_match_the_c_oracle(stride, pa
     t = synth.generate(spec, 0, spec.n_reads)
     exp = c_oracle.ec_from_tuples(t["read_id"], t["locus"], t["hapflag"], spec.n_haps, threads=4)
     d = [torch.from_numpy(t[k].view(np.int32)).to(dev) for k in ("read_id", "locus", "hapflag")]
-    for hint in (0, exp["n_reads"]):
-        with ecb.EcBuilder(spec.n_loci, spec.n_haps) as b:
-            b.hint_reads(hint)
-            b.push_device(*d)
-            s = b.finalize()
-            _check(b.export(), s, exp)
-            b.reset()
-            b.push_device(*d)
-            assert b.verify_device(*d) == (0, 0)
+    # (the stream kernel is compiled three times -- k_stream.inc: ks_std, ks_short, ks_par -- and the library picks per batch: every
+    #  compilation a stream of this shape can take is forced in turn, and the library's own choice runs last, over a stream pushed in two
+    #  batches so that the second one is picked by what the first one met)
+    for force in ("ECB_NO_PAR", "ECB_FORCE_PAR", None):
+        for k in ("ECB_NO_PAR", "ECB_FORCE_PAR"):
+            monkeypatch.delenv(k, raising=False)
+        if force:
+            monkeypatch.setenv(force, "1")
+        for hint in (0, exp["n_reads"]):
+            with ecb.EcBuilder(spec.n_loci, spec.n_haps) as b:
+                b.hint_reads(hint)
+                if force is None:
+                    rid, n = t["read_id"], len(t["read_id"])
+                    cut = (n // 2) & ~3                     # (device streams must be 16-byte aligned: a multiple of four records)
+                    while cut < n and rid[cut] == rid[cut - 1]:      # a record at which the run counter steps starts a read
+                        cut += 4
+                    assert 0 < cut < n
+                    b.push_device(*[x[:cut] for x in d])
+                    b.push_device(*[x[cut:] for x in d])
+                    if paralogs >= 30 and hint:
+                        assert b.profile_kernel().startswith("ks_par::"), b.profile_kernel()
+                    if not paralogs and stride in (4, 8, 64, 1024):
+                        assert b.profile_kernel().startswith("ks_std::"), b.profile_kernel()
+                else:
+                    b.push_device(*d)
+                s = b.finalize()
+                _check(b.export(), s, exp)
+                b.reset()
+                b.push_device(*d)
+                assert b.verify_device(*d) == (0, 0)
 
 
 def test_many_small_batches_do_not_leak_the_key_arena():

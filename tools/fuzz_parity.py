@@ -36,6 +36,10 @@ for seed in range(first, first + n_cases):
         _check(out, sizes, exp)
     # device-resident push + the exactness pass
     d = [torch.from_numpy(t[k].view(np.int32)).to(dev) for k in ("read_id", "locus", "hapflag")]
+    for k in ("ECB_FORCE_PAR", "ECB_NO_PAR"):          # the compilation of the stream kernel: the library's choice, ks_par forced, ks_par ruled out -- in turn
+        os.environ.pop(k, None)
+    if seed % 3:
+        os.environ["ECB_FORCE_PAR" if seed % 3 == 1 else "ECB_NO_PAR"] = "1"
     with ecb.EcBuilder(n_loci, n_haps) as b:
         if seed & 1:                                   # every other case with the stream's reads bounded up front (one wait per push)
             b.hint_reads(int(exp["n_reads"]) if "n_reads" in exp else len(t["read_id"]))
