@@ -503,7 +503,9 @@ def main():
             if m is not None:
                 sizes.update(m.b.finalize())
                 n_ecs = sizes["n_ecs"]
-            ecdist.exchange_multisample(eng, m, n_ecs, root=0)      # every rank's reads -> (EC, cell, file) triples against the merged ECs
+            nt = ecdist.exchange_multisample(eng, m, n_ecs, root=0)      # every rank's reads -> (EC, cell, file) triples against the merged ECs
+            if m is not None:
+                sizes["nnz_n"] = nt
             if m is not None:
                 ms_sizes.update(m.b.ms_filter_sizes(n_cells, min_count))
         elif multisample:      # + the cell of every read (4 B per read), the (EC, cell, file) triples, cell order / filter / N on the device

@@ -27,7 +27,30 @@ def main():
     slack = (48 << 20) // 4
     arenas = [None] + [torch.empty(3 * stride + slack, dtype=torch.int32, device=dev) for _ in range(n_arenas - 1)]
     staggers = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
-    with ecb.EcBuilder(T, H, device=0, ec_capacity=1 << (25 if wl == "c3r" else 24 if wl.startswith("c3") else 22), arena_capacity=1 << 26) as b:
+    rounds = [x for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else []       # ECB_ROUNDS[:ECB_MIN_TILES] settings: slices per wave of the launch
+    cap = 1 << (25 if wl == "c3r" else 24 if wl.startswith("c3") else 22)
+    if rounds:                                   # slice geometry against placement: a handle per setting (the launch shape is read once per handle)
+        for i, a in enumerate(arenas):
+            if a is None:
+                views = (rid, loc, hf)
+            else:
+                views = (a[:n], a[stride:stride + n], a[2 * stride:2 * stride + n])
+                for v, src in zip(views, (rid, loc, hf)):
+                    v.copy_(src)
+                torch.cuda.synchronize()
+            for setting in rounds:
+                r_, _, m_ = setting.partition(":")
+                os.environ["ECB_ROUNDS"] = r_
+                if m_:
+                    os.environ["ECB_MIN_TILES"] = m_
+                else:
+                    os.environ.pop("ECB_MIN_TILES", None)
+                with ecb.EcBuilder(T, H, device=0, ec_capacity=cap, arena_capacity=1 << 26) as b:
+                    b.hint_reads(st["reads"])
+                    k, s = timed(b, *views)
+                print("arena %d at %x  slices per wave %s: k_stream %.3f ms  step %.2f ms" % (i, views[0].data_ptr(), setting, k, s), flush=True)
+        return
+    with ecb.EcBuilder(T, H, device=0, ec_capacity=cap, arena_capacity=1 << 26) as b:
         b.hint_reads(st["reads"])
         for rep in range(2):
             for i, a in enumerate(arenas):
