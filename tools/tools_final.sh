@@ -5,7 +5,7 @@
 W=${1:-c3}; TAG=${2:-r04}; COMMIT=${3:-unknown}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final_$W; mkdir -p $O
 timeout -k 10 500 python $R/bench.py --workload $W > $O/bench.log 2>$O/bench.err && grep '^{' $O/bench.log > $O/${TAG}_bench_${W}_n1.json
-bash $R/tools/tools_prof.sh $W gpurun_out/final_$W/prof > $O/${TAG}_rocprof_kernel_stats_$W.txt 2>&1; rm -rf $O/prof
+bash $R/tools/tools_prof.sh $W gpurun_out/final_$W/prof > $O/${TAG}_rocprof_kernel_stats_$W.txt 2>&1; cp $O/prof/profiled_run.json $O/${TAG}_bench_${W}_n1_profiled_run.json 2>/dev/null; rm -rf $O/prof
 bash $R/tools/tools_pmc.sh $W gpurun_out/final_$W/pmc > $O/${TAG}_pmc_k_stream_$W.txt 2>&1; rm -rf $O/pmc
 # FETCH_SIZE once more with the EC table switched off (ECB_ABLATE=4): what is left is the record streams (16-byte-per-lane streaming
 # loads, which gfx950 reports at half their bytes); the difference to the full kernel is the table's 64-byte lines (reported 1:1,

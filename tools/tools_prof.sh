@@ -15,4 +15,11 @@ for r in rows:
     name = r['Name'].split('anonymous namespace)::', 1)[1].split('(')[0] if '::k_' in r['Name'] else r['Name'].split('(')[0]      # (ks_std::k_stream<...> keeps its namespace)
     print("%-34s %6s %10.3f %10.3f %10.3f %12.3f" % (name[:34], r['Calls'], float(r['AverageNs']) / 1e6, float(r.get('MinNs', 0)) / 1e6, float(r.get('MaxNs', 0)) / 1e6, float(r['TotalDurationNs']) / 1e6))
 PY
-tail -1 $OUT/run.log | cut -c1-400
+# the bench line of THIS (profiled) run, whole: its HIP-event time for k_stream is what the profiler's average above must agree with -- another
+# process would have its tuples somewhere else in HBM, which moves the kernel by up to 14 %
+grep '^{' $OUT/run.log | tail -1 > $OUT/profiled_run.json
+python - $OUT/profiled_run.json <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read()); r = d["roofline"]
+print("the profiled run's own bench line: k_stream %.3f ms per launch by HIP events (%s), step %.3f ms, frac %.3f" % (r["kernel_ms_per_launch"], r["kernel"], d["ms_per_step"], r["frac"]))
+PY
