@@ -295,6 +295,14 @@ struct StreamArgs {
     const StreamCold* cold;
     u32 ablate;                      // profiling builds only (-DECB_ABLATE_RT, env ECB_ABLATE): 1 = stop after (a), 2 = after (b), 4 = no EC table, 8 / 16 / 32 see table_lookup
 };
+// Words from one tile of a stream to the next: 512 = three arrays (ecb_push_device); 1536 = whole tiles, a tile's 512 read ids, 512 loci and 512
+// haplotype/flag words side by side (ecb_push_device_tiled: rid = base, loc = base + 512, hf = base + 1024).  Read off the pointers -- three arrays
+// that sit like this hold at most one tile, for which the two readings are the same -- rather than passed: a kernel argument is a scalar register
+// pair for the whole launch, and the stream kernel spills them.
+__device__ __forceinline__ u32 stream_tw(const u32* rid, const u32* loc, const u32* hf) { return (loc == rid + 512 && hf == rid + 1024) ? 1536u : 512u; }
+#define A_TW(A) stream_tw((A).rid, (A).loc, (A).hf)
+// record i of a stream whose tiles are tw words apart
+__host__ __device__ __forceinline__ u64 rec_at(u64 i, u32 tw) { return (i >> 9) * (u64)tw + (i & 511ull); }
 
 __device__ __forceinline__ void wave_sync() {   // orders this wave's LDS traffic (lanes run in lockstep)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -328,8 +336,8 @@ struct TileRegs { u32 rr[RPL], ll[RPL], hh[RPL]; };
 
 // First record of read `rd` among records [b, e) -- the run counter never decreases, and it steps ON a read's first record
 // (the rare paths that hand a read to k_slow ask; nothing on the way of an ordinary tile keeps head positions)
-__device__ __forceinline__ u64 tile_head(const u32* rid, u64 b, u64 e, u32 rd) {
-    while (b < e) { const u64 m = b + ((e - b) >> 1); if ((int)(rid[m] - rd) < 0) b = m + 1; else e = m; }
+__device__ __forceinline__ u64 tile_head(const u32* rid, u64 b, u64 e, u32 rd, u32 tw) {
+    while (b < e) { const u64 m = b + ((e - b) >> 1); if ((int)(rid[rec_at(m, tw)] - rd) < 0) b = m + 1; else e = m; }
     return b;
 }
 __device__ __forceinline__ void load_tile(const StreamArgs& A, u64 tb, u64 te, u32 lane, TileRegs& R) {
@@ -339,9 +347,10 @@ __device__ __forceinline__ void load_tile(const StreamArgs& A, u64 tb, u64 te, u
         // a whole tile: wave-uniform base (scalar registers) + 16 bytes per lane, the second group 4 KB on -- the address costs
         // one shift per tile, not six 64-bit additions
         // (non-temporal: the stream is read once; without the hint it pushes the EC table's lines out of L2 -- measured 3 %)
-        const char* pr = reinterpret_cast<const char*>(A.rid + tb);
-        const char* pl = reinterpret_cast<const char*>(A.loc + tb);
-        const char* ph = reinterpret_cast<const char*>(A.hf + tb);
+        const u64 tbw = (tb >> 9) * (u64)A_TW(A);              // (tb is a tile boundary)
+        const char* pr = reinterpret_cast<const char*>(A.rid + tbw);
+        const char* pl = reinterpret_cast<const char*>(A.loc + tbw);
+        const char* ph = reinterpret_cast<const char*>(A.hf + tbw);
         const u32 off = lane * 16u;                      // (32 bits: the loads take it as an offset to the scalar base)
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -360,9 +369,9 @@ __device__ __forceinline__ void load_tile(const StreamArgs& A, u64 tb, u64 te, u
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool in = i0 + j < te;
-            R.rr[4 * g + j] = A.rid[in ? i0 + j : te - 1];          // (past the end: the last read id again -- no step, no head)
-            R.ll[4 * g + j] = in ? A.loc[i0 + j] : 0u;
-            R.hh[4 * g + j] = in ? A.hf[i0 + j] : 0x4u;
+            R.rr[4 * g + j] = A.rid[rec_at(in ? i0 + j : te - 1, A_TW(A))];          // (past the end: the last read id again -- no step, no head)
+            R.ll[4 * g + j] = in ? A.loc[rec_at(i0 + j, A_TW(A))] : 0u;
+            R.hh[4 * g + j] = in ? A.hf[rec_at(i0 + j, A_TW(A))] : 0x4u;
         }
     }
 }
@@ -728,18 +737,18 @@ __global__ __launch_bounds__(TPB_COUNT) void k_count_bins(const u16* pairs, cons
 // ---------------------------------------------------------------------------------------------
 // k_slow: one workgroup per deferred read (longer than a tile, or bounced off a full table).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_slow_len(const u32* rid, u64 n, const u64* queue, u64 nq, u64* len) {
+__global__ __launch_bounds__(TPB) void k_slow_len(const u32* rid, u64 n, const u64* queue, u64 nq, u64* len, u32 tw) {
     // length in records of each queued read (its head index .. the next change of read_id)
     const u64 q = blockIdx.x;
     if (q >= nq) return;
     __shared__ u64 s_end;
     const u64 h = queue[q];
-    const u32 r0 = rid[h];
+    const u32 r0 = rid[rec_at(h, tw)];
     if (threadIdx.x == 0) s_end = n;
     __syncthreads();
     for (u64 b = h; b < n; b += TPB) {
         const u64 i = b + threadIdx.x;
-        if (i < n && rid[i] != r0) atomicMin(&s_end, i);
+        if (i < n && rid[rec_at(i, tw)] != r0) atomicMin(&s_end, i);
         __syncthreads();
         const bool found = (s_end != n);
         __syncthreads();
@@ -786,9 +795,9 @@ __global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
     __shared__ u32 s_np, s_st, s_n1, s_off, s_cnt, s_diff, s_inc, s_probes;
 
     for (u64 i = tid; i < L; i += TPB) {
-        const u32 f = A.hf[h + i];
+        const u32 f = A.hf[rec_at(h + i, A_TW(A))];
         if (!rec_valid(f)) continue;
-        const u32 lc = A.loc[h + i], hap = (f >> ECB_HAP_SHIFT) & 0xFFu;
+        const u32 lc = A.loc[rec_at(h + i, A_TW(A))], hap = (f >> ECB_HAP_SHIFT) & 0xFFu;
         if (lc >= A.n_loci || hap >= A.n_haps) { atomicOr(&A.ctr->err, ERR_RANGE); continue; }
         u64 p = slow_probe_start(lc, cap2);
         for (;;) {
@@ -814,7 +823,7 @@ __global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
     np = wave_sum(np);
     if (lane == 0) { s_acc[tid >> 6] = a0; s_n[tid >> 6] = np; }
     __syncthreads();
-    const u32 r0 = A.rid[h];
+    const u32 r0 = A.rid[rec_at(h, A_TW(A))];
     if (tid == 0) {
         a0 = 0; np = 0;
         for (int w = 0; w < TPB / 64; ++w) { a0 += s_acc[w]; np += s_n[w]; }
@@ -2404,7 +2413,7 @@ int ensure_read_slot(ecb_handle* h, u64 need) {
 // deferred reads: measure, scratch, k_slow; grow the table and repeat while reads bounce.  All scratch lives in the
 // handle's pool (a stream of long reads pays no hipMalloc per round, and no early return can leak it).
 // verify: the exactness pass over the same reads (compare with the EC each was given; no insert, one round).
-int run_slow(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf, u64 n, u64* d_q, u64 nq, bool verify = false) {
+int run_slow(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf, u64 n, u64* d_q, u64 nq, bool verify = false, u32 tw = 512u) {
     int rc = ECB_OK;
     int flip = 0;
     while (nq) {
@@ -2412,7 +2421,7 @@ int run_slow(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf,
         POOL(h, P_SLOW_LEN, d_len, nq); POOL(h, P_SLOW_OFF, d_off, nq); POOL(h, P_SLOW_NRE, d_nre, 1);
         if (flip) POOL(h, P_SLOW_REQ2, nre_buf, nq); else POOL(h, P_SLOW_REQ, nre_buf, nq);      // (d_q may be the other one)
         HIPCHK(h, hipMemsetAsync(d_nre, 0, sizeof(u64), h->stream));
-        k_slow_len<<<(unsigned)nq, TPB, 0, h->stream>>>(d_rid, n, d_q, nq, d_len);
+        k_slow_len<<<(unsigned)nq, TPB, 0, h->stream>>>(d_rid, n, d_q, nq, d_len, tw);
         std::vector<u64> len(nq), off(nq);
         HIPCHK(h, hipMemcpyAsync(len.data(), d_len, nq * sizeof(u64), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -2492,7 +2501,7 @@ int plan_stream(ecb_handle* h, u64 n, StreamPlan* P, bool ranges = false, bool s
 // set is derived again from its records and compared, pair by pair, with the key of the EC the read was given.
 // Reads longer than a tile go through k_slow's compare.  *n_mismatch = reads in a wrong EC (0 = exact); *n_long = how many
 // took the long path.
-int verify_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf, u64 n, u32 prev_rid, u64* n_mismatch, u64* n_long) {
+int verify_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf, u64 n, u32 prev_rid, u64* n_mismatch, u64* n_long, u32 tw = 512u) {
     StreamPlan P;
     int rc = plan_stream(h, n, &P);
     if (rc != ECB_OK) return rc;
@@ -2515,7 +2524,7 @@ int verify_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d
     if (rc != ECB_OK) return rc;
     const u64 nq = std::min<u64>(h->hctr.n_queue, h->queue_cap);
     if (nq) {
-        rc = run_slow(h, d_rid, d_loc, d_hf, n, h->queue, nq, true);
+        rc = run_slow(h, d_rid, d_loc, d_hf, n, h->queue, nq, true, tw);
         if (rc != ECB_OK) return rc;
     }
     *n_mismatch = h->hctr.n_mismatch;
@@ -2526,7 +2535,7 @@ int verify_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d
 }
 
 // one batch of whole reads, device-resident
-int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf, const int* d_pos, u64 n) {
+int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf, const int* d_pos, u64 n, u32 tw = 512u) {
     if (n == 0) return ECB_OK;
     // How many reads the stream holds after this batch: the read id of its last record, fetched before anything is launched -- or,
     // when the caller has said how many reads the whole stream holds at most (ecb_hint_reads), that bound now and the
@@ -2535,7 +2544,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     u32 last_rid = 0;
     u64 reads_after = std::max<u64>(h->reads_hint, h->n_reads);
     if (!hinted) {
-        HIPCHK(h, hipMemcpyAsync(&last_rid, d_rid + (n - 1), sizeof(u32), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(&last_rid, d_rid + rec_at(n - 1, tw), sizeof(u32), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         reads_after = (u64)(u32)(last_rid + 1u);
         if (reads_after < h->n_reads) return fail(h, ECB_ERR_CONTRACT, "read_id went backwards across pushes");
@@ -2601,7 +2610,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
         else if (par) { ks_par::k_stream<false><<<(unsigned)blocks, TPB, 0, h->stream>>>(a); h->last_kernel = "ks_par::k_stream<false, false>"; }
         else { ks_std::k_stream<false><<<(unsigned)blocks, TPB, 0, h->stream>>>(a); h->last_kernel = "ks_std::k_stream<false, false>"; }
         if (h->prof) hipEventRecord(h->ev1, h->stream);
-        k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, pwaves, h->ctr, 0u, offered, d_rid + (n - 1));
+        k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, pwaves, h->ctr, 0u, offered, d_rid + rec_at(n - 1, tw));
         offered = 0;                                    // (a relaunch after a park continues the same batch)
         HIPCHK(h, hipGetLastError());
         rc = sync_counters(h);
@@ -2612,7 +2621,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
         if (rc != ECB_OK) break;
         const bool parked = h->hctr.full != 0;
         if (h->hctr.n_queue) {
-            rc = run_slow(h, d_rid, d_loc, d_hf, n, h->queue, std::min<u64>(h->hctr.n_queue, h->queue_cap));
+            rc = run_slow(h, d_rid, d_loc, d_hf, n, h->queue, std::min<u64>(h->hctr.n_queue, h->queue_cap), false, tw);
             if (rc != ECB_OK) break;
         }
         if (!parked) break;
@@ -2639,7 +2648,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     if (h->prof) h->prof_records += n;
     if (h->cfg.flags & ECB_F_VERIFY) {                  // belt and braces: the grouping is exact by construction (Slot), this re-derives it
         u64 bad = 0, nl = 0;
-        rc = verify_batch(h, d_rid, d_loc, d_hf, n, h->prev_rid, &bad, &nl);
+        rc = verify_batch(h, d_rid, d_loc, d_hf, n, h->prev_rid, &bad, &nl, tw);
         if (rc != ECB_OK) return rc;
         h->n_mismatch += bad;
         if (bad) return fail(h, ECB_ERR_VERIFY, "exactness pass: %llu read(s) of this batch sit in an EC whose key is not their target set", (unsigned long long)bad);
@@ -2657,8 +2666,9 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
 
 int ensure_staging(ecb_handle* h, u64 need) {
     if (need <= h->st_cap) return ECB_OK;
-    // one allocation for the three (four) staging streams, each on a 2 MiB boundary within it (see bench.py: generate_shard -- where separate
-    // allocations land moves the stream kernel by several per cent)
+    // one allocation for the three (four) staging streams, each on a 2 MiB boundary within it.  (Staging in whole tiles -- what
+    // ecb_push_device_tiled takes -- was built and measured: the pitched host-to-device copies cost the PCIe-inclusive rate 8 %, and the
+    // tile layout did not take the placement dependence out of the kernel after all: DESIGN.md section 6.)
     if (h->st_rid) hipFree(h->st_rid);
     h->st_rid = h->st_loc = h->st_hf = nullptr; h->st_pos = nullptr;
     h->st_cap = std::max<u64>(need, h->cfg.max_batch_records);
@@ -3113,6 +3123,37 @@ int ecb_push_device(ecb_handle* h, const void* d_read_id, const void* d_locus, c
     if (!h->c_rid.empty()) return fail(h, ECB_ERR_STATE, "ecb_push_device while a host push has an open read");
     HIPCHK(h, hipSetDevice(h->device));
     return process_batch(h, (const u32*)d_read_id, (const u32*)d_locus, (const u32*)d_hapflag, (const int*)d_pos, n);
+}
+
+// The same from ONE buffer of whole tiles: tile t = words [1536 t, 1536 t + 1536) = 512 read ids | 512 loci | 512 haplotype/flag words of records
+// [512 t, 512 t + 512) (the last tile padded: the buffer holds ceil(n / 512) tiles).  What a tile of the stream kernel reads is then 6 KB in one
+// place instead of 2 KB in each of three.  (Built to take the kernel's dependence on where the streams sit in HBM out -- a micro-benchmark of the
+// reads alone said three streams side by side were the sensitive part -- and measured: it narrows the spread, 7.7 - 8.7 ms against 7.7 - 9.3 on
+// config 3, but does not remove it: DESIGN.md section 6.  Kept as a second way in for callers whose tuples sit in one buffer.)
+int ecb_push_device_tiled(ecb_handle* h, const void* d_tiles, size_t n) {
+    if (!h) return ECB_ERR_ARG;
+    if (h->finalized || h->counted) return fail(h, ECB_ERR_STATE, "push after finalize / table export");
+    if (n && !d_tiles) return fail(h, ECB_ERR_ARG, "null tuple stream");
+    if (h->cfg.flags & ECB_F_RANGES) return fail(h, ECB_ERR_STATE, "ECB_F_RANGES takes the four streams of ecb_push_device");
+    if ((uintptr_t)d_tiles & 15) return fail(h, ECB_ERR_ARG, "device streams must be 16-byte aligned");
+    if (!h->c_rid.empty()) return fail(h, ECB_ERR_STATE, "ecb_push_device_tiled while a host push has an open read");
+    HIPCHK(h, hipSetDevice(h->device));
+    const u32* d = (const u32*)d_tiles;
+    return process_batch(h, d, d + 512, d + 1024, nullptr, n, 1536u);
+}
+
+int ecb_verify_device_tiled(ecb_handle* h, const void* d_tiles, size_t n, uint64_t* n_mismatch, uint64_t* n_long_reads) {
+    if (!h || !n_mismatch) return ECB_ERR_ARG;
+    if (!n || !d_tiles) return fail(h, ECB_ERR_ARG, "null tuple stream");
+    if ((uintptr_t)d_tiles & 15) return fail(h, ECB_ERR_ARG, "device streams must be 16-byte aligned");
+    HIPCHK(h, hipSetDevice(h->device));
+    u64 bad = 0, nl = 0;
+    const u32* d = (const u32*)d_tiles;
+    const int rc = verify_batch(h, d, d + 512, d + 1024, n, 0xFFFFFFFFu, &bad, &nl, 1536u);
+    if (rc != ECB_OK) return rc;
+    *n_mismatch = bad;
+    if (n_long_reads) *n_long_reads = nl;
+    return ECB_OK;
 }
 
 int ecb_push(ecb_handle* h, const uint32_t* rid, const uint32_t* loc, const uint32_t* hf, const int32_t* pos, size_t n) {

@@ -34,7 +34,7 @@ SYMBOLS = ("ecb_abi_version", "ecb_device_count", "ecb_create", "ecb_destroy", "
            "ecb_export_firsts_device", "ecb_assemble_ranges_device", "ecb_table_rebase_device",
            "ecb_export_ec_keys_device", "ecb_ms_local_triples_device", "ecb_ms_adopt_triples_device", "ecb_counters", "ecb_add_counters", "ecb_profile",
            "ecb_profile_read", "ecb_profile_kernel", "ecb_csr_to_hapcsc_device", "ecb_hapcsc_to_csr_device", "ecb_release_scratch",
-           "ecb_csr_to_hapcsc", "ecb_hapcsc_to_csr", "ecb_merge")
+           "ecb_csr_to_hapcsc", "ecb_hapcsc_to_csr", "ecb_merge", "ecb_push_device_tiled", "ecb_verify_device_tiled")
 ABI_VERSION = 4            # include/ecb.h: ECB_ABI_VERSION
 
 
@@ -132,6 +132,9 @@ def load():
     lib.ecb_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]
     if not ab or hasattr(lib, "ecb_merge"):
         lib.ecb_merge.argtypes = [C.POINTER(vp), C.c_uint32, vp, C.POINTER(Sizes)]
+    if not ab or hasattr(lib, "ecb_push_device_tiled"):
+        lib.ecb_push_device_tiled.argtypes = [vp, vp, sz]
+        lib.ecb_verify_device_tiled.argtypes = [vp, vp, sz, C.POINTER(u64), C.POINTER(u64)]
     if not ab or hasattr(lib, "ecb_profile_kernel"):
         lib.ecb_profile_kernel.argtypes = [vp]
         lib.ecb_profile_kernel.restype = C.c_char_p
@@ -150,6 +153,24 @@ def _ptr(a):
 
 def _dev_ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def tile_tuples(read_id, locus, hapflag, out=None):
+    """Three device arrays of ``n`` records -> one int32 tensor of whole tiles for :meth:`EcBuilder.push_device_tiled` (tile t = words
+    ``[1536 t, 1536 t + 1536)`` = 512 read ids | 512 loci | 512 haplotype/flag words; the last tile's padding is zero)."""
+    import torch
+    n = read_id.numel()
+    nt = (n + 511) // 512
+    tiles = out if out is not None else torch.zeros(nt * 1536, dtype=torch.int32, device=read_id.device)
+    v = tiles[:nt * 1536].view(nt, 3, 512)
+    full = n // 512
+    for k, src in enumerate((read_id, locus, hapflag)):
+        src = src.view(torch.int32) if src.dtype != torch.int32 else src
+        if full:
+            v[:full, k, :] = src[:full * 512].view(full, 512)
+        if n > full * 512:
+            v[full, k, :n - full * 512] = src[full * 512:]
+    return tiles
 
 
 def csr_to_hapcsc(indptr, indices, data, n_loci, n_haps, nnz=None):
@@ -291,6 +312,18 @@ class EcBuilder(object):
                 raise ValueError("device tuple streams must be contiguous 4-byte CUDA tensors of equal length")
         self._chk(self._lib.ecb_push_device(self._h, _dev_ptr(read_id), _dev_ptr(locus), _dev_ptr(hapflag),
                                             _dev_ptr(pos), n))
+
+    def push_device_tiled(self, tiles, n):
+        """``n`` records in ONE int32 CUDA tensor of whole tiles (``ecb_push_device_tiled``: 512 read ids | 512 loci | 512 haplotype/flag
+        words per tile, ``ceil(n / 512) * 1536`` words); whole reads per call.  :func:`tile_tuples` lays three arrays out this way."""
+        if not tiles.is_cuda or not tiles.is_contiguous() or tiles.element_size() != 4 or tiles.numel() < (n + 511) // 512 * 1536:
+            raise ValueError("tiles: a contiguous 4-byte CUDA tensor of ceil(n / 512) * 1536 words")
+        self._chk(self._lib.ecb_push_device_tiled(self._h, _dev_ptr(tiles), n))
+
+    def verify_device_tiled(self, tiles, n):
+        bad, skipped = C.c_uint64(), C.c_uint64()
+        self._chk(self._lib.ecb_verify_device_tiled(self._h, _dev_ptr(tiles), n, C.byref(bad), C.byref(skipped)))
+        return bad.value, skipped.value
 
     def hint_reads(self, max_reads):
         """The stream holds at most ``max_reads`` reads: ``push_device`` then waits for the device once per call, not twice

@@ -80,6 +80,48 @@ def generate_shard(spec, r0, r1, device, chunk_reads=1 << 20):
     return rid, loc, hf, dict(records=n, reads=reads, valid=valid)
 
 
+def generate_tiles(spec, r0, r1, device, chunk_reads=1 << 20):
+    """The same tuples in the layout of ``ecb_push_device_tiled``: ONE int32 tensor of whole tiles, tile t = words [1536 t, 1536 t + 1536) = the 512
+    read ids | 512 loci | 512 haplotype/flag words of records [512 t, 512 t + 512).  -> (tiles, counts as generate_shard's)."""
+    import torch
+    from alntools_amd import synth
+    n = synth.count_records(spec, r0, r1, device=device)
+    nt = (n + 511) // 512
+    tiles = torch.zeros(nt * 1536, dtype=torch.int32, device=device)
+    cols = [torch.as_strided(tiles, (nt, 512), (1536, 1), 512 * k) for k in range(3)]      # stream k as rows of 512 records
+
+    def put(col, at, src):                       # src -> records [at, at + len(src)) of a stream
+        m = src.numel()
+        head = min(m, (512 - at % 512) % 512)
+        if head:
+            col[at // 512, at % 512:at % 512 + head] = src[:head]
+        rows = (m - head) // 512
+        if rows:
+            col[(at + head) // 512:(at + head) // 512 + rows] = src[head:head + rows * 512].view(rows, 512)
+        tail = m - head - rows * 512
+        if tail:
+            col[(at + m) // 512, :tail] = src[m - tail:]
+
+    at, reads, valid = 0, 0, 0
+    for a in range(r0, r1, chunk_reads):
+        g = synth.generate(spec, a, min(a + chunk_reads, r1), device=device, read_id_base=reads)
+        for col, key in zip(cols, ("read_id", "locus", "hapflag")):
+            put(col, at, g[key])
+        at += g["n_records"]
+        reads += g["n_reads"]
+        valid += g["n_valid"]
+        del g
+    assert at == n
+    return tiles, dict(records=n, reads=reads, valid=valid)
+
+
+def tiles_to_arrays(tiles, n):
+    """Three contiguous int32 tensors out of a tensor of whole tiles (copies: the oracle legs and the host-path legs want arrays)."""
+    import torch
+    nt = (n + 511) // 512
+    return tuple(torch.as_strided(tiles, (nt, 512), (1536, 1), 512 * k).reshape(-1)[:n].contiguous() for k in range(3))
+
+
 def _host_slice(rid, loc, hf, n_reads):
     """The first ``n_reads`` reads of the device-resident stream as host uint32 arrays (whole reads)."""
     import numpy as np
@@ -109,12 +151,12 @@ def cpu_baseline(rid, loc, hf, n_haps, sample_reads, threads=0):
     return line, (r if whole else None)
 
 
-def parity_vs_oracle(b, rid, loc, hf, exp):
+def parity_vs_oracle(b, push, exp):
     """The GPU's result on the whole workload against the C oracle's on the same tuples: CSR A (indptr, indices, data), the
     counts and the three counters, bit for bit.  Outside the timed region.  -> (equal?, what differs)."""
     import numpy as np
     b.reset()
-    b.push_device(rid, loc, hf)
+    push()                                     # (the product path as the timed steps took it: tiles or arrays)
     sizes = b.finalize()
     out = b.export()
     diff = [k for k, (a, e) in dict(indptr=(out["indptrA"], exp["indptr"]), indices=(out["indicesA"], exp["indices"]),
@@ -190,7 +232,7 @@ def e2e_from_bam(spec_args, reads, tmpdir):
                      "all @SQ names included (host_header_seconds: a fixed cost per file, most of a slice this small)" % decoder)
 
 
-def secondary(name, device, local, steps, with_oracle):
+def secondary(name, device, local, steps, with_oracle, layout="arrays"):
     """A further workload behind the headline's timed steps, on the same box in the same run: ``steps`` whole steps (reset -> push ->
     finalize) after one warm-up, the stream kernel's own HIP-event time, and the result held to the C oracle's on the whole workload
     (workloads above a billion records: the device's own exactness pass instead -- every read's target set against its EC's key)."""
@@ -198,16 +240,28 @@ def secondary(name, device, local, steps, with_oracle):
     from alntools_amd import ecb
     R, T, H, paired, desc = WORKLOADS[name]
     spec = workload_spec(name)
-    rid, loc, hf, st = generate_shard(spec, 0, R, device)
+    tiled = layout == "tiles"
+    if tiled:
+        tiles, st = generate_tiles(spec, 0, R, device)
+        rid = loc = hf = None
+    else:
+        rid, loc, hf, st = generate_shard(spec, 0, R, device)
+    n_rec = st["records"]
+
+    def push():
+        if tiled:
+            b.push_device_tiled(tiles, n_rec)
+        else:
+            b.push_device(rid, loc, hf)
     cap = 1 << (25 if name == "c3r" else 24 if name.startswith("c3") else 22)
-    out = {"workload": desc, "records": st["records"], "reads_with_alignments": st["reads"]}
+    out = {"workload": desc, "records": st["records"], "reads_with_alignments": st["reads"], "layout": layout}
     with ecb.EcBuilder(T, H, device=local, ec_capacity=cap, arena_capacity=1 << 26) as b:
         b.hint_reads(st["reads"])
         sizes = {}
 
         def step():
             b.reset()
-            b.push_device(rid, loc, hf)
+            push()
             sizes.update(b.finalize())
 
         step()
@@ -227,8 +281,8 @@ def secondary(name, device, local, steps, with_oracle):
                    achieved=alg / (k_per * 1e-3) / 1e9, frac=alg / (k_per * 1e-3) / 1e9 / HBM_PEAK_GBS, algorithmic_bytes_per_launch=alg,
                    value=st["records"] / (dt / steps), ecs=sizes.get("n_ecs"), nnz_a=sizes.get("nnz_a"))
         if with_oracle and st["records"] <= 1_000_000_000:
-            base, oracle_result = cpu_baseline(rid, loc, hf, H, 0)
-            ok, diff = parity_vs_oracle(b, rid, loc, hf, oracle_result)
+            base, oracle_result = cpu_baseline(*(tiles_to_arrays(tiles, n_rec) if tiled else (rid, loc, hf)), H, 0)
+            ok, diff = parity_vs_oracle(b, push, oracle_result)
             out["parity_vs_oracle"] = ok
             out["cpu_baseline"] = {"value": base["value"], "cores": base["cores"], "kind": base["kind"]}
             if not ok:
@@ -236,35 +290,41 @@ def secondary(name, device, local, steps, with_oracle):
             del oracle_result
         else:
             b.reset()
-            b.push_device(rid, loc, hf)
-            bad, skipped = b.verify_device(rid, loc, hf)
+            push()
+            bad, skipped = b.verify_device_tiled(tiles, n_rec) if tiled else b.verify_device(rid, loc, hf)
             out["parity_vs_oracle"] = None
             out["exactness_pass"] = {"reads_differing_from_their_ec_key": bad, "reads_on_the_long_read_path": skipped}
     del rid, loc, hf
+    if tiled:
+        del tiles
     torch.cuda.empty_cache()
     return out
 
 
-def placement_spread(b, rid, loc, hf, step_from, n_arenas=3, steps=3):
-    """k_stream's time with the SAME tuples at other places in HBM: ``n_arenas`` further allocations of the streams' size, the tuples copied
-    into each, ``steps`` steps from each (untimed for the headline, which was measured where generate_shard put the tuples).  On one box the time
-    moves by up to 14 % with where the 40 GB sit, reproducibly per allocation and for no reason this repository could pin down (not the stagger
-    between the streams, not the region's plain read rate: profiles/r04_stream_regions*.txt); this says where in that spread the run's own
-    allocation lies.  -> ms per launch, the run's own allocation first."""
+def placement_spread(b, tensors, step_from, n_arenas=3, steps=3):
+    """k_stream's time with the SAME tuples at other places in HBM: ``n_arenas`` further allocations of the tuples' size, the tuples copied
+    into each, ``steps`` steps from each (untimed for the headline, which was measured where the generator put the tuples).  ``tensors``: the
+    one tensor of whole tiles, or the three arrays (which then share ONE further allocation each time, as generate_shard lays them out).
+    With three arrays the time moves by up to 14 % with where the 40 GB sit, reproducibly per allocation (profiles/r04_stream_regions*.txt);
+    with whole tiles by somewhat less (profiles/r04_tiles_against_arrays.txt).  -> ms per launch, the run's own allocation first."""
     import torch
-    n = rid.numel()
-    stride = (n * 4 + (2 << 20) - 1) // (2 << 20) * (2 << 20) // 4
-    out = []
-    arenas = []
+    out, arenas = [], []
     try:
         for i in range(n_arenas + 1):
             if i == 0:
-                views = (rid, loc, hf)
-            else:
-                a = torch.empty(3 * stride, dtype=torch.int32, device=rid.device)
+                views = tensors
+            elif len(tensors) == 1:
+                a = torch.empty_like(tensors[0])
                 arenas.append(a)              # (all kept until the end: allocations that exist at the same time are different memory)
+                a.copy_(tensors[0])
+                views = (a,)
+            else:
+                n = tensors[0].numel()
+                stride = (n * 4 + (2 << 20) - 1) // (2 << 20) * (2 << 20) // 4
+                a = torch.empty(3 * stride, dtype=torch.int32, device=tensors[0].device)
+                arenas.append(a)
                 views = (a[:n], a[stride:stride + n], a[2 * stride:2 * stride + n])
-                for v, src in zip(views, (rid, loc, hf)):
+                for v, src in zip(views, tensors):
                     v.copy_(src)
             torch.cuda.synchronize()
             step_from(*views)
@@ -381,6 +441,9 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the C baseline (0 = every hardware thread of the host)")
     ap.add_argument("--py-sample-reads", type=int, default=1_000_000, help="reads of the Python restatement's slice")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip every host-side measurement (C / Python baselines, H2D, BAM)")
+    ap.add_argument("--layout", default="arrays", choices=("arrays", "tiles"),
+                    help="how the resident tuples sit in HBM: three arrays in one allocation (ecb_push_device; the default: what the library's own staging for "
+                         "host batches uses) or one buffer of whole tiles (ecb_push_device_tiled)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (c2, c3r, dip) behind a default config-3 run")
     ap.add_argument("--secondary-steps", type=int, default=5)
     ap.add_argument("--e2e-slice-reads", type=int, default=100_000, help="reads of the config-2 slice converted from a real BAM file")
@@ -426,9 +489,21 @@ def main():
     spec = workload_spec(args.workload)
     r0, r1 = rank * R // world, (rank + 1) * R // world
     t_gen = time.perf_counter()
-    rid, loc, hf, st = generate_shard(spec, r0, r1, device)
+    tiled = args.layout == "tiles"
+    tiles = rid = loc = hf = None
+    if tiled:
+        tiles, st = generate_tiles(spec, r0, r1, device)
+    else:
+        rid, loc, hf, st = generate_shard(spec, r0, r1, device)
+    n_rec = st["records"]
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
+
+    def push():                                   # the resident tuples into the handle: whole tiles or three arrays
+        if tiled:
+            b.push_device_tiled(tiles, n_rec)
+        else:
+            b.push_device(rid, loc, hf)
 
     # EC-table slots: sized for the workload's EC count (c3: 3.7 M ECs) so that the timed steps do not grow it
     # (a shard of 1/4 or 1/8 of config 3 still founds 2.3 - 3 M of its 3.7 M ECs: 2^23 slots keep it under half full)
@@ -495,7 +570,7 @@ def main():
 
     def step():
         b.reset()
-        b.push_device(rid, loc, hf)
+        push()
         if multisample and use_dist:      # config 4 as BASELINE names it: per-barcode EC build over the GPUs
             b.push_cells_device(meta, 0)
             m = ecdist.exchange_and_merge(eng, make_part, make_root, root=0, finalize_ranges=per_range)
@@ -583,8 +658,8 @@ def main():
     if not use_dist and not multisample and not os.environ.get("ECB_ABLATE") and not os.environ.get("ECB_NO_VERIFY"):
         # outside the timed region: re-derive every read's target set and compare it with its EC's stored key
         b.reset()
-        b.push_device(rid, loc, hf)
-        bad, skipped = b.verify_device(rid, loc, hf)
+        push()
+        bad, skipped = b.verify_device_tiled(tiles, n_rec) if tiled else b.verify_device(rid, loc, hf)
         exact = {"reads_differing_from_their_ec_key": bad, "reads_on_the_long_read_path": skipped}
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
@@ -644,6 +719,8 @@ def main():
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
+            "layout": ("whole tiles: one buffer, 512 read ids | 512 loci | 512 haplotype/flag words per tile (ecb_push_device_tiled)" if tiled else
+                       "three arrays in one allocation (ecb_push_device)"),
             "config": {"workload": desc, "reads": R, "loci": T, "haplotypes": H, "paired_end": paired,
                        "records": total_records, "valid_alignments": total_valid, "reads_with_alignments": total_reads,
                        "ecs": sizes.get("n_ecs"), "nnz_a": sizes.get("nnz_a"),
@@ -666,22 +743,28 @@ def main():
         }
         out["config"]["sensors_under_load"] = sensors
         if world == 1 and not multisample and not os.environ.get("ECB_ABLATE") and not args.no_cpu_baseline and args.workload in ("c3", "c2"):
-            def step_from(r_, l_, h_):
+            def step_from(*t_):
                 b.reset()
-                b.push_device(r_, l_, h_)
+                if tiled:
+                    b.push_device_tiled(t_[0], n_rec)
+                else:
+                    b.push_device(*t_)
                 b.finalize()
             try:
-                spread = placement_spread(b, rid, loc, hf, step_from)
+                spread = placement_spread(b, (tiles,) if tiled else (rid, loc, hf), step_from)
                 out["roofline"]["kernel_ms_by_placement"] = spread
                 out["roofline"]["kernel_ms_by_placement_note"] = ("k_stream ms per launch with the same tuples in this run's own allocation (first) and in %d further allocations made "
-                                                                  "side by side: where the tuples sit in HBM moves the kernel by up to 14 %% on one box, reproducibly per allocation "
-                                                                  "(profiles/r04_stream_regions*.txt); the headline is the first one's, whatever it is" % (len(spread) - 1))
+                                                                  "side by side (layout: %s).  As three arrays, where the tuples sit in HBM moves the kernel by up to 14 %% on one box, "
+                                                                  "reproducibly per allocation (profiles/r04_stream_regions*.txt); as whole tiles by somewhat less "
+                                                                  "(profiles/r04_tiles_against_arrays.txt).  The headline is the first one's, whatever it is" % (len(spread) - 1, args.layout))
             except Exception as e:
                 out["roofline"]["kernel_ms_by_placement"] = {"error": repr(e)}
         if not use_dist and not args.no_cpu_baseline and not multisample:
+            if tiled:                          # (the host-side legs -- the oracle, the Python baseline, the PCIe-inclusive push -- take arrays: copies)
+                rid, loc, hf = tiles_to_arrays(tiles, n_rec)
             out["cpu_baseline"], oracle_result = cpu_baseline(rid, loc, hf, H, args.cpu_sample_reads, args.cpu_threads)
             if oracle_result is not None:      # the whole workload went through the oracle: hold the GPU's result to it, bit for bit
-                ok, diff = parity_vs_oracle(b, rid, loc, hf, oracle_result)
+                ok, diff = parity_vs_oracle(b, push, oracle_result)
                 out["parity_vs_oracle"] = ok
                 out["config"]["parity_vs_oracle"] = "CSR A, counts and counters of the whole workload equal oracle/ec_oracle.c's" if ok else "DIFFERS: " + ", ".join(diff)
                 parity_failed = not ok
@@ -691,7 +774,7 @@ def main():
                 out["secondary"] = {}
                 for name in ("c2", "c3r", "dip"):
                     try:
-                        out["secondary"][name] = secondary(name, device, local, args.secondary_steps, True)
+                        out["secondary"][name] = secondary(name, device, local, args.secondary_steps, True, args.layout)
                         if out["secondary"][name].get("parity_vs_oracle") is False:
                             parity_failed = True
                     except Exception as e:      # (a secondary line never costs the headline)

@@ -111,6 +111,12 @@ int ecb_push(ecb_handle* h, const uint32_t* read_id, const uint32_t* locus, cons
              const int32_t* pos, size_t n);
 int ecb_push_device(ecb_handle* h, const void* d_read_id, const void* d_locus, const void* d_hapflag,
                     const void* d_pos, size_t n);
+/* The same from ONE device buffer of whole tiles (ABI 4): tile t = uint32 words [1536 t, 1536 t + 1536) = the 512 read ids | 512 loci | 512
+ * haplotype/flag words of records [512 t, 512 t + 512); the buffer holds ceil(n / 512) tiles (the last one padded with anything), 16-byte
+ * aligned; whole reads per call as for ecb_push_device; not with ECB_F_RANGES.  A tile of the stream kernel then reads 6 KB in one place
+ * instead of 2 KB in each of three multi-GB arrays: on config 3 that narrows how far the kernel's time moves with where the tuples sit in
+ * HBM (7.7 - 8.7 ms against 7.7 - 9.3 ms), without removing it.  Batches of the two kinds may be mixed on one handle. */
+int ecb_push_device_tiled(ecb_handle* h, const void* d_tiles, size_t n);
 /* Optional: the whole stream holds at most max_reads reads (reads with a record that passes the filter).  With the bound
  * known, a push of device-resident tuples sizes its per-read state from it and no longer asks the device for the batch's
  * last read id before it launches anything: one host wait per push instead of two.  A stream that runs past the bound is
@@ -181,6 +187,7 @@ int ecb_export_read_ec(ecb_handle* h, int32_t* ec_of_read);
  * which are re-checked too, on the long-read path. */
 int ecb_verify_device(ecb_handle* h, const void* d_read_id, const void* d_locus, const void* d_hapflag, size_t n,
                       uint64_t* n_mismatch, uint64_t* n_long);
+int ecb_verify_device_tiled(ecb_handle* h, const void* d_tiles, size_t n, uint64_t* n_mismatch, uint64_t* n_long_reads);
 
 /* Multi-GPU: one handle per GPU over contiguous read shards (the reference's contiguous chunk
  * ranges per process, bam_utils.py:646-658).  A rank serialises its EC table (device buffers the

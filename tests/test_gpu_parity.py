@@ -1252,3 +1252,60 @@ def test_multi_gpu_entry_points_refuse_wrong_states():
         ms.ms_adopt_triples_device([out + (0,)])                         # not an adopting, finalized handle
     b.close()
     ms.close()
+
+
+def test_tuples_pushed_as_whole_tiles_equal_tuples_pushed_as_three_arrays():
+    """``ecb_push_device_tiled``: one buffer of tiles -- 512 read ids | 512 loci | 512 haplotype/flag words per tile -- instead of three arrays.
+    Same result as the oracle's on: a stream that ends inside a tile, one shorter than a tile, reads longer than a tile (the long-read path
+    indexes the tiles too), a stream pushed half as tiles and half as arrays, the short-read and the paralog compilations, a table that has to
+    grow; the exactness pass reads the tiles; the entry point refuses what it cannot take."""
+    import torch
+    from oracle import c_oracle
+    dev = torch.device("cuda:0")
+
+    def up(t):
+        return [torch.from_numpy(t[k].view(np.int32)).to(dev) for k in ("read_id", "locus", "hapflag")]
+
+    cases = []
+    for spec in (synth.SynthSpec(30011, 3000, 8, paired=True), synth.SynthSpec(7, 50, 2, paired=False),
+                 synth.SynthSpec(90000, 2000, 2, paired=False, n_variants=2), synth.SynthSpec(60000, 9000, 8, paired=True, paralog_pct=60)):
+        t = synth.generate(spec, 0, spec.n_reads)
+        cases.append((t, spec.n_loci, spec.n_haps))
+    T, H = 5000, 4
+    big = [(1, (i * 7) % T, i % H, 0) for i in range(6000)]
+    recs = [(0, 5, 1, 0), (0, 5, 2, 0)] + big + [(2, 5, 2, 0)] + [(3, l, h, f) for (_, l, h, f) in reversed(big)] + [(4, 4999, 3, 0)]
+    cases.append((_hand(recs, H), T, H))
+    for t, n_loci, n_haps in cases:
+        exp = c_oracle.ec_from_tuples(t["read_id"], t["locus"], t["hapflag"], n_haps, threads=4)
+        d = up(t)
+        n = len(t["read_id"])
+        tiles = ecb.tile_tuples(*d)
+        assert tiles.numel() == (n + 511) // 512 * 1536
+        for hint, cap in ((0, 1 << 16), (exp["n_reads"], 1 << 10)):
+            with ecb.EcBuilder(n_loci, n_haps, ec_capacity=cap) as b:
+                b.hint_reads(hint)
+                b.push_device_tiled(tiles, n)
+                s = b.finalize()
+                _check(b.export(), s, exp)
+                b.reset()
+                b.push_device_tiled(tiles, n)
+                assert b.verify_device_tiled(tiles, n)[0] == 0          # (second figure: reads that took the long-read compare)
+                assert b.verify_device(*d) == b.verify_device_tiled(tiles, n)      # (the same records as three arrays)
+        # first part as tiles, the rest as three arrays (cut at a tile boundary where a read starts)
+        rid = t["read_id"]
+        cut = (n // 2) & ~511
+        while 0 < cut < n and rid[cut] == rid[cut - 1]:
+            cut += 512
+        if 0 < cut < n:
+            with ecb.EcBuilder(n_loci, n_haps) as b:
+                b.push_device_tiled(tiles[:cut // 512 * 1536], cut)
+                b.push_device(*[x[cut:] for x in d])
+                s = b.finalize()
+                _check(b.export(), s, exp)
+    with ecb.EcBuilder(10, 2, track_ranges=True) as b:          # the range update wants its fourth stream
+        with pytest.raises(ecb.EcbError) as e:
+            b.push_device_tiled(torch.zeros(1536, dtype=torch.int32, device=dev), 5)
+        assert e.value.code == -6
+    with ecb.EcBuilder(10, 2) as b:
+        with pytest.raises(ValueError):
+            b.push_device_tiled(torch.zeros(1536, dtype=torch.int32, device=dev), 600)      # two tiles' worth of records, one tile of buffer

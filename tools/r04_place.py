@@ -15,12 +15,17 @@ from alntools_amd import ecb  # noqa: E402
 
 
 def timed(b, rid, loc, hf, steps=3):
-    b.reset(); b.push_device(rid, loc, hf); b.finalize()
+    abl = bool(os.environ.get("ECB_ABLATE"))        # (profiling build with phases switched off: no ECs, nothing to finalize)
+
+    def fin():
+        if not abl:
+            b.finalize()
+    b.reset(); b.push_device(rid, loc, hf); fin()
     b.profile(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        b.reset(); b.push_device(rid, loc, hf); b.finalize()
+        b.reset(); b.push_device(rid, loc, hf); fin()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     ms, n, _ = b.profile_read()
