@@ -209,6 +209,40 @@ __device__ __forceinline__ SlotView make_view(uint4 a, uint4 b, uint4 c, uint4 d
     v.p[3] = make_uint2(d.x, d.y); v.p[4] = make_uint2(d.z, d.w);
     return v;
 }
+// The pairs of a key of at most RANKED_MAX pairs in ascending order of their loci: emit(rank, locus, mask) once per pair.  The key is held in
+// registers and ranked with every index a compile-time constant: pairs picked by a run-time index (`key_pair(s, arena, j)` on a copy of the
+// slot) put the copy in scratch memory and every step of the ranking behind a round trip to it -- k_emit_small 0.20 ms at C3 and 0.60 on the
+// paralog stream.  A pair that is not there holds locus 2^32 - 1: it ranks behind everything and is not emitted.
+constexpr u32 RANKED_MAX = 16;
+template <class F>
+__device__ __forceinline__ void ranked_pairs(const SlotView& v, const uint2* arena, F&& emit) {
+    const u32 sn = v.n;
+    u32 X[RANKED_MAX], Y[RANKED_MAX];
+#pragma unroll
+    for (u32 i = 0; i < INL; ++i) { X[i] = i < sn ? v.p[i].x : 0xFFFFFFFFu; Y[i] = v.p[i].y; }
+    if (sn <= INL) {
+#pragma unroll
+        for (u32 i = 0; i < INL; ++i) {
+            u32 r = 0;
+#pragma unroll
+            for (u32 j = 0; j < INL; ++j) r += X[j] < X[i] ? 1u : 0u;    // loci within a key are distinct
+            if (i < sn) emit(r, X[i], Y[i]);
+        }
+    } else {                                         // ... the rest of a longer key from the arena, all loads in flight together
+#pragma unroll
+        for (u32 k = 0; k < RANKED_MAX - INL; ++k) {
+            const uint2 t = INL + k < sn ? arena[(u64)v.off + k] : make_uint2(0xFFFFFFFFu, 0u);
+            X[INL + k] = t.x; Y[INL + k] = t.y;
+        }
+#pragma unroll
+        for (u32 i = 0; i < RANKED_MAX; ++i) {
+            u32 r = 0;
+#pragma unroll
+            for (u32 j = 0; j < RANKED_MAX; ++j) r += X[j] < X[i] ? 1u : 0u;
+            if (i < sn) emit(r, X[i], Y[i]);
+        }
+    }
+}
 template <class Cmp>
 __device__ __forceinline__ int table_lookup(Slot* table, u64 cap_mask, u64 lo, u64& j, u32& probes, const Cmp& cmp, u32 abl = 0u, u32* first_inv_seen = nullptr) {
     for (; probes < MAX_PROBE; ++probes, j = (j + 1) & cap_mask) {
@@ -1062,7 +1096,7 @@ __global__ __launch_bounds__(TPB) void k_parts_count(const Slot* table, const u3
 // count per part, reserve (one global atomic per part), then place.  Keys leave SORTED by locus (ranked like the CSR rows
 // of k_emit_*): two exported keys are then equal iff they are equal element by element, which is what k_merge tests first.
 // Keys of more than EXPORT_SMALL pairs are queued for k_parts_sort_big (one wave each).
-constexpr u32 EXPORT_SMALL = 16;
+constexpr u32 EXPORT_SMALL = RANKED_MAX;
 __global__ __launch_bounds__(TPB) void k_parts_export(const Slot* table, const u32* list, u64 n, const uint2* arena, u32 n_parts,
                                                       u64* cur, const u64* pair_base, Entry* out_e, uint2* out_p, u32 read_base,
                                                       u64* big, u32* n_big) {
@@ -1075,9 +1109,13 @@ __global__ __launch_bounds__(TPB) void k_parts_export(const Slot* table, const u
         __syncthreads();
         for (u64 eb = e0; eb < e1; eb += TPB) {
             const u64 e = eb + threadIdx.x;
-            Slot s{};
+            uint4 sa = make_uint4(0u, 0u, 1u, 0u), sb = sa, sc = sa, sd = sa;      // the slot's line (n1 = 1: an empty key)
             u32 q = MAX_PARTS, re = 0, rp = 0, sn = 0;
-            if (e < e1) { s = table[list[e]]; q = part_of(s.lo, n_parts); sn = s.n1 - 1u; }
+            if (e < e1) {
+                const uint4* sl = reinterpret_cast<const uint4*>(table + list[e]);
+                sa = sl[0]; sb = sl[1]; sc = sl[2]; sd = sl[3];
+                q = part_of(((u64)sa.y << 32) | sa.x, n_parts); sn = sa.z - 1u;
+            }
             for (u32 t = 0; t < n_parts; ++t) {      // rank within the workgroup: wave prefix + one LDS atomic per wave and part
                 const bool mine = q == t;
                 const u64 m = __ballot(mine);
@@ -1092,19 +1130,14 @@ __global__ __launch_bounds__(TPB) void k_parts_export(const Slot* table, const u
             if (pass == 1 && e < e1) {
                 const u64 po = bp[q] + rp;
                 if (sn <= EXPORT_SMALL) {
-                    for (u32 i = 0; i < sn; ++i) {
-                        const uint2 pi = key_pair(s, arena, i);
-                        u32 r = 0;
-                        for (u32 k = 0; k < sn; ++k) r += key_pair(s, arena, k).x < pi.x;   // loci within a key are distinct
-                        out_p[po + r] = pi;
-                    }
+                    ranked_pairs(make_view(sa, sb, sc, sd), arena, [&](u32 r, u32 x, u32 y) { out_p[po + r] = make_uint2(x, y); });
                 } else {
                     const u32 bi = atomicAdd(n_big, 1u);
                     big[2 * (u64)bi] = po; big[2 * (u64)bi + 1] = ((u64)list[e] << 32) | sn;
                 }
                 Entry en;
-                en.lo = s.lo; en.reserved = 0; en.count = s.count;
-                en.first_inv = ~(~s.first_inv + read_base);
+                en.lo = ((u64)sa.y << 32) | sa.x; en.reserved = 0; en.count = sb.x;
+                en.first_inv = ~(~sb.y + read_base);
                 en.off = (u32)(po - pair_base[q]); en.n = sn;
                 out_e[be[q] + re] = en;
             }
@@ -1266,9 +1299,30 @@ __global__ __launch_bounds__(TPB) void k_merge(const MergeDesc* D, Slot* table, 
 // ---------------------------------------------------------------------------------------------
 // finalize: rank by first appearance, CSR emit
 // ---------------------------------------------------------------------------------------------
-__global__ void k_popc(const u32* in, u64 n, u32* out) {
+// First-appearance ranks: rank of read f among the marked reads = marked reads before f's 64-byte line of the bitmap (an exclusive scan of the
+// lines' popcounts: 1/16 of the bitmap's words, a table that stays in L2) + the marked bits before f within its line.  (A prefix per 32-bit word
+// made every rank two reads of lines that are nowhere near each other -- the bitmap's and the prefix array's -- where this is one.)
+constexpr u32 BM_LINE = 16;                     // bitmap words per line; the bitmap is allocated in whole lines (bitmap_words)
+inline u64 bitmap_words(u64 n_bits) { return ((n_bits + 31) / 32 + BM_LINE) / BM_LINE * BM_LINE; }
+__global__ void k_popc(const u32* in, u64 n_lines, u32* out) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (i < n) out[i] = __popc(in[i]);
+    if (i >= n_lines) return;
+    const uint4* q = reinterpret_cast<const uint4*>(in + i * BM_LINE);
+    u32 c = 0;
+#pragma unroll
+    for (int k = 0; k < (int)BM_LINE / 4; ++k) { const uint4 v = q[k]; c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
+    out[i] = c;
+}
+__device__ __forceinline__ u32 bit_rank(const u32* bitmap, const u32* lprefix, u32 f) {
+    const uint4* q = reinterpret_cast<const uint4*>(bitmap + ((f >> 5) & ~(BM_LINE - 1u)));
+    const uint4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+    const u32 w[BM_LINE] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+    const u32 k = (f >> 5) & (BM_LINE - 1u), below = (1u << (f & 31u)) - 1u;
+    u32 r = lprefix[f >> 9];
+    static_assert(BM_LINE == 16, "f >> 9: 512 bits per line");
+#pragma unroll
+    for (u32 i = 0; i < BM_LINE; ++i) r += __popc(w[i] & (i < k ? 0xFFFFFFFFu : i == k ? below : 0u));
+    return r;
 }
 
 // Exclusive scan of u32, ONE pass over the data: a workgroup takes the next stretch of 16 384 values (a ticket: stretches start in
@@ -1373,7 +1427,7 @@ __global__ void k_rank(const u32* list, const uint2* list_fn, u64 n, u64 n_bits,
     const uint2 fn = list_fn[e];
     const u32 f = fn.x;
     if (f >= n_bits) return;                       // (an EC without a first read: finalize's count check reports it)
-    const u32 r = wprefix[f >> 5] + __popc(bitmap[f >> 5] & ((1u << (f & 31u)) - 1u));
+    const u32 r = bit_rank(bitmap, wprefix, f);
     if (r >= n) return;
     ord2[r] = make_uint2(si, fn.y);
 }
@@ -1387,27 +1441,45 @@ __global__ void k_slot_ranks(const u32* order, u64 n, u32* rank_of_slot) {
 // CSR rows: every (locus, mask) pair of an EC is ranked by locus and written in place (columns ascending, as scipy's
 // csc -> csr leaves them: bin_utils.py:211).  Short rows: one thread each.  Long rows: queued, one wave each.
 // The indices the host supplied are validated here, once per EC instead of once per record.
-constexpr u32 EMIT_SMALL = 16;
+constexpr u32 EMIT_SMALL = RANKED_MAX;
+// The rows of a wave's 64 ECs are one stretch of `indices` / `data`: the ranked pairs are laid out in LDS and leave in whole lines (a lane
+// storing its own row pair by pair wrote 4 bytes at a time, some twenty bytes apart from its neighbour's: three times the bytes in write
+// transactions).  A wave with a long row among its 64 (k_emit_big's) stores directly.
 __global__ __launch_bounds__(TPB) void k_emit_small(const Slot* table, const uint2* ord2, u32* order, u64 n, const uint2* arena,
                                                      const u32* indptr, int* indices, int* data, int* counts,
                                                      u32 n_loci, u32 n_haps, u32* big, u32* n_big, Counters* ctr) {
+    __shared__ u32 sx[TPB / 64][64 * EMIT_SMALL], sy[TPB / 64][64 * EMIT_SMALL];
     const u64 e = (u64)blockIdx.x * TPB + threadIdx.x;
-    if (e >= n) return;
-    const u32 si = ord2[e].x;
-    order[e] = si;
-    const Slot s = table[si];
-    const u32 sn = s.n1 - 1u;
-    counts[e] = (int)s.count;
-    if (sn > EMIT_SMALL) { big[atomicAdd(n_big, 1u)] = (u32)e; return; }
-    const u32 dst = indptr[e];
+    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const bool have = e < n;
+    const u64 hm = __ballot(have);
+    if (!hm) return;
+    uint4 a = make_uint4(0u, 0u, 1u, 0u), b = a, c = a, d = a;      // (n1 = 1: an empty key)
+    u32 dst = 0;
+    if (have) {
+        const u32 si = ord2[e].x;
+        order[e] = si;
+        const uint4* q = reinterpret_cast<const uint4*>(table + si);
+        a = q[0]; b = q[1]; c = q[2]; d = q[3];
+        counts[e] = (int)b.x;                       // Slot::count
+        dst = indptr[e];
+    }
+    const SlotView v = make_view(a, b, c, d);
+    const bool is_big = have && v.n > EMIT_SMALL;
+    if (is_big) big[atomicAdd(n_big, 1u)] = (u32)e;
+    const u32 base = (u32)__builtin_amdgcn_readfirstlane((int)dst);                                     // (lane 0 has an EC whenever any lane has)
+    const u32 end = (u32)__builtin_amdgcn_readlane((int)(dst + v.n), 63 - __builtin_clzll(hm));        // ... and the last one that has ends the stretch
+    const bool staged = __ballot(is_big) == 0ull && end - base <= 64u * EMIT_SMALL;
     bool bad = false;
-    for (u32 i = 0; i < sn; ++i) {
-        const uint2 pi = key_pair(s, arena, i);
-        u32 r = 0;
-        for (u32 j = 0; j < sn; ++j) r += key_pair(s, arena, j).x < pi.x;   // loci within a key are distinct
-        indices[dst + r] = (int)pi.x;
-        data[dst + r] = (int)pi.y;
-        bad |= pi.x >= n_loci || (pi.y >> n_haps) != 0u;
+    if (!is_big)
+        ranked_pairs(v, arena, [&](u32 r, u32 x, u32 y) {
+            if (staged) { const u32 at = min(dst - base + r, 64u * EMIT_SMALL - 1u); sx[w][at] = x; sy[w][at] = y; }     // (the bound: a broken row pointer must not reach beyond the stage)
+            else { indices[dst + r] = (int)x; data[dst + r] = (int)y; }
+            bad |= x >= n_loci || (y >> n_haps) != 0u;
+        });
+    if (staged) {
+        wave_sync();
+        for (u32 i = lane; i < end - base; i += 64u) { indices[base + i] = (int)sx[w][i]; data[base + i] = (int)sy[w][i]; }
     }
     if (bad) atomicOr(&ctr->err, ERR_RANGE);
 }
@@ -2945,7 +3017,7 @@ __global__ void k_piece_place(const PieceDesc* P, u64 n_total, u64 n_bits, const
     if (f >= n_bits) return;                             // (reported by k_mark_bits)
     const long long s0 = d.indptr[e], s1 = d.indptr[e + 1];
     if (s0 < 0 || s1 < s0 || (u64)s1 > d.nnz) { atomicOr(&ctr->err, ERR_CONTRACT); return; }
-    const u32 r = wprefix[f >> 5] + __popc(bitmap[f >> 5] & ((1u << (f & 31u)) - 1u));
+    const u32 r = bit_rank(bitmap, wprefix, f);
     if (r >= n_total) return;
     place[r] = make_uint4((u32)e + 1u, (u32)(s1 - s0), (u32)d.counts[e], blockIdx.y);    // (two pieces claiming one first read: either, whole; the caller reports it)
 }
@@ -3262,12 +3334,12 @@ int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
     // Everything below is queued on the stream; the host waits once, at the end, and checks what the device counted.
     // rank by first appearance: bitmap over read indices (marked while the table is compacted), popcount prefix
     const u64 total_reads = h->n_reads + h->extra_reads;
-    const u64 words = (total_reads + 31) / 32 + 1;
+    const u64 words = bitmap_words(total_reads), lines = words / BM_LINE;
     const u64 nnz_max = std::min<u64>(E * INL + arena_used(h), (1ull << 32) - 1);     // every key pair there can be
     u32 *bitmap = nullptr, *wpop = nullptr, *wprefix = nullptr, *ord2_raw = nullptr;
     uint2* list_fn = nullptr;
     u64* d_tot = nullptr;                            // [0] occupied slots, [1] distinct first reads, [2] nnz, [3] long rows (u32)
-    POOL(h, P_BITMAP, bitmap, words); POOL(h, P_WPOP, wpop, words); POOL(h, P_WPREFIX, wprefix, words);
+    POOL(h, P_BITMAP, bitmap, words); POOL(h, P_WPOP, wpop, lines); POOL(h, P_WPREFIX, wprefix, lines);
     POOL(h, P_ROWLEN, ord2_raw, 2 * E); POOL(h, P_LISTFN, list_fn, E);
     uint2* ord2 = reinterpret_cast<uint2*>(ord2_raw);           // (slot, row length) by rank
     POOL(h, P_ORDER, h->order, E);
@@ -3300,8 +3372,8 @@ int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
             if (rc != ECB_OK) return rc;
         }
     }
-    k_popc<<<nblk(words, TPB), TPB, 0, h->stream>>>(bitmap, words, wpop);
-    rc = excl_scan_dev(h, wpop, words, wprefix, d_tot + 1);
+    k_popc<<<nblk(lines, TPB), TPB, 0, h->stream>>>(bitmap, lines, wpop);
+    rc = excl_scan_dev(h, wpop, lines, wprefix, d_tot + 1);
     if (rc != ECB_OK) return rc;
     k_rank<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->list, list_fn, E, total_reads, bitmap, wprefix, ord2);
     rc = excl_scan_dev(h, ord2_raw + 1, E, h->indptr, d_tot + 2, 2);
@@ -3371,10 +3443,10 @@ int ecb_assemble_ranges_device(ecb_handle* h, uint32_t n_pieces, const void* con
     if (total_reads >= (1ull << 32) - 1) return fail(h, ECB_ERR_LIMIT, "more than 2^32-2 reads in total");
     HIPCHK(h, hipSetDevice(h->device));
     free_results(h);
-    const u64 words = (total_reads + 31) / 32 + 1;
+    const u64 words = bitmap_words(total_reads), lines = words / BM_LINE;
     u32 *bitmap = nullptr, *wpop = nullptr, *wprefix = nullptr, *place_raw = nullptr;
     u64* d_tot = nullptr;
-    POOL(h, P_BITMAP, bitmap, words); POOL(h, P_WPOP, wpop, words); POOL(h, P_WPREFIX, wprefix, words);
+    POOL(h, P_BITMAP, bitmap, words); POOL(h, P_WPOP, wpop, lines); POOL(h, P_WPREFIX, wprefix, lines);
     POOL(h, P_ROWLEN, place_raw, 4 * E);
     uint4* place = reinterpret_cast<uint4*>(place_raw);         // {EC within its piece + 1, row length, count, piece} by rank
     POOL(h, P_INDPTR, h->indptr, E + 1); POOL(h, P_COUNTS, h->counts, E);
@@ -3399,8 +3471,8 @@ int ecb_assemble_ranges_device(ecb_handle* h, uint32_t n_pieces, const void* con
     HIPCHK(h, hipMemcpyAsync(d_desc_raw, desc.data(), desc.size() * sizeof(PieceDesc), hipMemcpyHostToDevice, h->stream));
     const dim3 grid((unsigned)nblk(most, TPB), (unsigned)desc.size());
     k_mark_bits<<<grid, TPB, 0, h->stream>>>(d_desc, total_reads, bitmap, h->ctr);
-    k_popc<<<nblk(words, TPB), TPB, 0, h->stream>>>(bitmap, words, wpop);
-    rc = excl_scan_dev(h, wpop, words, wprefix, d_tot + 1);
+    k_popc<<<nblk(lines, TPB), TPB, 0, h->stream>>>(bitmap, lines, wpop);
+    rc = excl_scan_dev(h, wpop, lines, wprefix, d_tot + 1);
     if (rc != ECB_OK) return rc;
     k_piece_place<<<grid, TPB, 0, h->stream>>>(d_desc, E, total_reads, bitmap, wprefix, place, h->ctr);
     rc = excl_scan_dev(h, place_raw + 1, E, h->indptr, d_tot + 2, 4);

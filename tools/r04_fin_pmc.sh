@@ -10,10 +10,10 @@ run() { # name counters...
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "$RE" --output-format csv -d $RAW/$name -- python $R/bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $R/$OUT/$name.log 2>&1
   f=$(find $RAW/$name -name "*counter_collection.csv" | head -1)
   python - "$f" <<'PY'
-import csv, sys, collections
+import csv, re, sys, collections
 d = collections.defaultdict(float); n = collections.defaultdict(int)
 for r in csv.DictReader(open(sys.argv[1])):
-    k = (r.get('Kernel_Name', '').split('(')[0], r['Counter_Name'])
+    m = re.search(r'k_\w+', r.get('Kernel_Name', '')); k = (m.group(0) if m else '?', r['Counter_Name'])
     d[k] += float(r['Counter_Value']); n[k] += 1
 for k in sorted(d): print("%-26s %-24s %16.0f  (per dispatch, %d)" % (k[0][:26], k[1], d[k] / max(n[k], 1), n[k]))
 PY
