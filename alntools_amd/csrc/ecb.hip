@@ -485,7 +485,8 @@ __global__ __launch_bounds__(1024) void k_sum_counts(const u32* wave_counts, u64
 // ---------------------------------------------------------------------------------------------
 constexpr u32 BIN_BITS = 14;                   // slots per range = LDS bins of one k_count_bins workgroup: 2^14 (64 KB of LDS, two workgroups per CU;
                                                // 2^13 made the partition's runs half as long: +0.08 ms at C3) up to a table of 2^27 slots,
-constexpr u32 MAX_BIN_BITS = 15;               // 2^15 (128 KB) beyond -- a run-time argument `bb`
+constexpr u32 MAX_BIN_BITS = 15;               // 2^15 (128 KB) beyond -- a run-time argument `bb`, chosen per stream (ensure_counts)
+constexpr u32 MIN_BIN_BITS = 11;
 constexpr u32 MAX_BUCKETS = 8192;
 static_assert(MAX_BIN_BITS <= 16, "a slot's index within its range is kept in 16 bits (k_part_scatter*, k_count_bins)");              // LDS histogram of the partition passes  (=> at most 2^28 slots)
 
@@ -609,14 +610,9 @@ constexpr int TPB_COUNT = 1024;
 // far above the average into pieces.  One piece = one workgroup; the pieces of a cut range add into the slots with
 // atomics, whole ranges are the only writer of their slots and just store.
 struct CountWork { u32 bucket, start, end, shared; };
-__global__ void k_bucket_starts(const u32* offs, u32 G, u32 n_buckets, const u64* total, u32* starts) {
-    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < n_buckets) starts[b] = offs[(u64)b * G];
-    if (b == n_buckets) starts[b] = (u32)*total;
-}
 // The work list is built on the device (one workgroup: a few thousand ranges), so that nothing between the stream kernel and
 // the CSR waits for the host.  work[0 .. *n_work): whole ranges, or pieces of `piece` elements of a range far above the average.
-__global__ __launch_bounds__(1024) void k_build_work(const u32* starts, u32 n_buckets, u32 piece, CountWork* work, u32 max_work, u32* n_work) {
+__global__ __launch_bounds__(1024) void k_build_work(const u32* offs, u32 G, const u64* total, u32 n_buckets, u32 piece, CountWork* work, u32 max_work, u32* n_work) {
     __shared__ u32 s_w[16];
     __shared__ u32 s_carry;
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
@@ -625,7 +621,7 @@ __global__ __launch_bounds__(1024) void k_build_work(const u32* starts, u32 n_bu
     for (u32 b0 = 0; b0 < n_buckets; b0 += 1024) {
         const u32 b = b0 + tid;
         u32 s0 = 0, s1 = 0, np = 0;
-        if (b < n_buckets) { s0 = starts[b]; s1 = starts[b + 1]; }
+        if (b < n_buckets) { s0 = offs[(u64)b * G]; s1 = b + 1 < n_buckets ? offs[(u64)(b + 1) * G] : (u32)*total; }      // (a range starts where its first workgroup's elements do)
         const u32 len = s1 - s0;
         const bool cut = len > piece + piece / 2;
         if (len) np = cut ? (len + piece - 1) / piece : 1u;
@@ -658,7 +654,7 @@ __global__ __launch_bounds__(TPB_COUNT) void k_count_bins(const u16* pairs, cons
     auto add = [&](u32 bin, bool have) {
         const u64 hm = __ballot(have);
         if (!hm) return;
-        const u32 v = __shfl(bin, __ffsll((long long)hm) - 1);
+        const u32 v = (u32)__builtin_amdgcn_readlane((int)bin, __ffsll((long long)hm) - 1);      // (the lane index is wave-uniform: a VALU readlane, not __shfl's trip through the LDS crossbar)
         const bool same = have && bin == v;
         const u64 m = __ballot(same);
         if (__popcll(m) >= 8) {
@@ -1336,7 +1332,7 @@ constexpr int SCB_TPB = 1024, SCB_ITEMS = 16, SCB = SCB_TPB * SCB_ITEMS;
 constexpr u64 SC_AGG = 1ull << 62, SC_PFX = 2ull << 62, SC_VAL = (1ull << 62) - 1ull;
 inline u64 scan_blocks(u64 n) { return std::max<u64>(1, (n + SCB - 1) / SCB); }
 inline u64 scan_words(u64 n) { return 2 * (scan_blocks(n) + 2); }             // u32 words of scratch a scan of n values needs
-__global__ __launch_bounds__(SCB_TPB) void k_scan_lb(const u32* in, u64 n, u32* out, u64* st, u64 nb, u64* d_total, u32 stride) {
+__global__ __launch_bounds__(SCB_TPB) void k_scan_lb(const u32* in, u64 n, u32* out, u64* st, u64 nb, u64* d_total, u32 stride, u32* last32) {
     __shared__ u64 s_b, s_excl;
     __shared__ u32 s_w[SCB_TPB / 64];
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
@@ -1391,7 +1387,11 @@ __global__ __launch_bounds__(SCB_TPB) void k_scan_lb(const u32* in, u64 n, u32* 
             }
             if (lane == 0) __hip_atomic_store(&st[b], SC_PFX | ((excl + tot) & SC_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (lane == 0) { s_excl = excl; if (b + 1 == nb && d_total) *d_total = excl + tot; }
+        if (lane == 0) {
+            s_excl = excl;
+            if (b + 1 == nb && d_total) *d_total = excl + tot;
+            if (b + 1 == nb && last32) *last32 = (u32)(excl + tot);      // (a row-pointer array's last element: the total, where its scan ends)
+        }
     }
     __syncthreads();
     u32 run = (u32)s_excl + before + incl - s;
@@ -1408,12 +1408,12 @@ __global__ __launch_bounds__(SCB_TPB) void k_scan_lb(const u32* in, u64 n, u32* 
     }
 }
 // queue a scan on `st`: scratch = scan_words(n) u32 words (8-byte aligned); the total (64 bits) lands in *d_total (may be null)
-inline hipError_t scan_launch(hipStream_t st, const u32* in, u64 n, u32* out, u32* scratch, u64* d_total, u32 stride = 1) {
+inline hipError_t scan_launch(hipStream_t st, const u32* in, u64 n, u32* out, u32* scratch, u64* d_total, u32 stride = 1, u32* last32 = nullptr) {
     const u64 nb = scan_blocks(n);
     u64* words = reinterpret_cast<u64*>(scratch);
-    hipError_t e = hipMemsetAsync(words, 0, (nb + 1) * 8, st);
+    hipError_t e = hipMemsetAsync(words, 0, ((nb + 1) * 8 + 15) & ~15ull, st);      // (nb + 1 words; in whole 16 bytes -- scan_words has the room --: the runtime fills a ragged end with a kernel of its own)
     if (e != hipSuccess) return e;
-    k_scan_lb<<<(unsigned)nb, SCB_TPB, 0, st>>>(in, n, out, words, nb, d_total, stride);
+    k_scan_lb<<<(unsigned)nb, SCB_TPB, 0, st>>>(in, n, out, words, nb, d_total, stride, last32);
     return hipGetLastError();
 }
 
@@ -1504,7 +1504,6 @@ __global__ __launch_bounds__(TPB) void k_emit_big(const Slot* table, const u32* 
     }
     if (bad) atomicOr(&ctr->err, ERR_RANGE);
 }
-__global__ void k_set_last(u32* dst, const u64* v) { *dst = (u32)*v; }
 
 // multisample: sort key = EC rank << 32 | (cell, file) of every read, the cell ABOVE the file: the triples come out in the order
 // (EC, cell, file), in which the files of one (EC, cell) pair -- one entry of N -- follow each other
@@ -2784,10 +2783,10 @@ void free_results(ecb_handle* h) {   // result buffers live in the pool: nothing
 
 // exclusive scan of u32 values, queued on the handle's stream; the sum (64 bits) is left in *d_total on the device
 // (a sum of 2^32 or more: the caller's limit check, `out` wrapped)
-int excl_scan_dev(ecb_handle* h, const u32* in, u64 n, u32* out, u64* d_total, u32 stride = 1) {
+int excl_scan_dev(ecb_handle* h, const u32* in, u64 n, u32* out, u64* d_total, u32 stride = 1, u32* last32 = nullptr) {
     u32* sums = nullptr;
     POOL(h, P_SUMS, sums, scan_words(n));
-    HIPCHK(h, scan_launch(h->stream, in, n, out, sums, d_total, stride));
+    HIPCHK(h, scan_launch(h->stream, in, n, out, sums, d_total, stride, last32));
     return ECB_OK;
 }
 // ... and with the sum brought to the host (one wait)
@@ -2880,8 +2879,18 @@ int ensure_counts(ecb_handle* h, const CompactSink* sink = nullptr) {
         sink = &own;
     }
     if (R) {
+        // Slots per range: 512 ranges -- one k_count_bins workgroup for each of the chip's 512 places, all at once -- unless that takes more than 2^14 slots
+        // each (64 KB of LDS counters: two workgroups per CU; 2^15 leaves room for one).  C3: 1 024 ranges of 2^14; C2: 512 of 2^13; the diploid stream
+        // 512 of 2^13.  Fewer, fuller ranges leave CUs without a workgroup (C2 with 256 ranges: k_count_bins 0.19 ms against 0.13); more ranges make the
+        // partition's runs shorter (k_part_scatter_staged at C3 with 2 048: 0.38 ms against 0.26; on the diploid stream with 2 048: 0.71 against 0.49 with 1 024)
+        // -- profiles/r04_finalize_kernels.txt.
         u32 bb = BIN_BITS;
-        if (const char* e = getenv("ECB_BIN_BITS")) bb = (u32)std::min<long>(std::max<long>(atol(e), 13), MAX_BIN_BITS);   // (measurement knob: tools/tools_env.sh)
+        {
+            u32 lc = 0;
+            while ((1ull << (lc + 1)) <= h->cap) ++lc;   // the table holds 2^lc slots
+            bb = std::min<u32>(std::max<u32>(lc, 9u + MIN_BIN_BITS) - 9u, BIN_BITS);
+        }
+        if (const char* e = getenv("ECB_BIN_BITS")) bb = (u32)std::min<long>(std::max<long>(atol(e), MIN_BIN_BITS), MAX_BIN_BITS);   // (measurement knob: tools/tools_env.sh)
         while (bb < MAX_BIN_BITS && (h->cap >> bb) > MAX_BUCKETS) ++bb;
         const u32 nb = (u32)std::max<u64>(1, h->cap >> bb);
         if (nb > MAX_BUCKETS) return fail(h, ECB_ERR_LIMIT, "EC table larger than 2^28 slots is not supported");
@@ -2910,15 +2919,12 @@ int ensure_counts(ecb_handle* h, const CompactSink* sink = nullptr) {
         } else                                     // (tables beyond 2^25 slots: the counters would crowd the stage out of LDS)
             k_part_scatter<<<G, TPB_PART, nb * 4, h->stream>>>(h->read_slot, R, nb, bb, offs, pairs);
         // work list of k_count_bins: ranges far above the average are cut into pieces (see CountWork)
-        u32* d_starts = nullptr;
-        POOL(h, P_STARTS, d_starts, (u64)nb + 1);
-        k_bucket_starts<<<nblk((u64)nb + 1, TPB), TPB, 0, h->stream>>>(offs, G, nb, d_tot, d_starts);
         const u32 piece = std::max<u32>(32768u, 2u * (u32)((R + nb - 1) / nb));
         const u32 max_work = nb + (u32)(R / piece) + 1;
         CountWork* d_work = nullptr;
         POOL(h, P_WORK, d_work, (u64)max_work + 1);          // (+ 1: its length sits behind the list)
         u32* d_nwork = reinterpret_cast<u32*>(d_work + max_work);
-        k_build_work<<<1, 1024, 0, h->stream>>>(d_starts, nb, piece, d_work, max_work, d_nwork);
+        k_build_work<<<1, 1024, 0, h->stream>>>(offs, G, d_tot, nb, piece, d_work, max_work, d_nwork);
         k_count_bins<<<max_work, TPB_COUNT, 4u << bb, h->stream>>>(pairs, d_work, d_nwork, bb, h->table, sink ? *sink : CompactSink{nullptr, 0, nullptr, nullptr, 0, nullptr});
         if (sink == &own) { h->list_counted = true; h->d_list_n = own.n_list; }
         else if (sink) h->list_from_counts = true;
@@ -3376,9 +3382,8 @@ int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
     rc = excl_scan_dev(h, wpop, lines, wprefix, d_tot + 1);
     if (rc != ECB_OK) return rc;
     k_rank<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->list, list_fn, E, total_reads, bitmap, wprefix, ord2);
-    rc = excl_scan_dev(h, ord2_raw + 1, E, h->indptr, d_tot + 2, 2);
+    rc = excl_scan_dev(h, ord2_raw + 1, E, h->indptr, d_tot + 2, 2, h->indptr + E);
     if (rc != ECB_OK) return rc;
-    k_set_last<<<1, 1, 0, h->stream>>>(h->indptr + E, d_tot + 2);
     k_emit_small<<<nblk(E, TPB), TPB, 0, h->stream>>>(h->table, ord2, h->order, E, h->arena, h->indptr, h->indices, h->data,
                                                        h->counts, h->cfg.n_loci, h->cfg.n_haplotypes, big, d_nbig, h->ctr);
     // long rows, one wave each: a fixed launch that walks the queue (its length stays on the device)
@@ -3475,9 +3480,8 @@ int ecb_assemble_ranges_device(ecb_handle* h, uint32_t n_pieces, const void* con
     rc = excl_scan_dev(h, wpop, lines, wprefix, d_tot + 1);
     if (rc != ECB_OK) return rc;
     k_piece_place<<<grid, TPB, 0, h->stream>>>(d_desc, E, total_reads, bitmap, wprefix, place, h->ctr);
-    rc = excl_scan_dev(h, place_raw + 1, E, h->indptr, d_tot + 2, 4);
+    rc = excl_scan_dev(h, place_raw + 1, E, h->indptr, d_tot + 2, 4, h->indptr + E);
     if (rc != ECB_OK) return rc;
-    k_set_last<<<1, 1, 0, h->stream>>>(h->indptr + E, d_tot + 2);
     k_piece_rows<<<nblk(E, TPB), TPB, 0, h->stream>>>(d_desc, (u32)desc.size(), place, E, h->indptr, h->indices, h->data, h->counts);
     u64 tot[8];
     HIPCHK(h, hipMemcpyAsync(tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, h->stream));

@@ -1309,3 +1309,34 @@ def test_tuples_pushed_as_whole_tiles_equal_tuples_pushed_as_three_arrays():
     with ecb.EcBuilder(10, 2) as b:
         with pytest.raises(ValueError):
             b.push_device_tiled(torch.zeros(1536, dtype=torch.int32, device=dev), 600)      # two tiles' worth of records, one tile of buffer
+
+
+def test_counts_survive_a_second_finalize_and_a_table_export_after_the_first():
+    """What finalize leaves in the table -- every EC's reads, first read and key -- is what a second finalize and a table export
+    after the first read again: both must give what the first gave.  Reference: N = reads per EC, ``bam_utils.py:309-312``."""
+    import torch
+    from alntools_amd import dist as ecdist
+    dev = torch.device("cuda:0")
+    spec = synth.SynthSpec(n_reads=60000, n_loci=3000, n_haps=8, paired=True)
+    t = synth.generate(spec, 0, spec.n_reads, device=dev)
+    exp = _expect(synth.generate(spec, 0, spec.n_reads), spec.n_loci, spec.n_haps)
+    with ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=1 << 12) as b, ecb.EcBuilder(spec.n_loci, spec.n_haps, ec_capacity=1 << 12) as plain:
+        b.push_device(t["read_id"], t["locus"], t["hapflag"])
+        plain.push_device(t["read_id"], t["locus"], t["hapflag"])
+        s1 = b.finalize()
+        first = b.export()
+        _check(first, s1, exp)
+        s2 = b.finalize()                                        # again: everything is derived from the table once more
+        again = b.export()
+        assert s1 == s2
+        for k in first:
+            assert np.array_equal(first[k], again[k]), k
+        # the table of the finalized handle, exported: the same entries (hash, reads, first read, key length) as a handle that was never finalized
+        ent, _ = ecdist.GpuEngine(b, dev).table_export(0)
+        ent0, _ = ecdist.GpuEngine(plain, dev).table_export(0)
+        ne = b.table_sizes()[0]
+        assert ne == plain.table_sizes()[0] == s1["n_ecs"]
+        e, e0 = ent[:ne * 4].view(-1, 4).cpu().numpy(), ent0[:ne * 4].view(-1, 4).cpu().numpy()
+        e, e0 = e[np.argsort(e[:, 0], kind="stable")], e0[np.argsort(e0[:, 0], kind="stable")]
+        assert np.array_equal(e[:, 0], e0[:, 0]) and np.array_equal(e[:, 2], e0[:, 2]) and np.array_equal(e[:, 3] >> 32, e0[:, 3] >> 32)
+        assert int((e[:, 2] & 0xFFFFFFFF).sum()) == s1["n_reads"]
