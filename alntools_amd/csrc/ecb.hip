@@ -2327,6 +2327,8 @@ struct ecb_handle {
     Counters* ctr = nullptr;
     Counters hctr{};                  // last read-back
     Counters* pin_ctr = nullptr;      // pinned staging for clear_counters
+    struct PinOut { Counters c; u64 tot[8]; };
+    PinOut* pin_out = nullptr;        // ... and where the device's counters and finalize's totals land (a copy into pageable memory is staged by the runtime, behind a wait of its own)
     StreamCold *d_cold = nullptr, *pin_cold = nullptr;   // k_stream's rarely used arguments (device copy, pinned staging)
     u32* read_slot = nullptr; u64 read_slot_cap = 0;
     u32* meta = nullptr; u64 meta_cap = 0, meta_hi = 0;   // multisample: cell | file << 22 per read
@@ -2432,8 +2434,9 @@ u64 arena_used(const ecb_handle* h) {
 }
 
 int sync_counters(ecb_handle* h) {
-    HIPCHK(h, hipMemcpyAsync(&h->hctr, h->ctr, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&h->pin_out->c, h->ctr, sizeof(Counters), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->hctr = h->pin_out->c;
     h->ctr_synced = true;
     if (h->hctr.err & ERR_CONTRACT) return fail(h, ECB_ERR_CONTRACT, "read_id run counter violates the tuple contract (see ecb.h)");
     if (h->hctr.err & ERR_RANGE) return fail(h, ECB_ERR_CONTRACT, "locus or haplotype index out of range in a valid record");
@@ -3087,6 +3090,7 @@ int ecb_create(const ecb_config* cfg, ecb_handle** out) {
     if ((e = hipMalloc(&h->ctr, sizeof(Counters))) != hipSuccess) return bail(ECB_ERR_HIP, "hipMalloc(counters)", e);
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->pin_ctr), sizeof(Counters), hipHostMallocDefault)) != hipSuccess) return bail(ECB_ERR_HIP, "hipHostMalloc", e);
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->pin_cold), sizeof(StreamCold), hipHostMallocDefault)) != hipSuccess) return bail(ECB_ERR_HIP, "hipHostMalloc", e);
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->pin_out), sizeof(ecb_handle::PinOut), hipHostMallocDefault)) != hipSuccess) return bail(ECB_ERR_HIP, "hipHostMalloc", e);
     if ((e = hipMalloc(&h->d_cold, sizeof(StreamCold))) != hipSuccess) return bail(ECB_ERR_HIP, "hipMalloc(args)", e);
     hipMemsetAsync(h->table, 0, h->cap * sizeof(Slot), h->stream);
     hipMemsetAsync(h->arena, 0, h->arena_cap * sizeof(uint2), h->stream);     // stale arena bytes must never look like a key (see ecb_reset)
@@ -3110,6 +3114,7 @@ void ecb_destroy(ecb_handle* h) {
     hipFree(h->table); hipFree(h->arena); hipFree(h->ctr); hipFree(h->read_slot); hipFree(h->meta);
     hipFree(h->rng); hipFree(h->queue); hipFree(h->wave_arena);
     if (h->pin_ctr) hipHostFree(h->pin_ctr);
+    if (h->pin_out) hipHostFree(h->pin_out);
     if (h->pin_cold) hipHostFree(h->pin_cold);
     hipFree(h->d_cold);
     for (int i = 0; i < ecb_handle::P_N; ++i) hipFree(h->pool[i]);
@@ -3389,8 +3394,8 @@ int ecb_finalize(ecb_handle* h, ecb_sizes* out) {
     // long rows, one wave each: a fixed launch that walks the queue (its length stays on the device)
     k_emit_big<<<(unsigned)std::min<u64>(nblk(E * 64, TPB), 2048), TPB, 0, h->stream>>>(h->table, h->order, big, d_nbig, h->arena, h->indptr,
                                                                                        h->indices, h->data, h->cfg.n_loci, h->cfg.n_haplotypes, h->ctr);
-    u64 tot[4] = {0, 0, 0, 0};
-    HIPCHK(h, hipMemcpyAsync(tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, h->stream));
+    u64* const tot = h->pin_out->tot;
+    HIPCHK(h, hipMemcpyAsync(tot, d_tot, 4 * sizeof(u64), hipMemcpyDeviceToHost, h->stream));
     rc = sync_counters(h);                           // the one wait
     if (rc != ECB_OK) return rc;
     h->n_list = tot[0];
