@@ -1916,6 +1916,12 @@ __global__ void k_split_minmax(const int2* rng, u64 n, int* mn, int* mx) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i < n) { const int2 r = rng[i]; mn[i] = r.x; mx[i] = r.y; }
 }
+// the used stretches of the key arena, back to zero (ecb_reset): blockIdx.y = stretch
+struct ArenaClear { u64 start[ARENA_REGIONS + 1], len[ARENA_REGIONS + 1]; };
+__global__ void k_clear_arena(uint2* arena, ArenaClear A) {
+    const u64 s = A.start[blockIdx.y], n = A.len[blockIdx.y];
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) arena[s + i] = make_uint2(0u, 0u);
+}
 __global__ void k_clear_slots(Slot* table, const u32* list, u64 n) {
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -3146,14 +3152,22 @@ int ecb_reset(ecb_handle* h) {
     // The used stretches of the key arena go back to zero: a key pair is only ever compared against bytes that are either
     // zero (no haplotype mask: never equal to a pair) or final, whatever a cache still holds of them.
     if (!h->ctr_synced) sync_counters(h);               // (the cursors; an error the run already reported is not this call's)
-    {
+    {   // (one launch for all of them: a fill per region was 64 dispatches of ~5 us on a stream with long keys -- the paralog stream's reset 0.3 ms)
         const u32 R = arena_regions(h->arena_cap);
         const u64 per = h->arena_cap / R;
+        ArenaClear ac{};
+        u32 n = 0;
+        u64 longest = 0;
         for (u32 r = 0; r < R; ++r) {
             const u64 used = std::min<u64>(h->hctr.arena_reg[r], (u64)(r + 1) * per) - r * per;
-            if (used) HIPCHK(h, hipMemsetAsync(h->arena + r * per, 0, used * sizeof(uint2), h->stream));
+            if (used) { ac.start[n] = r * per; ac.len[n] = used; ++n; longest = std::max(longest, used); }
         }
-        if (h->hctr.arena_top) HIPCHK(h, hipMemsetAsync(h->arena, 0, std::min<u64>(h->hctr.arena_top, h->arena_cap) * sizeof(uint2), h->stream));
+        if (h->hctr.arena_top) { ac.start[n] = 0; ac.len[n] = std::min<u64>(h->hctr.arena_top, h->arena_cap); longest = std::max(longest, ac.len[n]); ++n; }
+        if (n) {
+            const dim3 grid((unsigned)std::min<u64>(nblk(longest, TPB), 2048), n);
+            k_clear_arena<<<grid, TPB, 0, h->stream>>>(h->arena, ac);
+            HIPCHK(h, hipGetLastError());
+        }
     }
 #if defined(ECB_TIMING) || defined(ECB_EXPERIMENTS)     // experiment builds only (tools/exp_hits.py: a pass over a table that holds every EC already)
     if (!getenv("ECB_KEEP_TABLE"))

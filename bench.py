@@ -738,6 +738,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "step_achieved": step_achieved, "step_frac": step_achieved / HBM_PEAK_GBS,
                          "step_algorithmic_bytes": step_bytes,
+                         "step_ms_besides_kernel": ms_per_step - k_ms_per_launch * launches_per_step,      # (partition-and-count, ranking, CSR emit, reset, host waits)
                          "peak_measured_copy": peak_copy, "peak_measured_read": peak_read, "peak_measured_how": peak_how,
                          "frac_of_measured_copy": (achieved / peak_copy) if peak_copy else None},
         }
