@@ -1340,3 +1340,38 @@ def test_counts_survive_a_second_finalize_and_a_table_export_after_the_first():
         e, e0 = e[np.argsort(e[:, 0], kind="stable")], e0[np.argsort(e0[:, 0], kind="stable")]
         assert np.array_equal(e[:, 0], e0[:, 0]) and np.array_equal(e[:, 2], e0[:, 2]) and np.array_equal(e[:, 3] >> 32, e0[:, 3] >> 32)
         assert int((e[:, 2] & 0xFFFFFFFF).sum()) == s1["n_reads"]
+
+
+@pytest.mark.parametrize("ec_capacity", [1 << 10, 1 << 14, 1 << 21])
+def test_rows_of_every_length_leave_in_column_order(ec_capacity):
+    """ECs of 1 .. 24 loci side by side, loci in descending order in the stream: rows short enough for the slot's own pairs, rows that
+    continue in the key arena, and rows of more than sixteen (one wave each) meet in the same waves of the CSR emit, and every one of
+    them must leave with its columns ascending (scipy's csc -> csr, ``bin_utils.py:211``).  The table sizes put the counting
+    partition at one range, at a few, and at 512 (ensure_counts); first reads sit on both sides of every 512-read boundary of the
+    first-appearance bitmap."""
+    T, H = 200000, 8
+    rng = np.random.default_rng(1234)
+    n_ecs = 3000
+    recs = []
+    rid = 0
+    for k in range(n_ecs):
+        n = k % 24 + 1
+        base = (k * 37) % (T - 64 * 24)
+        loci = (base + np.arange(n) * (1 + k % 5))[::-1]
+        haps = rng.integers(0, H, size=n)
+        recs += [(rid, int(l), int(h), 0) for l, h in zip(loci, haps)]
+        if n > 3:
+            recs.append((rid, int(loci[0]), int(haps[0]), 0))                    # a duplicate (read, target): collapses
+        rid += 1
+    first_lap = list(recs)
+    for (r, l, h, f) in first_lap[: len(first_lap) // 2]:        # the first half of the ECs once more, as new reads
+        recs.append((rid + r, l, h, f))
+    t = _hand(recs, H)
+    out, sizes = _run_host(t, T, H, ec_capacity=ec_capacity)
+    exp = _expect(t, T, H)
+    _check(out, sizes, exp)
+    assert sizes["n_ecs"] == len(exp["count"]) and int(out["dataN"].max()) == 2
+    rows = np.diff(out["indptrA"])
+    assert rows.max() == 24 and rows.min() == 1
+    for a, b in zip(out["indptrA"][:-1], out["indptrA"][1:]):
+        assert np.all(np.diff(out["indicesA"][a:b]) > 0)
