@@ -806,16 +806,17 @@ __device__ __forceinline__ u64 slow_probe_start(u32 lc, u64 cap2) { return __umu
 // The read's {locus -> mask} table (2 slots per record) sits in LDS when it fits SLOW_LDS slots (reads of up to 2 048 records:
 // all but the pathological ones), in the global scratch otherwise: its compare-and-swaps are what a long read costs.
 constexpr u32 SLOW_LDS = 4096;
-__global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
-    extern __shared__ u32 sh_scr[];                // SLOW_LDS keys, SLOW_LDS masks
-    const u64 q = blockIdx.x;
+// (IN_LDS is a template argument, not a pointer picked at run time: with one pointer for both homes every access to the read's table was a FLAT
+//  instruction with agent-scope ordering -- compare-and-swaps, ORs and "atomic" loads on what is, for all but pathological reads, this workgroup's
+//  own LDS.  profiles/r04_long_reads.txt)
+template <bool IN_LDS> __device__ __forceinline__ u32 slow_ld(const u32* p) {
+    if constexpr (IN_LDS) return *p; else return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool IN_LDS>
+__device__ __forceinline__ void slow_body(const SlowArgs& A, u32* key, u32* msk, const u64 q, const u64 h, const u64 L) {
     const u32 tid = threadIdx.x, lane = tid & 63u;
-    const u64 h = A.queue[q], L = A.len[q];
     const u64 cap2 = 2 * L;
-    const bool in_lds = cap2 <= (u64)SLOW_LDS;
-    u32* key = in_lds ? sh_scr : A.scr_key + A.scr_off[q];
-    u32* msk = in_lds ? sh_scr + SLOW_LDS : A.scr_mask + A.scr_off[q];
-    if (in_lds) {
+    if (IN_LDS) {
         for (u32 p = tid; p < (u32)cap2; p += TPB) { key[p] = 0; msk[p] = 0; }
         __syncthreads();
     }
@@ -836,14 +837,14 @@ __global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
             if (++p == cap2) p = 0;
         }
     }
-    __threadfence();
+    if (!IN_LDS) __threadfence();
     __syncthreads();
     u64 a0 = 0;
     u32 np = 0;
     for (u64 p = tid; p < cap2; p += TPB) {
-        const u32 k = __hip_atomic_load(&key[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u32 k = slow_ld<IN_LDS>(&key[p]);
         if (k) {
-            const u32 m = __hip_atomic_load(&msk[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u32 m = slow_ld<IN_LDS>(&msk[p]);
             ++np;
             a0 += pair_hash64(k - 1u, m);                   // same set hash as k_stream
         }
@@ -892,8 +893,8 @@ __global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
                 if (pr.x < A.n_loci) {
                     u64 p = slow_probe_start(pr.x, cap2);
                     for (u64 t = 0; t < cap2; ++t) {
-                        const u32 k = __hip_atomic_load(&key[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (k == pr.x + 1u) { diff = __hip_atomic_load(&msk[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr.y; break; }
+                        const u32 k = slow_ld<IN_LDS>(&key[p]);
+                        if (k == pr.x + 1u) { diff = slow_ld<IN_LDS>(&msk[p]) != pr.y; break; }
                         if (k == 0u) break;
                         if (++p == cap2) p = 0;
                     }
@@ -951,9 +952,9 @@ __global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
             Slot* sl = A.table + s_j;
             const bool dead = s_n1 == DEAD_KEY;
             if (!dead) for (u64 p = tid; p < cap2; p += TPB) {
-                const u32 k = __hip_atomic_load(&key[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const u32 k = slow_ld<IN_LDS>(&key[p]);
                 if (k) {
-                    const u32 m = __hip_atomic_load(&msk[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const u32 m = slow_ld<IN_LDS>(&msk[p]);
                     const u32 pos = atomicAdd(&s_cnt, 1u);
                     uint2* dst = pos < INL ? &sl->pair[pos] : A.arena + ((u64)s_off + (pos - INL));
                     store_wt64(reinterpret_cast<u64*>(dst), pack2(make_uint2(k - 1u, m)));
@@ -967,9 +968,16 @@ __global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
         }
     }
     __syncthreads();
-    if (!in_lds) for (u64 p = tid; p < cap2; p += TPB) {    // leave the global scratch zeroed for the next round
-        if (__hip_atomic_load(&key[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { key[p] = 0; msk[p] = 0; }
+    if (!IN_LDS) for (u64 p = tid; p < cap2; p += TPB) {    // leave the global scratch zeroed for the next round
+        if (slow_ld<IN_LDS>(&key[p])) { key[p] = 0; msk[p] = 0; }
     }
+}
+__global__ __launch_bounds__(TPB) void k_slow(SlowArgs A) {
+    extern __shared__ u32 sh_scr[];                // SLOW_LDS keys, SLOW_LDS masks
+    const u64 q = blockIdx.x;
+    const u64 h = A.queue[q], L = A.len[q];
+    if (2 * L <= (u64)SLOW_LDS) slow_body<true>(A, sh_scr, sh_scr + SLOW_LDS, q, h, L);
+    else slow_body<false>(A, A.scr_key + A.scr_off[q], A.scr_mask + A.scr_off[q], q, h, L);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1483,24 +1491,43 @@ __global__ __launch_bounds__(TPB) void k_emit_small(const Slot* table, const uin
     }
     if (bad) atomicOr(&ctr->err, ERR_RANGE);
 }
+// (A long row's loci are ranked out of LDS -- the wave's copy of them, read four at a time, every lane the same address -- where a rank used to be
+//  a walk over the key in global memory per pair: 700 x 700 loads for a read of 700 loci, 6 ms for the 39 k long ECs of tools/slow_path.py.)
+constexpr u32 BIG_LDS = 2048;                   // loci of a row ranked out of LDS: 8 KB per wave; longer rows walk the key in memory as before
 __global__ __launch_bounds__(TPB) void k_emit_big(const Slot* table, const u32* order, const u32* big, const u32* n_big,
                                                    const uint2* arena, const u32* indptr, int* indices, int* data,
                                                    u32 n_loci, u32 n_haps, Counters* ctr) {
-    const u32 lane = threadIdx.x & 63u, nb = *n_big;
+    __shared__ __attribute__((aligned(16))) u32 sx[TPB / 64][BIG_LDS];
+    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6, nb = *n_big;
     bool bad = false;
     for (u32 b = (blockIdx.x * TPB + threadIdx.x) >> 6; b < nb; b += (gridDim.x * TPB) >> 6) {
         const u32 e = big[b];
         const Slot& s = table[order[e]];
         const u32 sn = s.n1 - 1u;
         const u32 dst = indptr[e];
+        const bool in_lds = sn <= BIG_LDS;
+        if (in_lds) {
+            for (u32 i = lane; i < sn; i += 64) sx[w][i] = key_pair(s, arena, i).x;
+            wave_sync();
+        }
         for (u32 i = lane; i < sn; i += 64) {
             const uint2 pi = key_pair(s, arena, i);
             u32 r = 0;
-            for (u32 j = 0; j < sn; ++j) r += key_pair(s, arena, j).x < pi.x;
+            if (in_lds) {
+                u32 j = 0;
+                for (; j + 4u <= sn; j += 4u) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(&sx[w][j]);
+                    r += (v.x < pi.x ? 1u : 0u) + (v.y < pi.x ? 1u : 0u) + (v.z < pi.x ? 1u : 0u) + (v.w < pi.x ? 1u : 0u);
+                }
+                for (; j < sn; ++j) r += sx[w][j] < pi.x ? 1u : 0u;
+            } else {
+                for (u32 j = 0; j < sn; ++j) r += key_pair(s, arena, j).x < pi.x;
+            }
             indices[dst + r] = (int)pi.x;
             data[dst + r] = (int)pi.y;
             bad |= pi.x >= n_loci || (pi.y >> n_haps) != 0u;
         }
+        if (in_lds) wave_sync();                   // (the next row of this wave overwrites the copy)
     }
     if (bad) atomicOr(&ctr->err, ERR_RANGE);
 }
