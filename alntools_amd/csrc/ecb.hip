@@ -53,6 +53,7 @@ constexpr int TPB = 256;             // threads per workgroup (4 waves of 64)
 constexpr u32 MAX_PROBE = 256;       // EC-table probes before a read is deferred to k_slow
 constexpr u32 PENDING = 0xFFFFFFFFu;
 constexpr u32 ARENA_CHUNK = 512;     // pairs a wave reserves from the key arena per global atomic
+constexpr u32 QSTRIPES = 64;         // the deferred-read queue is filled in this many stripes, each with a counter of its own (queue_defer)
 constexpr u32 ARENA_REGIONS = 64;    // the key arena has this many allocation cursors (see arena_alloc)
 constexpr u32 MAX_LOCI = (1u << 26) - 2u;         // k_stream's LDS keys hold locus + 1 below the read's index within the pass: 26 bits (k_stream.inc) ...
 constexpr u32 MAX_LOCI_SHORT = (1u << 25) - 2u;   // ... 25 in the kernel for short reads (seven bits of read index)
@@ -98,7 +99,8 @@ static_assert(sizeof(Entry) == 32, "exchange format");
 struct Counters {
     u64 all, valid;                  // records offered / passing the filter
     u64 arena_top;                   // pairs placed by ecb_table_adopt_device (dense from 0; an adopting handle allocates nothing else)
-    u64 n_queue;                     // reads deferred to k_slow
+    u64 n_queue;                     // reads deferred to k_slow (k_sum_counts: the sum over the stripes below)
+    u64 n_queue_s[QSTRIPES];         // ... counted per stripe of the queue (queue_defer)
     u64 n_ecs;                       // ECs created by k_slow / k_merge (k_stream's are counted by k_collect_new)
     u32 err;
     u32 full;                        // set when a read found no EC-table slot: workgroups park, host grows the table
@@ -312,6 +314,17 @@ struct StreamCold {
     // ECB_F_RANGES (k_stream<false, true>): reference_start of every record and the per-(locus, haplotype) extremes
     const int* pos; int2* rng; u32 n_loci, n_haps;     // rng[locus * n_haps + hap] = {min, max}: one 8-byte load per record
 };
+// A read k_stream hands to k_slow (longer than a pass carries, or bounced off a full table): its head goes into one of QSTRIPES stretches of the
+// queue, picked by a hash of the head, each with its own counter.  (One counter for all: a stream with 1 % of reads of 700 loci made 200 k
+// atomics on one address -- ~75 ns apiece at the memory side, in order: 15 ms on a 1 ms kernel, sat out by whatever the waves waited for next.
+// profiles/r04_long_reads.txt)  k_queue_compact closes the stretches up for k_slow.
+__device__ __forceinline__ void queue_defer(Counters* ctr, const StreamCold* C, u64 head) {
+    const u32 st = (u32)((head * 0x9E3779B97F4A7C15ull) >> 58);
+    static_assert(QSTRIPES == 64, "six bits of the hash pick the stripe");
+    const u64 seg = C->queue_cap / QSTRIPES;
+    const u64 qi = atomicAdd(&ctr->n_queue_s[st], 1ull);
+    if (qi < seg) C->queue[(u64)st * seg + qi] = head; else atomicOr(&ctr->err, ERR_QUEUE);
+}
 // Phases of k_stream can be switched off at run time in a profiling build (libecb_ablate.so: tools/pmc_ladder.sh, tools_ablate.sh);
 // the product build has the tests compiled out -- they cost a scalar register and a handful of branches per tile.
 #ifdef ECB_ABLATE_RT
@@ -459,9 +472,10 @@ __global__ void k_init_resume(u64* resume, u64 slices, u64 chunk, Counters* ctr 
     const u64 b = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (b < slices) { resume[2 * b] = b * chunk; resume[2 * b + 1] = b * chunk; }
     if (b == 0 && ctr) { ctr->n_queue = 0; ctr->full = 0; ctr->next_slice = 0; }
+    if (b < QSTRIPES && ctr) ctr->n_queue_s[b] = 0;
 }
 
-__global__ __launch_bounds__(1024) void k_sum_counts(const u32* wave_counts, u64 waves, Counters* ctr, u32 verify, u64 offered, const u32* d_last = nullptr) {
+__global__ __launch_bounds__(1024) void k_sum_counts(const u32* wave_counts, u64 waves, Counters* ctr, u32 verify, u64 offered, u64 queue_cap, const u32* d_last = nullptr) {
     __shared__ u64 s[3][16];
     u64 a = 0, v = 0, e = 0;
     for (u64 i = threadIdx.x; i < waves; i += 1024) { a += wave_counts[3 * i]; v += wave_counts[3 * i + 1]; e += wave_counts[3 * i + 2]; }
@@ -475,7 +489,18 @@ __global__ __launch_bounds__(1024) void k_sum_counts(const u32* wave_counts, u64
         if (verify) ctr->n_mismatch += e;                  // the exactness pass counts differing reads, and recounts nothing
         else { ctr->all += offered; ctr->valid += v; ctr->n_ecs += e; ctr->n_probe_tiles += a; }
         if (d_last) ctr->last_rid = *d_last;
+        u64 nq = 0;                                        // deferred reads: what the stripes of the queue hold (a stripe that ran over has said so: ERR_QUEUE)
+        for (u32 st = 0; st < QSTRIPES; ++st) nq += min(ctr->n_queue_s[st], queue_cap / QSTRIPES);
+        ctr->n_queue = nq;
     }
+}
+// the stripes of the deferred-read queue, closed up: one workgroup per stripe
+__global__ void k_queue_compact(const u64* queue, u64 queue_cap, const Counters* ctr, u64* out) {
+    const u64 seg = queue_cap / QSTRIPES;
+    u64 at = 0;
+    for (u32 st = 0; st < blockIdx.x; ++st) at += min(ctr->n_queue_s[st], seg);
+    const u64 n = min(ctr->n_queue_s[blockIdx.x], seg);
+    for (u64 i = threadIdx.x; i < n; i += blockDim.x) out[at + i] = queue[(u64)blockIdx.x * seg + i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2394,7 +2419,7 @@ struct ecb_handle {
     enum { P_RESUME, P_SUMS, P_HIST, P_OFFS, P_PAIRS, P_CNT, P_PARTS, P_STARTS, P_WORK, P_LIST, P_BITMAP, P_WPOP, P_WPREFIX, P_ROWLEN, P_ORDER,
            P_WCOUNTS, P_RANK, P_INDPTR, P_COUNTS, P_INDICES, P_DATA, P_MS_KEYS, P_MS_KEYS2, P_MS_VALS, P_MS_VALS2, P_MS_TMP,
            P_MS_FLAG, P_MS_POS, P_MS_OKEY, P_MS_OFIRST, P_MS_OSTART, P_MS_X, P_MS_OCOUNT, P_MS_GRANK, P_MS_CIN, P_MS_FIN, P_LISTFN,
-           P_REMAP, P_TOTALS, P_SLOW_LEN, P_SLOW_OFF, P_SLOW_NRE, P_SLOW_REQ, P_SLOW_REQ2, P_SLOW_KEY, P_SLOW_MASK, P_BIG, P_RS_HIST, P_RS_OFFS, P_RS_SUMS,
+           P_REMAP, P_TOTALS, P_SLOW_LEN, P_SLOW_OFF, P_SLOW_NRE, P_SLOW_REQ, P_SLOW_REQ2, P_QCOMPACT, P_SLOW_KEY, P_SLOW_MASK, P_BIG, P_RS_HIST, P_RS_OFFS, P_RS_SUMS,
            P_F_CELLS, P_F_IPA, P_F_IXA, P_F_DAA, P_F_IPN, P_F_IXN, P_F_DAN, P_EXPORT, P_N };
     void* pool[P_N] = {}; u64 pool_bytes[P_N] = {};
 
@@ -2604,6 +2629,18 @@ int plan_stream(ecb_handle* h, u64 n, StreamPlan* P, bool ranges = false, bool s
     return ECB_OK;
 }
 
+// the reads a k_stream launch deferred (h->hctr.n_queue of them, in the stripes of h->queue), closed up and handed to k_slow
+int run_deferred(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d_hf, u64 n, bool verify, u32 tw, u64* n_done = nullptr) {
+    const u64 nq = h->hctr.n_queue;
+    if (n_done) *n_done = nq;
+    if (!nq) return ECB_OK;
+    u64* d_q = nullptr;
+    POOL(h, P_QCOMPACT, d_q, nq);
+    k_queue_compact<<<QSTRIPES, TPB, 0, h->stream>>>(h->queue, h->queue_cap, h->ctr, d_q);
+    HIPCHK(h, hipGetLastError());
+    return run_slow(h, d_rid, d_loc, d_hf, n, d_q, nq, verify, tw);
+}
+
 // The exactness pass over one device-resident batch (whole reads, read ids continuing from prev_rid): every read's target
 // set is derived again from its records and compared, pair by pair, with the key of the EC the read was given.
 // Reads longer than a tile go through k_slow's compare.  *n_mismatch = reads in a wrong EC (0 = exact); *n_long = how many
@@ -2616,7 +2653,7 @@ int verify_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d
     POOL(h, P_RESUME, d_resume, 2 * P.slices); POOL(h, P_WCOUNTS, d_wcounts, 3 * P.pwaves);
     k_init_resume<<<nblk(P.slices, TPB), TPB, 0, h->stream>>>(d_resume, P.slices, P.chunk);
     HIPCHK(h, hipMemsetAsync(d_wcounts, 0, 3 * P.pwaves * sizeof(u32), h->stream));
-    HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));
+    HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, (1 + QSTRIPES) * sizeof(u64), h->stream));      // (the total and the stripes' counters behind it)
     HIPCHK(h, hipMemsetAsync(&h->ctr->full, 0, sizeof(u32), h->stream));
     HIPCHK(h, hipMemsetAsync(&h->ctr->next_slice, 0, sizeof(u64), h->stream));
     HIPCHK(h, hipMemsetAsync(&h->ctr->n_mismatch, 0, sizeof(u64), h->stream));
@@ -2625,18 +2662,16 @@ int verify_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* d
     HIPCHK(h, hipMemcpyAsync(h->d_cold, h->pin_cold, sizeof(StreamCold), hipMemcpyHostToDevice, h->stream));
     StreamArgs a{d_rid, d_loc, d_hf, n, h->table, h->cap - 1, h->ctr, h->read_slot, h->reads_hi, h->d_cold, 0u};
     ks_std::k_stream<true><<<(unsigned)P.blocks, TPB, 0, h->stream>>>(a);
-    k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, P.pwaves, h->ctr, 1u, 0ull);
+    k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, P.pwaves, h->ctr, 1u, 0ull, h->queue_cap);
     HIPCHK(h, hipGetLastError());
     rc = sync_counters(h);
     if (rc != ECB_OK) return rc;
-    const u64 nq = std::min<u64>(h->hctr.n_queue, h->queue_cap);
-    if (nq) {
-        rc = run_slow(h, d_rid, d_loc, d_hf, n, h->queue, nq, true, tw);
-        if (rc != ECB_OK) return rc;
-    }
+    u64 nq = 0;
+    rc = run_deferred(h, d_rid, d_loc, d_hf, n, true, tw, &nq);
+    if (rc != ECB_OK) return rc;
     *n_mismatch = h->hctr.n_mismatch;
     *n_long = nq;
-    HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));
+    HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, (1 + QSTRIPES) * sizeof(u64), h->stream));
     h->hctr.n_queue = 0;
     return ECB_OK;
 }
@@ -2706,7 +2741,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     u64 offered = n;                                    // records offered to the filter (bam_utils.py:261): all of the batch
     for (u32 launch = 0;; ++launch) {
         if (launch) {                                   // per launch (the first one's: k_init_resume)
-            HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, sizeof(u64), h->stream));
+            HIPCHK(h, hipMemsetAsync(&h->ctr->n_queue, 0, (1 + QSTRIPES) * sizeof(u64), h->stream));
             HIPCHK(h, hipMemsetAsync(&h->ctr->full, 0, sizeof(u32), h->stream));
             HIPCHK(h, hipMemsetAsync(&h->ctr->next_slice, 0, sizeof(u64), h->stream));
         }
@@ -2717,7 +2752,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
         else if (par) { ks_par::k_stream<false><<<(unsigned)blocks, TPB, 0, h->stream>>>(a); h->last_kernel = "ks_par::k_stream<false, false>"; }
         else { ks_std::k_stream<false><<<(unsigned)blocks, TPB, 0, h->stream>>>(a); h->last_kernel = "ks_std::k_stream<false, false>"; }
         if (h->prof) hipEventRecord(h->ev1, h->stream);
-        k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, pwaves, h->ctr, 0u, offered, d_rid + rec_at(n - 1, tw));
+        k_sum_counts<<<1, 1024, 0, h->stream>>>(d_wcounts, pwaves, h->ctr, 0u, offered, h->queue_cap, d_rid + rec_at(n - 1, tw));
         offered = 0;                                    // (a relaunch after a park continues the same batch)
         HIPCHK(h, hipGetLastError());
         rc = sync_counters(h);
@@ -2727,10 +2762,8 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
         }
         if (rc != ECB_OK) break;
         const bool parked = h->hctr.full != 0;
-        if (h->hctr.n_queue) {
-            rc = run_slow(h, d_rid, d_loc, d_hf, n, h->queue, std::min<u64>(h->hctr.n_queue, h->queue_cap), false, tw);
-            if (rc != ECB_OK) break;
-        }
+        rc = run_deferred(h, d_rid, d_loc, d_hf, n, false, tw);
+        if (rc != ECB_OK) break;
         if (!parked) break;
         rc = grow_table(h, h->cap * 4);                 // some workgroups stopped early: more room, then resume
         if (rc != ECB_OK) break;
