@@ -245,6 +245,39 @@ __device__ __forceinline__ void ranked_pairs(const SlotView& v, const uint2* are
         }
     }
 }
+// ... and of a longer key, by one wave: emit(rank, locus, mask) once per pair.  The loci are ranked out of LDS -- the wave's copy of them (`sx`: BIG_LDS
+// words), read four at a time, every lane the same address -- where a rank used to be a walk over the key in global memory per pair: 700 x 700
+// loads for a read of 700 loci (k_emit_big 6 ms for the 39 k long ECs of tools/slow_path.py; profiles/r04_long_reads.txt).  Keys of more than
+// BIG_LDS pairs walk the key in memory as before.
+constexpr u32 BIG_LDS = 2048;                   // 8 KB per wave
+template <class F>
+__device__ __forceinline__ void ranked_pairs_wave(const Slot& s, const uint2* arena, u32 sn, u32* sx, u32 lane, F&& emit) {
+    const bool in_lds = sn <= BIG_LDS;
+    if (in_lds) {
+        for (u32 i = lane; i < sn; i += 64) sx[i] = key_pair(s, arena, i).x;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (u32 i = lane; i < sn; i += 64) {
+        const uint2 pi = key_pair(s, arena, i);
+        u32 r = 0;
+        if (in_lds) {
+            u32 j = 0;
+            for (; j + 4u <= sn; j += 4u) {
+                const uint4 v = *reinterpret_cast<const uint4*>(&sx[j]);
+                r += (v.x < pi.x ? 1u : 0u) + (v.y < pi.x ? 1u : 0u) + (v.z < pi.x ? 1u : 0u) + (v.w < pi.x ? 1u : 0u);
+            }
+            for (; j < sn; ++j) r += sx[j] < pi.x ? 1u : 0u;
+        } else {
+            for (u32 j = 0; j < sn; ++j) r += key_pair(s, arena, j).x < pi.x;        // loci within a key are distinct
+        }
+        emit(r, pi.x, pi.y);
+    }
+    if (in_lds) {                                  // (the wave's next key overwrites the copy)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
 template <class Cmp>
 __device__ __forceinline__ int table_lookup(Slot* table, u64 cap_mask, u64 lo, u64& j, u32& probes, const Cmp& cmp, u32 abl = 0u, u32* first_inv_seen = nullptr) {
     for (; probes < MAX_PROBE; ++probes, j = (j + 1) & cap_mask) {
@@ -1181,17 +1214,13 @@ __global__ __launch_bounds__(TPB) void k_parts_export(const Slot* table, const u
 }
 // long keys of an export: one wave per key, rank = number of smaller loci
 __global__ __launch_bounds__(TPB) void k_parts_sort_big(const Slot* table, const uint2* arena, const u64* big, u32 n_big, uint2* out_p) {
+    __shared__ __attribute__((aligned(16))) u32 sx[TPB / 64][BIG_LDS];
     const u32 b = (blockIdx.x * TPB + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
     if (b >= n_big) return;
     const u64 po = big[2 * (u64)b];
     const u32 n = (u32)big[2 * (u64)b + 1];
     const Slot& s = table[big[2 * (u64)b + 1] >> 32];
-    for (u32 i = lane; i < n; i += 64) {
-        const uint2 pi = key_pair(s, arena, i);
-        u32 r = 0;
-        for (u32 k = 0; k < n; ++k) r += key_pair(s, arena, k).x < pi.x;
-        out_p[po + r] = pi;
-    }
+    ranked_pairs_wave(s, arena, n, sx[threadIdx.x >> 6], lane, [&](u32 r, u32 x, u32 y) { out_p[po + r] = make_uint2(x, y); });
 }
 // adopt: entries known to be distinct ECs go to consecutive slots of an empty table, no hashing.  The pair list was copied to
 // the arena at arena_base as it is: the slot takes its first INL pairs, the rest stay where they are.
@@ -1516,9 +1545,6 @@ __global__ __launch_bounds__(TPB) void k_emit_small(const Slot* table, const uin
     }
     if (bad) atomicOr(&ctr->err, ERR_RANGE);
 }
-// (A long row's loci are ranked out of LDS -- the wave's copy of them, read four at a time, every lane the same address -- where a rank used to be
-//  a walk over the key in global memory per pair: 700 x 700 loads for a read of 700 loci, 6 ms for the 39 k long ECs of tools/slow_path.py.)
-constexpr u32 BIG_LDS = 2048;                   // loci of a row ranked out of LDS: 8 KB per wave; longer rows walk the key in memory as before
 __global__ __launch_bounds__(TPB) void k_emit_big(const Slot* table, const u32* order, const u32* big, const u32* n_big,
                                                    const uint2* arena, const u32* indptr, int* indices, int* data,
                                                    u32 n_loci, u32 n_haps, Counters* ctr) {
@@ -1528,31 +1554,12 @@ __global__ __launch_bounds__(TPB) void k_emit_big(const Slot* table, const u32* 
     for (u32 b = (blockIdx.x * TPB + threadIdx.x) >> 6; b < nb; b += (gridDim.x * TPB) >> 6) {
         const u32 e = big[b];
         const Slot& s = table[order[e]];
-        const u32 sn = s.n1 - 1u;
         const u32 dst = indptr[e];
-        const bool in_lds = sn <= BIG_LDS;
-        if (in_lds) {
-            for (u32 i = lane; i < sn; i += 64) sx[w][i] = key_pair(s, arena, i).x;
-            wave_sync();
-        }
-        for (u32 i = lane; i < sn; i += 64) {
-            const uint2 pi = key_pair(s, arena, i);
-            u32 r = 0;
-            if (in_lds) {
-                u32 j = 0;
-                for (; j + 4u <= sn; j += 4u) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(&sx[w][j]);
-                    r += (v.x < pi.x ? 1u : 0u) + (v.y < pi.x ? 1u : 0u) + (v.z < pi.x ? 1u : 0u) + (v.w < pi.x ? 1u : 0u);
-                }
-                for (; j < sn; ++j) r += sx[w][j] < pi.x ? 1u : 0u;
-            } else {
-                for (u32 j = 0; j < sn; ++j) r += key_pair(s, arena, j).x < pi.x;
-            }
-            indices[dst + r] = (int)pi.x;
-            data[dst + r] = (int)pi.y;
-            bad |= pi.x >= n_loci || (pi.y >> n_haps) != 0u;
-        }
-        if (in_lds) wave_sync();                   // (the next row of this wave overwrites the copy)
+        ranked_pairs_wave(s, arena, s.n1 - 1u, sx[w], lane, [&](u32 r, u32 x, u32 y) {
+            indices[dst + r] = (int)x;
+            data[dst + r] = (int)y;
+            bad |= x >= n_loci || (y >> n_haps) != 0u;
+        });
     }
     if (bad) atomicOr(&ctr->err, ERR_RANGE);
 }

@@ -1375,3 +1375,58 @@ def test_rows_of_every_length_leave_in_column_order(ec_capacity):
     assert rows.max() == 24 and rows.min() == 1
     for a, b in zip(out["indptrA"][:-1], out["indptrA"][1:]):
         assert np.all(np.diff(out["indicesA"][a:b]) > 0)
+
+
+def test_long_keys_through_export_merge_and_adopt():
+    """Reads of 3, 30, 300 and 900 loci (keys that fit the slot, continue in the arena, take a wave of their own when exported, and
+    the long-read path of the stream kernel) in two shards that share some of their ECs: every shard cut into key ranges, the ranges
+    merged and adopted by a root as the multi-GPU protocol does (``alntools_amd/dist.py``; the reference's ordered merge,
+    ``bam_utils.py:680-724``) == one handle over both shards == the oracle."""
+    import torch
+    from alntools_amd import dist as ecdist
+    dev = torch.device("cuda:0")
+    T, H, P = 60000, 8, 3
+    rng = np.random.default_rng(77)
+
+    def shard(seed_bases, first_rid):
+        recs, rid = [], first_rid
+        for k, base in enumerate(seed_bases):
+            n = (3, 30, 300, 900)[k % 4]
+            loci = base + np.arange(n) * 2
+            haps = rng.integers(0, H, size=n)
+            order = rng.permutation(n)
+            recs += [(rid, int(loci[j]), int(haps[j]), 0) for j in order]
+            recs += [(rid, int(loci[0]), int((haps[0] + 1) % H), 0)]              # one locus with two haplotypes
+            rid += 1
+        return recs
+    bases_a = [int(b) for b in rng.integers(0, T - 2000, size=40)]
+    bases_b = bases_a[:12] + [int(b) for b in rng.integers(0, T - 2000, size=28)]        # twelve ECs... of the same loci -- but the haplotypes are drawn anew: mostly new ECs, same loci
+    ra, rb = shard(bases_a, 0), shard(bases_b, 0)
+    both = _hand(ra + [(r + 40, l, h, f) for (r, l, h, f) in rb] + [(80 + r, l, h, f) for (r, l, h, f) in ra[:len(ra) // 2]], H)     # + the first shard's first half again: shared ECs for certain
+    shards = [_hand(ra, H), _hand(rb + [(40 + r, l, h, f) for (r, l, h, f) in ra[:len(ra) // 2]], H)]
+    exp = _expect(both, T, H)
+    pieces, sizes, base = [], [], 0
+    for t in shards:
+        b = ecb.EcBuilder(T, H, ec_capacity=1 << 10)
+        b.push(t["read_id"], t["locus"], t["hapflag"])
+        eng = ecdist.GpuEngine(b, dev)
+        nreads = b.table_sizes()[2]
+        pieces.append(eng.table_export_parts(base, P))
+        sizes.append((nreads,) + b.counters()[:2])
+        base += nreads
+        b.close()
+    root = ecdist.GpuEngine(ecb.EcBuilder(T, H, ec_capacity=1 << 10), dev)
+    for q in range(P):
+        part = ecdist.GpuEngine(ecb.EcBuilder(T, H, ec_capacity=1 << 10), dev)
+        tabs = [(ent[eoff[q] * 4:eoff[q + 1] * 4], eoff[q + 1] - eoff[q], prs[poff[q]:poff[q + 1]], poff[q + 1] - poff[q])
+                for ent, prs, eoff, poff in pieces if eoff[q + 1] > eoff[q]]
+        part.table_merge_many(tabs)
+        pe_n, pp_n, _ = part.table_sizes()
+        pe, pp = part.table_export(0)
+        root.table_adopt(pe, pe_n, pp, pp_n)
+        part.b.close()
+    root.add_counters(sum(s[1] for s in sizes), sum(s[2] for s in sizes), base)
+    s = root.b.finalize()
+    _check(root.b.export(), s, exp)
+    assert int(np.diff(exp["indptr"]).max()) == 900 and s["n_reads"] == base
+    root.b.close()
