@@ -374,6 +374,10 @@ struct StreamArgs {
     u64 reads_hi;                    // read_slot holds [0, reads_hi): a read index beyond it is a broken run counter
     const StreamCold* cold;
     u32 ablate;                      // profiling builds only (-DECB_ABLATE_RT, env ECB_ABLATE): 1 = stop after (a), 2 = after (b), 4 = no EC table, 8 / 16 / 32 see table_lookup
+    // ECB_F_RANGES (k_stream<false, true>) reads these two HERE and not behind `cold`: a pointer loaded from memory has no address space the compiler
+    // knows, and the position stream and the range table were FLAT loads and atomics (57 of them in that compilation); the other compilations never
+    // touch the two words, which then cost them nothing
+    const int* pos; int2* rng;
 };
 // Words from one tile of a stream to the next: 512 = three arrays (ecb_push_device); 1536 = whole tiles, a tile's 512 read ids, 512 loci and 512
 // haplotype/flag words side by side (ecb_push_device_tiled: rid = base, loc = base + 512, hf = base + 1024).  Read off the pointers -- three arrays
@@ -2742,7 +2746,7 @@ int process_batch(ecb_handle* h, const u32* d_rid, const u32* d_loc, const u32* 
     *h->pin_cold = cold;      // (pinned: rewritten by the next batch, which starts after this one's host wait)
     HIPCHK(h, hipMemcpyAsync(h->d_cold, h->pin_cold, sizeof(StreamCold), hipMemcpyHostToDevice, h->stream));
     StreamArgs a{d_rid, d_loc, d_hf, n, h->table, h->cap - 1, h->ctr, h->read_slot, h->reads_hi, h->d_cold,
-                 getenv("ECB_ABLATE") ? (u32)atoi(getenv("ECB_ABLATE")) : 0u};
+                 getenv("ECB_ABLATE") ? (u32)atoi(getenv("ECB_ABLATE")) : 0u, d_pos, h->rng};
     h->ctr_synced = false;
     const u64 probe_before = h->hctr.n_probe_tiles;
     u64 offered = n;                                    // records offered to the filter (bam_utils.py:261): all of the batch
